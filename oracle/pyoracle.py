@@ -1,0 +1,274 @@
+"""ctypes binding of the CPU ORACLE (oracle/libdcreg_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under dcreg_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libdcreg_oracle.so")
+
+DET = {"NONE_DETE": 0, "SCHUR_CONDITION_NUMBER": 1, "FULL_EVD_MIN_EIGENVALUE": 2,
+       "EVD_SUB_CONDITION": 3, "FULL_SVD_CONDITION": 4}
+HAND = {"NONE_HAND": 0, "STANDARD_REGULARIZATION": 1, "ADAPTIVE_REGULARIZATION": 2,
+        "PRECONDITIONED_CG": 3, "SOLUTION_REMAPPING": 4, "TRUNCATED_SVD": 5}
+# method-name -> (detection, handling): DCReg/config/icp.yaml:101-116
+METHODS = {
+    "ME-SR": ("FULL_EVD_MIN_EIGENVALUE", "SOLUTION_REMAPPING"),
+    "ME-TSVD": ("FULL_EVD_MIN_EIGENVALUE", "TRUNCATED_SVD"),
+    "ME-TReg": ("FULL_EVD_MIN_EIGENVALUE", "STANDARD_REGULARIZATION"),
+    "FCN-SR": ("FULL_SVD_CONDITION", "SOLUTION_REMAPPING"),
+    "Ours": ("SCHUR_CONDITION_NUMBER", "PRECONDITIONED_CG"),
+    "NONE": ("NONE_DETE", "NONE_HAND"),
+}
+
+
+class LinParams(C.Structure):
+    _fields_ = [("search_radius", C.c_double), ("max_plane_thickness_sq", C.c_double),
+                ("min_normal_norm", C.c_double), ("weight_slope", C.c_double),
+                ("weight_min", C.c_double), ("use_weight_derivative", C.c_int),
+                ("num_threads", C.c_int)]
+
+
+class LinOut(C.Structure):
+    _fields_ = [("H_upper", C.c_double * 21), ("g", C.c_double * 6), ("sum_r2", C.c_double),
+                ("sum_b2", C.c_double), ("n_eff", C.c_int64), ("n_pt", C.c_int64)]
+
+
+class LinDebug(C.Structure):
+    _fields_ = [("nn_idx", C.POINTER(C.c_int32)), ("nn_d2", C.POINTER(C.c_float)),
+                ("flag", C.POINTER(C.c_uint8)), ("normal", C.POINTER(C.c_double)),
+                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double))]
+
+
+class Config(C.Structure):
+    _fields_ = [("search_radius", C.c_double), ("max_iterations", C.c_int),
+                ("thresh_rot", C.c_double), ("thresh_trans", C.c_double),
+                ("thres_cond", C.c_double), ("thres_eig", C.c_double),
+                ("kappa_target", C.c_double), ("pcg_tolerance", C.c_double),
+                ("pcg_max_iter", C.c_int), ("std_reg_gamma", C.c_double),
+                ("adaptive_reg_alpha", C.c_double), ("use_weight_derivative", C.c_int),
+                ("always_compute_schur", C.c_int), ("num_threads", C.c_int),
+                ("gt", C.c_double * 16)]
+
+
+class Analysis(C.Structure):
+    _fields_ = [("is_degenerate", C.c_int), ("mask", C.c_int * 6),
+                ("cond_schur_rot", C.c_double), ("cond_schur_trans", C.c_double),
+                ("cond_diag_rot", C.c_double), ("cond_diag_trans", C.c_double),
+                ("cond_full", C.c_double), ("cond_full_sub_rot", C.c_double),
+                ("cond_full_sub_trans", C.c_double), ("eigenvalues_full", C.c_double * 6),
+                ("eigenvectors_full", C.c_double * 36), ("singular_values", C.c_double * 6),
+                ("lambda_schur_rot", C.c_double * 3), ("lambda_schur_trans", C.c_double * 3),
+                ("lambda_sub_rot", C.c_double * 3), ("lambda_sub_trans", C.c_double * 3),
+                ("schur_V_rot", C.c_double * 9), ("schur_V_trans", C.c_double * 9),
+                ("P_preconditioner", C.c_double * 36), ("pcg_iterations", C.c_int)]
+
+
+class IterLog(C.Structure):
+    _fields_ = [("iter", C.c_int), ("n_eff", C.c_int64), ("n_pt", C.c_int64),
+                ("rmse", C.c_double), ("fitness", C.c_double), ("objective", C.c_double),
+                ("gradient", C.c_double * 6), ("dx", C.c_double * 6), ("T", C.c_double * 16),
+                ("trans_err", C.c_double), ("rot_err_deg", C.c_double),
+                ("H_upper", C.c_double * 21), ("an", Analysis)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("status", C.c_int),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("cov", C.c_double * 36)]
+
+
+def build(force=False):
+    """Compile the oracle (gcc, seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "dcreg_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "dcreg_oracle.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.orc_kdtree_build.restype = C.c_void_p
+    L.orc_kdtree_build.argtypes = [fp, C.c_int64, C.c_int64]
+    L.orc_kdtree_free.argtypes = [C.c_void_p]
+    L.orc_kdtree_size.restype = C.c_int64
+    L.orc_kdtree_size.argtypes = [C.c_void_p]
+    L.orc_knn.restype = C.c_int
+    L.orc_knn.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
+    L.orc_knn_batch.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, C.c_int, ip, fp, C.c_int]
+    L.orc_colpiv_qr_solve.restype = C.c_int
+    L.orc_colpiv_qr_solve.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+    L.orc_sym_eig.argtypes = [C.c_int, dp, dp, dp]
+    L.orc_inv3_fullpiv.restype = C.c_int
+    L.orc_inv3_fullpiv.argtypes = [dp, dp]
+    L.orc_plane_fit.restype = C.c_int
+    L.orc_plane_fit.argtypes = [dp, dp, dp, dp]
+    L.orc_linearize.restype = C.c_int
+    L.orc_linearize.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, dp, dp, C.POINTER(LinParams),
+                                C.POINTER(LinOut), C.POINTER(LinDebug)]
+    L.orc_unpack_H.argtypes = [dp, dp]
+    L.orc_analyze.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis)]
+    L.orc_solve.argtypes = [dp, dp, C.c_int, C.POINTER(Config), C.POINTER(Analysis), dp]
+    L.orc_pcg.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, C.POINTER(C.c_int)]
+    L.orc_so3_exp.argtypes = [dp, dp]
+    L.orc_boxplus.argtypes = [dp, dp, dp, dp, dp]
+    L.orc_pose6d_to_matrix.argtypes = [C.c_double] * 6 + [dp]
+    L.orc_pose_error.argtypes = [dp, dp, dp, dp]
+    L.orc_default_config.argtypes = [C.POINTER(Config)]
+    L.orc_icp_run.restype = C.c_int
+    L.orc_icp_run.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, dp, dp, C.c_int, C.c_int,
+                              C.POINTER(Config), C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult)]
+    L.orc_p2p_error.argtypes = [fp, C.c_int64, C.c_void_p, fp, C.c_int64, C.c_double, dp, dp, dp,
+                                C.POINTER(C.c_int64)]
+    L.orc_sizeof_iter_log.restype = C.c_size_t
+    L.orc_sizeof_analysis.restype = C.c_size_t
+    assert L.orc_sizeof_iter_log() == C.sizeof(IterLog), "IterLog layout mismatch"
+    assert L.orc_sizeof_analysis() == C.sizeof(Analysis), "Analysis layout mismatch"
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_config(**kw):
+    cfg = Config()
+    lib().orc_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if k == "gt":
+            cfg.gt = (C.c_double * 16)(*np.asarray(v, dtype=np.float64).reshape(16))
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def default_lin_params(search_radius=1.0, use_weight_derivative=0, num_threads=0):
+    return LinParams(search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, use_weight_derivative, num_threads)
+
+
+class KdTree:
+    """Owns an oracle kd-tree over a float32 [n,3] target cloud."""
+
+    def __init__(self, xyz):
+        self.xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self.ptr = lib().orc_kdtree_build(_fp(self.xyz), self.xyz.shape[0], 3)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().orc_kdtree_free(self.ptr)
+            self.ptr = None
+
+    def knn(self, q, k=5, num_threads=0):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), np.int32)
+        d2 = np.empty((q.shape[0], k), np.float32)
+        lib().orc_knn_batch(self.ptr, _fp(q), q.shape[0], 3, k,
+                            idx.ctypes.data_as(C.POINTER(C.c_int32)), _fp(d2), num_threads)
+        return idx, d2
+
+
+def pose6d_to_matrix(roll, pitch, yaw, x, y, z):
+    T = np.empty(16)
+    lib().orc_pose6d_to_matrix(roll, pitch, yaw, x, y, z, _dp(T))
+    return T.reshape(4, 4)
+
+
+def pose_error(gt, T):
+    a, b = C.c_double(), C.c_double()
+    gt = np.ascontiguousarray(gt, np.float64)
+    T = np.ascontiguousarray(T, np.float64)
+    lib().orc_pose_error(_dp(gt), _dp(T), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def unpack_H(H_upper):
+    H = np.empty(36)
+    hu = np.ascontiguousarray(H_upper, np.float64)
+    lib().orc_unpack_H(_dp(hu), _dp(H))
+    return H.reshape(6, 6)
+
+
+def linearize(tree, src, R, t, params=None, debug=False):
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    params = params or default_lin_params()
+    out = LinOut()
+    dbg = None
+    keep = {}
+    if debug:
+        n = src.shape[0]
+        keep = {"nn_idx": np.full((n, 5), -1, np.int32), "nn_d2": np.full((n, 5), np.inf, np.float32),
+                "flag": np.zeros(n, np.uint8), "normal": np.zeros((n, 3)), "r": np.zeros(n),
+                "s": np.zeros(n)}
+        dbg = LinDebug(keep["nn_idx"].ctypes.data_as(C.POINTER(C.c_int32)), _fp(keep["nn_d2"]),
+                       keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8)), _dp(keep["normal"]),
+                       _dp(keep["r"]), _dp(keep["s"]))
+    rc = lib().orc_linearize(tree.ptr, _fp(src), src.shape[0], 3, _dp(R), _dp(t), C.byref(params),
+                             C.byref(out), C.byref(dbg) if dbg is not None else None)
+    assert rc == 0
+    res = {"H_upper": np.array(out.H_upper[:]), "g": np.array(out.g[:]), "sum_r2": out.sum_r2,
+           "sum_b2": out.sum_b2, "n_eff": out.n_eff, "n_pt": out.n_pt}
+    res["H"] = unpack_H(res["H_upper"])
+    res.update(keep)
+    return res
+
+
+def analyze(H, detection, handling, cfg):
+    H = np.ascontiguousarray(H, np.float64).reshape(36)
+    an = Analysis()
+    lib().orc_analyze(_dp(H), DET[detection], HAND[handling], C.byref(cfg), C.byref(an))
+    return an
+
+
+def solve(H, g, handling, cfg, an):
+    H = np.ascontiguousarray(H, np.float64).reshape(36)
+    g = np.ascontiguousarray(g, np.float64).reshape(6)
+    x = np.empty(6)
+    lib().orc_solve(_dp(H), _dp(g), HAND[handling], C.byref(cfg), C.byref(an), _dp(x))
+    return x
+
+
+def icp_run(tree, src, T0, method, cfg, log_capacity=None):
+    """Run the oracle engine; returns (result, [IterLog...])."""
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
+    T0 = np.asarray(T0, np.float64).reshape(4, 4)
+    R0 = np.ascontiguousarray(T0[:3, :3]).reshape(9)
+    t0 = np.ascontiguousarray(T0[:3, 3])
+    det, hand = METHODS[method] if isinstance(method, str) else method
+    cap = log_capacity if log_capacity is not None else cfg.max_iterations
+    logs = (IterLog * max(cap, 1))()
+    res = IcpResult()
+    lib().orc_icp_run(tree.ptr, _fp(src), src.shape[0], 3, _dp(R0), _dp(t0), DET[det], HAND[hand],
+                      C.byref(cfg), logs, cap, C.byref(res))
+    n = min(res.iterations, cap)
+    # an aborted run logs only the completed iterations
+    if res.status == 1:
+        n = min(res.iterations - 1, cap)
+    return res, [logs[i] for i in range(max(n, 0))]
+
+
+def p2p_error(aligned, tree, error_threshold):
+    aligned = np.ascontiguousarray(aligned, np.float32).reshape(-1, 3)
+    r, f, c = C.c_double(), C.c_double(), C.c_double()
+    v = C.c_int64()
+    lib().orc_p2p_error(_fp(aligned), aligned.shape[0], tree.ptr, _fp(tree.xyz), tree.xyz.shape[0],
+                        error_threshold, C.byref(r), C.byref(f), C.byref(c), C.byref(v))
+    return r.value, f.value, c.value, v.value
