@@ -1,0 +1,385 @@
+"""ctypes mirror of include/dcreg.h (the C-ABI of libdcreg_hip.so).
+
+Python is plumbing here: tests, bench.py and multi-GPU launch use this thin binding; the product is the
+shared library.  There is no CPU fallback: creating a Context without a usable HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdcreg_hip.so")
+
+# enum values of DCReg/include/utils.hpp:106-121
+DETECTION = {"NONE_DETE": 0, "SCHUR_CONDITION_NUMBER": 1, "FULL_EVD_MIN_EIGENVALUE": 2,
+             "EVD_SUB_CONDITION": 3, "FULL_SVD_CONDITION": 4}
+HANDLING = {"NONE_HAND": 0, "STANDARD_REGULARIZATION": 1, "ADAPTIVE_REGULARIZATION": 2,
+            "PRECONDITIONED_CG": 3, "SOLUTION_REMAPPING": 4, "TRUNCATED_SVD": 5}
+# method-name dispatch of the YAML test_methods section (DCReg/config/icp.yaml:101-116)
+METHODS = {
+    "ME-SR": ("FULL_EVD_MIN_EIGENVALUE", "SOLUTION_REMAPPING"),
+    "ME-TSVD": ("FULL_EVD_MIN_EIGENVALUE", "TRUNCATED_SVD"),
+    "ME-TReg": ("FULL_EVD_MIN_EIGENVALUE", "STANDARD_REGULARIZATION"),
+    "FCN-SR": ("FULL_SVD_CONDITION", "SOLUTION_REMAPPING"),
+    "Ours": ("SCHUR_CONDITION_NUMBER", "PRECONDITIONED_CG"),
+    "NONE": ("NONE_DETE", "NONE_HAND"),
+}
+
+OK, E_INVALID, E_NOMEM, E_DEVICE, E_STATE = 0, -1, -2, -3, -4
+
+
+class LinParams(C.Structure):
+    _fields_ = [("search_radius", C.c_double), ("max_plane_thickness_sq", C.c_double),
+                ("min_normal_norm", C.c_double), ("weight_slope", C.c_double), ("weight_min", C.c_double),
+                ("use_weight_derivative", C.c_int), ("k", C.c_int)]
+
+
+class LinOut(C.Structure):
+    _fields_ = [("H_upper", C.c_double * 21), ("g", C.c_double * 6), ("sum_r2", C.c_double),
+                ("sum_b2", C.c_double), ("n_eff", C.c_int64), ("n_pt", C.c_int64)]
+
+
+class LinDebug(C.Structure):
+    _fields_ = [("nn_idx", C.POINTER(C.c_int32)), ("nn_d2", C.POINTER(C.c_float)),
+                ("flag", C.POINTER(C.c_uint8)), ("normal", C.POINTER(C.c_double)),
+                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double))]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("cell", C.c_double), ("origin", C.c_double * 3), ("dims", C.c_int32 * 3),
+                ("n_cells", C.c_int64), ("n_target", C.c_int64), ("n_source", C.c_int64),
+                ("max_ring", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("search_radius", C.c_double), ("max_iterations", C.c_int),
+                ("CONVERGENCE_THRESH_ROT", C.c_double), ("CONVERGENCE_THRESH_TRANS", C.c_double),
+                ("DEGENERACY_THRES_COND", C.c_double), ("DEGENERACY_THRES_EIG", C.c_double),
+                ("KAPPA_TARGET", C.c_double), ("PCG_TOLERANCE", C.c_double), ("PCG_MAX_ITER", C.c_int),
+                ("STD_REG_GAMMA", C.c_double), ("ADAPTIVE_REG_ALPHA", C.c_double),
+                ("use_weight_derivative", C.c_int), ("always_compute_schur", C.c_int),
+                ("gt_matrix", C.c_double * 16)]
+
+
+class Analysis(C.Structure):
+    _fields_ = [("isDegenerate", C.c_int), ("degenerate_mask", C.c_int * 6),
+                ("cond_schur_rot", C.c_double), ("cond_schur_trans", C.c_double),
+                ("cond_diag_rot", C.c_double), ("cond_diag_trans", C.c_double),
+                ("cond_full", C.c_double), ("cond_full_sub_rot", C.c_double),
+                ("cond_full_sub_trans", C.c_double), ("eigenvalues_full", C.c_double * 6),
+                ("eigenvectors_full", C.c_double * 36), ("singular_values", C.c_double * 6),
+                ("lambda_schur_rot", C.c_double * 3), ("lambda_schur_trans", C.c_double * 3),
+                ("lambda_sub_rot", C.c_double * 3), ("lambda_sub_trans", C.c_double * 3),
+                ("schur_V_rot", C.c_double * 9), ("schur_V_trans", C.c_double * 9),
+                ("aligned_V_rot", C.c_double * 9), ("aligned_V_trans", C.c_double * 9),
+                ("rot_indices", C.c_int * 3), ("trans_indices", C.c_int * 3),
+                ("P_preconditioner", C.c_double * 36), ("W_adaptive", C.c_double * 36),
+                ("pcg_iterations", C.c_int)]
+
+
+class IterLog(C.Structure):
+    _fields_ = [("iter_count", C.c_int), ("effective_points", C.c_int64), ("corr_pt_count", C.c_int64),
+                ("rmse", C.c_double), ("fitness", C.c_double), ("objective_value", C.c_double),
+                ("gradient", C.c_double * 6), ("update_dx", C.c_double * 6),
+                ("transform_matrix", C.c_double * 16), ("trans_error_vs_gt", C.c_double),
+                ("rot_error_vs_gt", C.c_double), ("iter_time_ms", C.c_double),
+                ("H_upper", C.c_double * 21), ("analysis", Analysis)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("status", C.c_int),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("icp_cov", C.c_double * 36),
+                ("time_ms", C.c_double)]
+
+
+class TrialResult(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("status", C.c_int),
+                ("time_ms", C.c_double), ("trans_error_m", C.c_double), ("rot_error_deg", C.c_double),
+                ("final_rmse", C.c_double), ("final_fitness", C.c_double), ("corr_num", C.c_int64),
+                ("final_transform", C.c_double * 16), ("H_upper", C.c_double * 21),
+                ("degenerate_mask", C.c_int * 6)]
+
+
+_STRUCTS = {"dcreg_lin_params": LinParams, "dcreg_lin_out": LinOut, "dcreg_lin_debug": LinDebug,
+            "dcreg_index_info": IndexInfo, "dcreg_config": Config, "dcreg_analysis": Analysis,
+            "dcreg_iter_log": IterLog, "dcreg_icp_result": IcpResult, "dcreg_trial_result": TrialResult}
+
+# every symbol include/dcreg.h declares
+EXPORTS = [
+    "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
+    "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
+    "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_debug", "dcreg_knn",
+    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
+    "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
+    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
+]
+
+_lib = None
+
+
+class DcregError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree HIP library.  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcregError("libdcreg_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                         "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.dcreg_backend_create.restype = C.c_int
+    L.dcreg_backend_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.dcreg_backend_destroy.restype = None
+    L.dcreg_backend_destroy.argtypes = [vp]
+    L.dcreg_last_error.restype = C.c_char_p
+    L.dcreg_last_error.argtypes = [vp]
+    L.dcreg_set_stream.argtypes = [vp, vp]
+    L.dcreg_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    for name in ("dcreg_set_target", "dcreg_set_target_device"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double]
+    for name in ("dcreg_set_source", "dcreg_set_source_device"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64]
+    L.dcreg_default_lin_params.argtypes = [C.POINTER(LinParams), C.c_double]
+    L.dcreg_linearize.argtypes = [vp, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut)]
+    L.dcreg_linearize_batch.argtypes = [vp, C.c_int, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut)]
+    L.dcreg_linearize_debug.argtypes = [vp, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut), C.POINTER(LinDebug)]
+    L.dcreg_knn.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int, C.c_double, ip, fp]
+    L.dcreg_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.dcreg_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
+    L.dcreg_default_config.restype = None
+    L.dcreg_default_config.argtypes = [C.POINTER(Config)]
+    L.dcreg_analyze_degeneracy.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis)]
+    L.dcreg_solve_degenerate_system.argtypes = [dp, dp, C.c_int, C.POINTER(Config), C.POINTER(Analysis), dp]
+    L.dcreg_unpack_hessian.restype = None
+    L.dcreg_unpack_hessian.argtypes = [dp, dp]
+    L.dcreg_boxplus.restype = None
+    L.dcreg_boxplus.argtypes = [dp, dp, dp, dp, dp]
+    L.dcreg_pose6d_to_matrix.restype = None
+    L.dcreg_pose6d_to_matrix.argtypes = [C.c_double] * 6 + [dp]
+    L.dcreg_pose_error.restype = None
+    L.dcreg_pose_error.argtypes = [dp, dp, dp, dp]
+    L.dcreg_icp_run.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
+                                C.POINTER(IcpResult)]
+    L.dcreg_icp_run_trials.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(TrialResult)]
+    L.dcreg_p2p_error.argtypes = [vp, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int64)]
+    L.dcreg_sizeof.restype = C.c_size_t
+    L.dcreg_sizeof.argtypes = [C.c_char_p]
+    L.dcreg_version.restype = C.c_char_p
+    for name, st in _STRUCTS.items():
+        if L.dcreg_sizeof(name.encode()) != C.sizeof(st):
+            raise DcregError("struct layout mismatch for %s" % name)
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None:
+        a = a.reshape(n)
+    return a
+
+
+def default_config(**kw):
+    cfg = Config()
+    load().dcreg_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if k == "gt_matrix":
+            cfg.gt_matrix = (C.c_double * 16)(*_f64(v, 16))
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            setattr(cfg, k, v)
+    return cfg
+
+
+def default_lin_params(search_radius=1.0, use_weight_derivative=0):
+    p = LinParams()
+    load().dcreg_default_lin_params(C.byref(p), float(search_radius))
+    p.use_weight_derivative = int(use_weight_derivative)
+    return p
+
+
+def unpack_hessian(H_upper):
+    H = np.empty(36)
+    load().dcreg_unpack_hessian(_dp(_f64(H_upper, 21)), _dp(H))
+    return H.reshape(6, 6)
+
+
+def analyze_degeneracy(H, detection, handling, cfg):
+    an = Analysis()
+    rc = load().dcreg_analyze_degeneracy(_dp(_f64(H, 36)), DETECTION[detection], HANDLING[handling], C.byref(cfg), C.byref(an))
+    if rc:
+        raise DcregError("dcreg_analyze_degeneracy rc=%d" % rc)
+    return an
+
+
+def solve_degenerate_system(H, g, handling, cfg, an):
+    x = np.empty(6)
+    rc = load().dcreg_solve_degenerate_system(_dp(_f64(H, 36)), _dp(_f64(g, 6)), HANDLING[handling], C.byref(cfg), C.byref(an), _dp(x))
+    if rc:
+        raise DcregError("dcreg_solve_degenerate_system rc=%d" % rc)
+    return x
+
+
+def boxplus(R, t, dx):
+    Ro, to = np.empty(9), np.empty(3)
+    load().dcreg_boxplus(_dp(_f64(R, 9)), _dp(_f64(t, 3)), _dp(_f64(dx, 6)), _dp(Ro), _dp(to))
+    return Ro.reshape(3, 3), to
+
+
+def pose6d_to_matrix(roll, pitch, yaw, x, y, z):
+    T = np.empty(16)
+    load().dcreg_pose6d_to_matrix(roll, pitch, yaw, x, y, z, _dp(T))
+    return T.reshape(4, 4)
+
+
+def pose_error(gt, T):
+    a, b = C.c_double(), C.c_double()
+    load().dcreg_pose_error(_dp(_f64(gt, 16)), _dp(_f64(T, 16)), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class Context:
+    """One device context (one GPU, one stream).  Stands for ICPContext (utils.hpp:340-425)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.dcreg_backend_create(C.byref(self._h), int(device))
+        if rc != OK:
+            self._h = None
+            raise DcregError("dcreg_backend_create(device=%d) failed with %d: no usable HIP device and no CPU fallback" % (device, rc))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dcreg_backend_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise DcregError("%s failed (%d): %s" % (what, rc, self._L.dcreg_last_error(self._h).decode()))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._L.dcreg_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)), "dcreg_set_stream")
+
+    def set_option(self, key, value):
+        self._check(self._L.dcreg_set_option(self._h, key.encode(), float(value)), "dcreg_set_option")
+
+    def set_target(self, xyz, search_radius):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = a.shape[0], a.shape[1]
+        self._check(self._L.dcreg_set_target(self._h, a.ctypes.data, n, stride, float(search_radius)), "dcreg_set_target")
+
+    def set_source(self, xyz):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        self._check(self._L.dcreg_set_source(self._h, a.ctypes.data, a.shape[0], a.shape[1]), "dcreg_set_source")
+
+    def set_target_device(self, dev_ptr, n, stride, search_radius):
+        self._check(self._L.dcreg_set_target_device(self._h, C.c_void_p(dev_ptr), n, stride, float(search_radius)), "dcreg_set_target_device")
+
+    def set_source_device(self, dev_ptr, n, stride):
+        self._check(self._L.dcreg_set_source_device(self._h, C.c_void_p(dev_ptr), n, stride), "dcreg_set_source_device")
+
+    def index_info(self):
+        info = IndexInfo()
+        self._L.dcreg_index_info_get(self._h, C.byref(info))
+        return info
+
+    @staticmethod
+    def _out_dict(o):
+        d = {"H_upper": np.array(o.H_upper[:]), "g": np.array(o.g[:]), "sum_r2": o.sum_r2, "sum_b2": o.sum_b2,
+             "n_eff": o.n_eff, "n_pt": o.n_pt}
+        d["H"] = unpack_hessian(d["H_upper"])
+        return d
+
+    def linearize(self, R, t, params=None, debug=False):
+        params = params or default_lin_params()
+        R, t = _f64(R, 9), _f64(t, 3)
+        out = LinOut()
+        if not debug:
+            self._check(self._L.dcreg_linearize(self._h, _dp(R), _dp(t), C.byref(params), C.byref(out)), "dcreg_linearize")
+            return self._out_dict(out)
+        n = self.index_info().n_source
+        keep = {"nn_idx": np.full((n, 5), -1, np.int32), "nn_d2": np.full((n, 5), np.inf, np.float32),
+                "flag": np.zeros(n, np.uint8), "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n)}
+        dbg = LinDebug(keep["nn_idx"].ctypes.data_as(C.POINTER(C.c_int32)), keep["nn_d2"].ctypes.data_as(C.POINTER(C.c_float)),
+                       keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8)), _dp(keep["normal"]), _dp(keep["r"]), _dp(keep["s"]))
+        self._check(self._L.dcreg_linearize_debug(self._h, _dp(R), _dp(t), C.byref(params), C.byref(out), C.byref(dbg)), "dcreg_linearize_debug")
+        d = self._out_dict(out)
+        d.update(keep)
+        return d
+
+    def linearize_raw(self, R, t, params, out):
+        """Hot-loop variant: caller-owned float64 arrays / structs, no allocation."""
+        return self._L.dcreg_linearize(self._h, _dp(R), _dp(t), C.byref(params), C.byref(out))
+
+    def linearize_batch(self, Rs, ts, params=None):
+        params = params or default_lin_params()
+        Rs = _f64(Rs).reshape(-1, 9)
+        ts = _f64(ts).reshape(-1, 3)
+        n = Rs.shape[0]
+        outs = (LinOut * n)()
+        self._check(self._L.dcreg_linearize_batch(self._h, n, _dp(Rs), _dp(ts), C.byref(params), outs), "dcreg_linearize_batch")
+        return [self._out_dict(o) for o in outs]
+
+    def knn(self, q, k=5, max_radius=0.0):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), np.int32)
+        d2 = np.empty((q.shape[0], k), np.float32)
+        self._check(self._L.dcreg_knn(self._h, q.ctypes.data_as(C.POINTER(C.c_float)), q.shape[0], 3, k, float(max_radius),
+                                      idx.ctypes.data_as(C.POINTER(C.c_int32)), d2.ctypes.data_as(C.POINTER(C.c_float))), "dcreg_knn")
+        return idx, d2
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_int64()
+        self._L.dcreg_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset))
+        return ms.value, n.value
+
+    def icp_run(self, T0, method, cfg, log_capacity=None):
+        T0 = _f64(T0).reshape(4, 4)
+        R0, t0 = np.ascontiguousarray(T0[:3, :3]).reshape(9), np.ascontiguousarray(T0[:3, 3])
+        det, hand = METHODS[method] if isinstance(method, str) else method
+        cap = cfg.max_iterations if log_capacity is None else log_capacity
+        logs = (IterLog * max(cap, 1))()
+        res = IcpResult()
+        self._check(self._L.dcreg_icp_run(self._h, _dp(R0), _dp(t0), DETECTION[det], HANDLING[hand], C.byref(cfg), logs, cap,
+                                          C.byref(res)), "dcreg_icp_run")
+        n = min(res.iterations, cap)
+        if res.status == 1:
+            n = min(res.iterations - 1, cap)
+        return res, [logs[i] for i in range(max(n, 0))]
+
+    def icp_run_trials(self, T0s, method, cfg):
+        T0s = _f64(T0s).reshape(-1, 4, 4)
+        n = T0s.shape[0]
+        R0 = np.ascontiguousarray(T0s[:, :3, :3]).reshape(n, 9)
+        t0 = np.ascontiguousarray(T0s[:, :3, 3]).reshape(n, 3)
+        det, hand = METHODS[method] if isinstance(method, str) else method
+        res = (TrialResult * max(n, 1))()
+        self._check(self._L.dcreg_icp_run_trials(self._h, n, _dp(R0), _dp(t0), DETECTION[det], HANDLING[hand], C.byref(cfg), res),
+                    "dcreg_icp_run_trials")
+        return [res[i] for i in range(n)]
+
+    def p2p_error(self, T, error_threshold):
+        r, f, ch = C.c_double(), C.c_double(), C.c_double()
+        v = C.c_int64()
+        self._check(self._L.dcreg_p2p_error(self._h, _dp(_f64(T, 16)), float(error_threshold), C.byref(r), C.byref(f), C.byref(ch),
+                                            C.byref(v)), "dcreg_p2p_error")
+        return r.value, f.value, ch.value, v.value

@@ -1,0 +1,64 @@
+"""Build libdcreg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdcreg_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+
+SOURCES = [
+    "device/context.hip",
+    "device/metrics.hip",
+    "host/solver.cpp",
+    "host/engine.cpp",
+]
+HEADERS = ["device/kernels.hpp", "device/context.hpp", "host/linalg.hpp", "host/se3.hpp",
+           "../../include/dcreg.h"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(a, deps):
+    if not os.path.exists(a):
+        return True
+    t = os.path.getmtime(a)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJDIR, s.replace("/", "_") + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
+                   "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+            if s.endswith(".cpp"):
+                cmd[1:1] = ["-x", "c++"]   # pure host translation units
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv, verbose=True))

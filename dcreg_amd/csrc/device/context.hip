@@ -1,0 +1,465 @@
+// Device seam of the C-ABI (include/dcreg.h): owns HBM buffers, the spatial index and the launches.
+// Replaces ICPContext::setTargetCloud (DCReg/include/utils.hpp:393-424) and the per-iteration body of
+// Point2PlaneICP_SO3_OpenMP up to AtA/Atb (DCReg/src/icp_test_runner.cpp:1704-1919).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../../include/dcreg.h"
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace dcreg {
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return DCREG_E_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
+template <typename T>
+static int ensure(dcreg_ctx *c, T *&ptr, size_t &cap, size_t need) {
+    if (need <= cap && ptr) return DCREG_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; cap = 0;
+    size_t n = std::max<size_t>(need, 1);
+    hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
+    if (e != hipSuccess) { c->fail("hipMalloc(%zu B) failed: %s", n * sizeof(T), hipGetErrorString(e)); return DCREG_E_NOMEM; }
+    cap = n;
+    return DCREG_OK;
+}
+
+static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------------ index build
+static int sort_pairs_u32(dcreg_ctx *c, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n, int bits) {
+    size_t tmp = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, bits, c->stream));
+    if (ensure(c, c->sort_tmp, c->sort_tmp_cap, tmp) != DCREG_OK) return DCREG_E_NOMEM;
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, bits, c->stream));
+    return DCREG_OK;
+}
+static int sort_pairs_u64(dcreg_ctx *c, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n) {
+    size_t tmp = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, 63, c->stream));
+    if (ensure(c, c->sort_tmp, c->sort_tmp_cap, tmp) != DCREG_OK) return DCREG_E_NOMEM;
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, 63, c->stream));
+    return DCREG_OK;
+}
+
+static int device_bounds(dcreg_ctx *c, const float4 *pts, int64_t n, double mn[3], double mx[3]) {
+    uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    HIP_TRY(c, hipMemcpyAsync(c->d_scratch, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const unsigned nb = std::min<unsigned>(blocks_for(n, 256), 2048);
+    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, pts, n, c->d_scratch);
+    uint32_t out[6];
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(out[a]); mx[a] = ord2f(out[3 + a]); }
+    return DCREG_OK;
+}
+
+// builds keys/sort/cell_start for the given cell edge; returns number of occupied cells
+static int build_grid_at(dcreg_ctx *c, double h, const double mn[3], const double mx[3], uint32_t *occupied) {
+    const int64_t n = c->n_tgt;
+    GridDev g{};
+    g.h = h; g.inv_h = 1.0 / h;
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    g.nx = (int)std::floor((mx[0] - mn[0]) * g.inv_h) + 1;
+    g.ny = (int)std::floor((mx[1] - mn[1]) * g.inv_h) + 1;
+    g.nz = (int)std::floor((mx[2] - mn[2]) * g.inv_h) + 1;
+    const int64_t n_cells = (int64_t)g.nx * g.ny * g.nz;
+    g.n_pts = (uint32_t)n;
+    if (ensure(c, c->d_keys, c->keys_cap, (size_t)n) || ensure(c, c->d_keys2, c->keys2_cap, (size_t)n) ||
+        ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
+        ensure(c, c->d_cell_start, c->cell_cap, (size_t)n_cells + 1) || ensure(c, c->d_tgt, c->tgt_cap, (size_t)n))
+        return DCREG_E_NOMEM;
+    hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_tgt_raw, n, g, c->d_keys, c->d_vals);
+    int bits = 1;
+    while (((int64_t)1 << bits) < n_cells && bits < 32) ++bits;
+    int rc = sort_pairs_u32(c, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2, (size_t)n, bits);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_tgt_raw, c->d_vals2, n, c->d_tgt);
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, c->d_cell_start, c->d_scratch);
+    HIP_TRY(c, hipMemcpyAsync(occupied, c->d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    g.cell_start = c->d_cell_start;
+    g.pts = c->d_tgt;
+    c->grid = g;
+    c->n_cells = n_cells;
+    return DCREG_OK;
+}
+
+static double cap_cell_for_budget(double h, const double mn[3], const double mx[3], double max_cells) {
+    // enlarge h until the dense grid fits the cell budget
+    for (int it = 0; it < 64; ++it) {
+        const double nx = std::floor((mx[0] - mn[0]) / h) + 1, ny = std::floor((mx[1] - mn[1]) / h) + 1, nz = std::floor((mx[2] - mn[2]) / h) + 1;
+        if (nx * ny * nz <= max_cells && nx < 2e9 && ny < 2e9 && nz < 2e9) return h;
+        h *= 1.26;
+    }
+    return h;
+}
+
+static int build_index(dcreg_ctx *c, double radius_hint) {
+    const int64_t n = c->n_tgt;
+    if (n <= 0) { c->fail("target cloud is empty"); return DCREG_E_INVALID; }
+    double mn[3], mx[3];
+    int rc = device_bounds(c, c->d_tgt_raw, n, mn, mx);
+    if (rc) return rc;
+    for (int a = 0; a < 3; ++a) if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) { c->fail("target cloud has non-finite coordinates"); return DCREG_E_INVALID; }
+    const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
+    const double max_cells = (double)((int64_t)1 << 27);
+    // the radius caps the cell edge (slightly above R so that one ring already covers the radius)
+    const double h_cap = radius_hint > 0.0 ? radius_hint * 1.00001 : ext / std::cbrt((double)n) * 4.0;
+    uint32_t occ = 0;
+    double h = c->opt_cell > 0.0 ? c->opt_cell : h_cap;
+    h = cap_cell_for_budget(h, mn, mx, max_cells);
+    rc = build_grid_at(c, h, mn, mx, &occ);
+    if (rc) return rc;
+    if (c->opt_cell <= 0.0) {
+        // density-adaptive cell: aim at `target_occ` points per occupied cell (surface data: occupancy ~ h^2)
+        const double target_occ = 1.59 * c->opt_cell_factor * c->opt_cell_factor;   // = rho*h^2 at h = factor * r5
+        double m1 = (double)n / std::max<uint32_t>(occ, 1);
+        double h1 = h, expo = 2.0;
+        for (int pass = 0; pass < 2 && m1 > target_occ * 1.3; ++pass) {
+            double h2 = h1 * std::pow(target_occ / m1, 1.0 / expo);
+            h2 = std::max(h2, h_cap / 64.0);
+            h2 = cap_cell_for_budget(h2, mn, mx, max_cells);
+            if (h2 >= h1 * 0.95) break;
+            rc = build_grid_at(c, h2, mn, mx, &occ);
+            if (rc) return rc;
+            const double m2 = (double)n / std::max<uint32_t>(occ, 1);
+            if (m2 < m1 && h2 < h1) expo = std::min(3.0, std::max(1.0, std::log(m1 / m2) / std::log(h1 / h2)));
+            h1 = h2; m1 = m2;
+        }
+    }
+    c->occupied_cells = occ;
+    return DCREG_OK;
+}
+
+static int upload_cloud(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride, bool on_device, float4 *&raw, size_t &raw_cap) {
+    if (!xyz || n < 0 || stride < 3) { c->fail("invalid cloud arguments"); return DCREG_E_INVALID; }
+    if (n >= ((int64_t)1 << 31)) { c->fail("cloud too large (%lld points)", (long long)n); return DCREG_E_INVALID; }
+    if (ensure(c, raw, raw_cap, (size_t)n)) return DCREG_E_NOMEM;
+    if (n == 0) return DCREG_OK;
+    const float *src = xyz;
+    if (!on_device) {
+        if (ensure(c, c->d_stage, c->stage_cap, (size_t)(n * stride))) return DCREG_E_NOMEM;
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage, xyz, sizeof(float) * (size_t)(n * stride), hipMemcpyHostToDevice, c->stream));
+        src = c->d_stage;
+    }
+    hipLaunchKernelGGL(k_pack, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, src, n, stride, raw);
+    HIP_TRY(c, hipGetLastError());
+    return DCREG_OK;
+}
+
+static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride, double radius_hint, bool on_device) {
+    if (!c) return DCREG_E_INVALID;
+    if (n <= 0) { c->fail("target cloud is null or empty"); return DCREG_E_INVALID; }   // icp_test_runner.cpp:1643
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload_cloud(c, xyz, n, stride, on_device, c->d_tgt_raw, c->tgt_raw_cap);
+    if (rc) return rc;
+    c->n_tgt = n;
+    c->radius_hint = radius_hint;
+    rc = build_index(c, radius_hint);
+    if (rc) { c->n_tgt = 0; return rc; }
+    return DCREG_OK;
+}
+
+static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride, bool on_device) {
+    if (!c) return DCREG_E_INVALID;
+    if (n <= 0) { c->fail("measure cloud is null or empty"); return DCREG_E_INVALID; }  // icp_test_runner.cpp:1635
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload_cloud(c, xyz, n, stride, on_device, c->d_src_raw, c->src_raw_cap);
+    if (rc) return rc;
+    // Morton order in the body frame (pose independent)
+    double mn[3], mx[3];
+    rc = device_bounds(c, c->d_src_raw, n, mn, mx);
+    if (rc) return rc;
+    const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
+    const double inv_q = 2097151.0 / ext * 0.999999;
+    if (ensure(c, c->d_mkeys, c->mkeys_cap, (size_t)n) || ensure(c, c->d_mkeys2, c->mkeys2_cap, (size_t)n) ||
+        ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
+        ensure(c, c->d_src, c->src_cap, (size_t)n))
+        return DCREG_E_NOMEM;
+    hipLaunchKernelGGL(k_morton_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
+    rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    c->n_src = n;
+    return DCREG_OK;
+}
+
+// ------------------------------------------------------------------------------------------ linearise
+static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
+    if (!p || !(p->search_radius > 0.0)) { c->fail("invalid linearisation parameters"); return DCREG_E_INVALID; }
+    if (p->k != 5 && p->k != 0) { c->fail("only k = 5 is supported (icp_test_runner.cpp:1722)"); return DCREG_E_INVALID; }
+    a.radius_sq = p->search_radius * p->search_radius;
+    float rf = (float)a.radius_sq;
+    if ((double)rf < a.radius_sq) rf = std::nextafterf(rf, INFINITY);
+    a.radius_sq_f = std::nextafterf(rf, INFINITY);   // candidates with d2 < this may pass the double gate
+    a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm;
+    a.w_slope = p->weight_slope; a.w_min = p->weight_min; a.use_wd = p->use_weight_derivative;
+    int k = 1;
+    while (k < 100000) {
+        const double safe = (double)k * c->grid.h * (1.0 - 1e-9);
+        if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break;
+        ++k;
+    }
+    a.max_ring = k;
+    c->last_max_ring = k;
+    return DCREG_OK;
+}
+
+int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
+                     dcreg_lin_out *outs, dcreg_lin_debug *dbg_host) {
+    if (!c) return DCREG_E_INVALID;
+    if (!R9 || !t3 || !outs || n_poses < 1) { c->fail("null argument"); return DCREG_E_INVALID; }
+    if (c->n_tgt <= 0) { c->fail("KdTree/target index is not set up in context"); return DCREG_E_STATE; }   // :1639
+    if (c->n_src <= 0) { c->fail("measure cloud is not set"); return DCREG_E_STATE; }
+    LinArgs a;
+    int rc = make_lin_args(c, p, a);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t nbx = blocks_for(c->n_src, kBlock);
+    if (ensure(c, c->d_partials, c->partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
+    if ((size_t)n_poses > c->out_cap) {
+        if (c->h_out) (void)hipHostFree(c->h_out);
+        c->h_out = nullptr; c->out_cap = 0;
+        const size_t cap = std::max<size_t>((size_t)n_poses, 64);
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_out, cap * kSlots * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_out, c->h_out, 0));
+        c->out_cap = cap;
+    }
+    PoseArg one{};
+    const PoseArg *d_poses = nullptr;
+    if (n_poses == 1) {
+        std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
+    } else {
+        if (ensure(c, c->d_poses, c->poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
+        c->h_poses.resize((size_t)n_poses);
+        for (int i = 0; i < n_poses; ++i) { std::memcpy(c->h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(c->h_poses[i].t, t3 + 3 * i, sizeof(one.t)); }
+        HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
+        d_poses = c->d_poses;
+    }
+    DebugDev dd{};
+    std::vector<void *> tmp_dev;
+    const int64_t n = c->n_src;
+    if (dbg_host) {
+        auto alloc = [&](size_t bytes, int fill) -> void * {
+            void *p2 = nullptr;
+            if (hipMalloc(&p2, bytes) != hipSuccess) return nullptr;
+            (void)hipMemsetAsync(p2, fill, bytes, c->stream);
+            tmp_dev.push_back(p2);
+            return p2;
+        };
+        if (dbg_host->nn_idx) dd.nn_idx = (int32_t *)alloc(sizeof(int32_t) * 5 * n, 0xFF);
+        if (dbg_host->nn_d2) dd.nn_d2 = (float *)alloc(sizeof(float) * 5 * n, 0);
+        if (dbg_host->flag) dd.flag = (uint8_t *)alloc(n, 0);
+        if (dbg_host->normal) dd.normal = (double *)alloc(sizeof(double) * 3 * n, 0);
+        if (dbg_host->r) dd.r = (double *)alloc(sizeof(double) * n, 0);
+        if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
+    }
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    const dim3 grid(nbx, (unsigned)n_poses);
+    if (dbg_host)
+        hipLaunchKernelGGL(k_linearize<1>, grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+    else
+        hipLaunchKernelGGL(k_linearize<0>, grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(1024), 0, c->stream, c->d_partials, nbx, c->d_out);
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (dbg_host) {
+        if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.nn_d2) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_d2, dd.nn_d2, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.flag) HIP_TRY(c, hipMemcpyAsync(dbg_host->flag, dd.flag, n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.normal) HIP_TRY(c, hipMemcpyAsync(dbg_host->normal, dd.normal, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.r) HIP_TRY(c, hipMemcpyAsync(dbg_host->r, dd.r, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.s) HIP_TRY(c, hipMemcpyAsync(dbg_host->s, dd.s, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (void *p2 : tmp_dev) (void)hipFree(p2);
+    HIP_TRY(c, hipGetLastError());
+    if (c->opt_time_kernels) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->kernel_ms_total += ms; c->kernel_launches += 1;
+    }
+    for (int i = 0; i < n_poses; ++i) {
+        const double *o = c->h_out + (size_t)i * kSlots;
+        std::memcpy(outs[i].H_upper, o, 21 * sizeof(double));
+        std::memcpy(outs[i].g, o + 21, 6 * sizeof(double));
+        outs[i].sum_r2 = o[27]; outs[i].sum_b2 = o[28];
+        outs[i].n_eff = (int64_t)std::llround(o[29]); outs[i].n_pt = (int64_t)std::llround(o[30]);
+    }
+    return DCREG_OK;
+}
+
+// k-NN of arbitrary queries (host pointer) or of the transformed source cloud (q == nullptr)
+int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
+               int32_t *d_idx, float *d_d2) {
+    float bound = INFINITY;
+    int max_ring;
+    if (max_radius > 0.0 && std::isfinite(max_radius)) {
+        const double r2 = max_radius * max_radius;
+        float rf = (float)r2; if ((double)rf < r2) rf = std::nextafterf(rf, INFINITY);
+        bound = std::nextafterf(rf, INFINITY);
+        int kk = 1;
+        while (kk < 100000) { const double s = (double)kk * c->grid.h * (1.0 - 1e-9); if (s * s * (1.0 - 1e-6) >= (double)bound) break; ++kk; }
+        max_ring = kk;
+    } else {
+        bound = 3.0e38f;
+        max_ring = std::max({c->grid.nx, c->grid.ny, c->grid.nz}) + 2;   // unbounded: may sweep the whole grid
+    }
+    PoseArg P{};
+    if (pose) P = *pose;
+    if (k == 1)
+        hipLaunchKernelGGL(k_knn<1>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, c->grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
+    else
+        hipLaunchKernelGGL(k_knn<5>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, c->grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
+    HIP_TRY(c, hipGetLastError());
+    return DCREG_OK;
+}
+
+}  // namespace dcreg
+
+using namespace dcreg;
+
+void dcreg_ctx::fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, sizeof(err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int dcreg_backend_create(dcreg_ctx **out, int device) {
+    if (!out) return DCREG_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        std::fprintf(stderr, "[dcreg] no usable HIP device (%s); this library has no CPU fallback\n",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return DCREG_E_DEVICE;
+    }
+    if (device < 0 || device >= count) return DCREG_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return DCREG_E_DEVICE;
+    dcreg_ctx *c = new (std::nothrow) dcreg_ctx();
+    if (!c) return DCREG_E_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void **)&c->d_scratch, 256) != hipSuccess) {
+        delete c;
+        return DCREG_E_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return DCREG_OK;
+}
+
+void dcreg_backend_destroy(dcreg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
+                    c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_partials, c->d_poses, c->d_scratch, c->sort_tmp,
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *dcreg_last_error(const dcreg_ctx *c) { return c ? c->err : "null context"; }
+
+int dcreg_set_stream(dcreg_ctx *c, void *s) {
+    if (!c) return DCREG_E_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return DCREG_OK;
+}
+
+int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
+    if (!c || !key) return DCREG_E_INVALID;
+    const std::string k(key);
+    if (k == "cell") c->opt_cell = v;
+    else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
+    else if (k == "time_kernels") c->opt_time_kernels = v != 0.0;
+    else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
+    return DCREG_OK;
+}
+
+int dcreg_set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride, double r) { return set_target(c, xyz, n, stride, r, false); }
+int dcreg_set_target_device(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride, double r) { return set_target(c, xyz, n, stride, r, true); }
+int dcreg_set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride) { return set_source(c, xyz, n, stride, false); }
+int dcreg_set_source_device(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride) { return set_source(c, xyz, n, stride, true); }
+
+int dcreg_default_lin_params(dcreg_lin_params *p, double radius) {
+    if (!p) return DCREG_E_INVALID;
+    p->search_radius = radius; p->max_plane_thickness_sq = 0.2 * 0.2; p->min_normal_norm = 1e-6;
+    p->weight_slope = 0.9; p->weight_min = 0.1; p->use_weight_derivative = 0; p->k = 5;
+    return DCREG_OK;
+}
+
+int dcreg_linearize(dcreg_ctx *c, const double R[9], const double t[3], const dcreg_lin_params *p, dcreg_lin_out *out) {
+    return launch_linearize(c, 1, R, t, p, out, nullptr);
+}
+int dcreg_linearize_batch(dcreg_ctx *c, int n, const double *R9, const double *t3, const dcreg_lin_params *p, dcreg_lin_out *outs) {
+    return launch_linearize(c, n, R9, t3, p, outs, nullptr);
+}
+int dcreg_linearize_debug(dcreg_ctx *c, const double R[9], const double t[3], const dcreg_lin_params *p, dcreg_lin_out *out, dcreg_lin_debug *dbg) {
+    return launch_linearize(c, 1, R, t, p, out, dbg);
+}
+
+int dcreg_knn(dcreg_ctx *c, const float *q, int64_t n, int64_t stride, int k, double max_radius, int32_t *idx, float *d2) {
+    if (!c) return DCREG_E_INVALID;
+    if (!q || !idx || !d2 || n < 0 || (k != 1 && k != 5)) { c->fail("invalid k-NN arguments (k must be 1 or 5)"); return DCREG_E_INVALID; }
+    if (c->n_tgt <= 0) { c->fail("target index is not set"); return DCREG_E_STATE; }
+    if (n == 0) return DCREG_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload_cloud(c, q, n, stride, false, c->d_aligned, c->aligned_cap);
+    if (rc) return rc;
+    if (ensure(c, c->d_nn_idx, c->nn_idx_cap, (size_t)n * k) || ensure(c, c->d_nn_d2, c->nn_d2_cap, (size_t)n * k)) return DCREG_E_NOMEM;
+    rc = launch_knn(c, c->d_aligned, n, k, max_radius, nullptr, c->d_nn_idx, c->d_nn_d2);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(idx, c->d_nn_idx, sizeof(int32_t) * (size_t)n * k, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d2, c->d_nn_d2, sizeof(float) * (size_t)n * k, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DCREG_OK;
+}
+
+int dcreg_index_info_get(const dcreg_ctx *c, dcreg_index_info *info) {
+    if (!c || !info) return DCREG_E_INVALID;
+    info->cell = c->grid.h;
+    info->origin[0] = c->grid.ox; info->origin[1] = c->grid.oy; info->origin[2] = c->grid.oz;
+    info->dims[0] = c->grid.nx; info->dims[1] = c->grid.ny; info->dims[2] = c->grid.nz;
+    info->n_cells = c->n_cells; info->n_target = c->n_tgt; info->n_source = c->n_src; info->max_ring = c->last_max_ring;
+    return DCREG_OK;
+}
+
+int dcreg_kernel_time(dcreg_ctx *c, double *ms_total, int64_t *launches, int reset) {
+    if (!c) return DCREG_E_INVALID;
+    if (ms_total) *ms_total = c->kernel_ms_total;
+    if (launches) *launches = c->kernel_launches;
+    if (reset) { c->kernel_ms_total = 0.0; c->kernel_launches = 0; }
+    return DCREG_OK;
+}
+
+}  // extern "C"

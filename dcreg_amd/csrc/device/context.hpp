@@ -1,0 +1,72 @@
+// dcreg_ctx: device state behind the C-ABI.  Stands for ICPContext (DCReg/include/utils.hpp:340-425):
+// the kd-tree becomes a cell-sorted target + cell table in HBM, the per-point scratch vectors become
+// nothing at all (the row of every point lives in registers and is reduced on the fly).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "kernels.hpp"
+
+struct dcreg_lin_params;
+struct dcreg_lin_out;
+struct dcreg_lin_debug;
+
+struct dcreg_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char err[512] = {0};
+
+    // target
+    int64_t n_tgt = 0;
+    float4 *d_tgt_raw = nullptr; size_t tgt_raw_cap = 0;   // original order
+    float4 *d_tgt = nullptr; size_t tgt_cap = 0;           // cell-sorted
+    uint32_t *d_cell_start = nullptr; size_t cell_cap = 0;
+    dcreg::GridDev grid{};
+    int64_t n_cells = 0;
+    uint32_t occupied_cells = 0;
+    double radius_hint = 0.0;
+    int last_max_ring = 0;
+
+    // source
+    int64_t n_src = 0;
+    float4 *d_src_raw = nullptr; size_t src_raw_cap = 0;
+    float4 *d_src = nullptr; size_t src_cap = 0;           // Morton-sorted
+
+    // build scratch
+    float *d_stage = nullptr; size_t stage_cap = 0;
+    uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
+    size_t keys_cap = 0, keys2_cap = 0, vals_cap = 0, vals2_cap = 0;
+    uint64_t *d_mkeys = nullptr, *d_mkeys2 = nullptr; size_t mkeys_cap = 0, mkeys2_cap = 0;
+    uint32_t *d_scratch = nullptr;
+    char *sort_tmp = nullptr; size_t sort_tmp_cap = 0;
+
+    // linearisation
+    double *d_partials = nullptr; size_t partials_cap = 0;
+    dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
+    std::vector<dcreg::PoseArg> h_poses;
+    double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped
+
+    // k-NN / p2p
+    float4 *d_aligned = nullptr; size_t aligned_cap = 0;
+    int32_t *d_nn_idx = nullptr; size_t nn_idx_cap = 0;
+    float *d_nn_d2 = nullptr; size_t nn_d2_cap = 0;
+    double *d_p2p_part = nullptr; size_t p2p_part_cap = 0;
+
+    // options / timing
+    double opt_cell = 0.0, opt_cell_factor = 2.0;
+    bool opt_time_kernels = false;
+    double kernel_ms_total = 0.0;
+    int64_t kernel_launches = 0;
+
+    void fail(const char *fmt, ...);
+};
+
+namespace dcreg {
+int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
+                     dcreg_lin_out *outs, dcreg_lin_debug *dbg_host);
+int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
+               int32_t *d_idx, float *d_d2);
+}  // namespace dcreg

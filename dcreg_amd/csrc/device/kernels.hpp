@@ -1,0 +1,597 @@
+// gfx950 kernels of the DCReg hot path: fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r
+// reduction (DCReg/src/icp_test_runner.cpp:1714-1915), plus the index-build and k-NN utility kernels.
+//
+// Layout in HBM
+//   target : float4 {x,y,z,bits(orig_idx)} sorted by linear grid cell (x fastest) + cell_start[n_cells+1]
+//            -> the three x-adjacent cells of one (y,z) row are ONE contiguous run of points
+//   source : float4 {x,y,z,bits(orig_idx)} sorted by Morton code of the body-frame position, so the 64
+//            lanes of a wave walk neighbouring cells (a rigid pose keeps neighbours neighbours)
+//   partial: double[pose][block][32]  (21 H + 6 g + sum r^2 + sum b^2 + n_eff + n_pt + pad)
+// Arithmetic: k-NN distances float32, non-fused, summed x,y,z in that order (what FLANN's L2 functor does
+// and what the oracle does); everything after the neighbour set is fp64, like the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcreg {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kSlots = 32;           // doubles per partial row
+constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
+
+struct GridDev {
+    double ox, oy, oz;   // origin (min corner)
+    double inv_h, h;
+    int nx, ny, nz;
+    uint32_t n_pts;
+    const uint32_t *cell_start;   // [nx*ny*nz + 1]
+    const float4 *pts;            // sorted target
+};
+
+struct PoseArg { double R[9]; double t[3]; };
+
+struct LinArgs {
+    double radius_sq;             // R^2 in double (gate :1726)
+    float radius_sq_f;            // smallest float >= R^2 (candidate prefilter)
+    double max_thick_sq, min_norm, w_slope, w_min;
+    int use_wd;
+    int max_ring;                 // rings needed to cover the radius
+};
+
+// ---------------------------------------------------------------- k-NN heap (sorted, K entries)
+// key = (float bits of d2) << 32 | original index  -> total order (d2, idx), ties -> lower index.
+template <int K>
+struct Heap {
+    uint64_t key[K];
+    uint32_t pos[K];
+    __device__ __forceinline__ void init(uint64_t bound) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
+    }
+    __device__ __forceinline__ void push(uint64_t k, uint32_t p) {
+        if (k < key[K - 1]) {
+            key[K - 1] = k; pos[K - 1] = p;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool sw = key[j] < key[j - 1];
+                const uint64_t ka = key[j - 1], kb = key[j];
+                const uint32_t pa = pos[j - 1], pb = pos[j];
+                key[j - 1] = sw ? kb : ka; key[j] = sw ? ka : kb;
+                pos[j - 1] = sw ? pb : pa; pos[j] = sw ? pa : pb;
+            }
+        }
+    }
+    __device__ __forceinline__ float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)); }
+};
+
+__device__ __forceinline__ float dist2_nofma(float qx, float qy, float qz, const float4 &c) {
+    const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
+    float d2 = __fmul_rn(dx, dx);
+    d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+    d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+    return d2;
+}
+
+template <int K>
+__device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz,
+                                         Heap<K> &hp) {
+    for (uint32_t p = s; p < e; ++p) {
+        const float4 c = g.pts[p];
+        const float d2 = dist2_nofma(qx, qy, qz, c);
+        hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p);
+    }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
+// Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
+// closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
+// the ball covers the search radius.
+template <int K>
+__device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy, float qz, float bound_f,
+                                           int max_ring, Heap<K> &hp) {
+    hp.init(((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull);
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+    // a query farther than max_ring cells from the grid cannot have a neighbour inside the radius
+    const double lim = (double)max_ring + 1.0;
+    if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
+    const int cx = (int)floor(fx), cy = (int)floor(fy), cz = (int)floor(fz);
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+
+    // ---- rings 0+1: the 3x3 rows of the 3x3x3 block, each row one contiguous run; flattened so the
+    // wave iterates max-over-lanes(total candidates) instead of sum-over-rows(max candidates)
+    {
+        const int x0 = clampi(cx - 1, 0, nx), x1 = clampi(cx + 2, 0, nx);   // [x0, x1)
+        uint32_t rs[9], re[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+            const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz;
+            const int64_t row = ok ? ((int64_t)z * ny + y) * nx : 0;
+            rs[r] = ok ? g.cell_start[row + x0] : 0u;
+            re[r] = ok ? g.cell_start[row + x1] : 0u;
+        }
+        int r = 0;
+        uint32_t p = 0, e = 0;
+        while (true) {
+            while (p >= e && r < 9) {
+                // static selection keeps rs/re in registers
+                uint32_t s_ = 0, e_ = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { if (k == r) { s_ = rs[k]; e_ = re[k]; } }
+                p = s_; e = e_; ++r;
+            }
+            if (p >= e) break;
+            const float4 c = g.pts[p];
+            const float d2 = dist2_nofma(qx, qy, qz, c);
+            hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p);
+            ++p;
+        }
+    }
+    // ---- shells k >= 2 (rare: sparse neighbourhoods, cloud borders)
+    for (int k = 1; k < max_ring; ++k) {
+        // after ring k: every point within k*h (minus a rounding guard) has been seen
+        const double safe = (double)k * g.h * (1.0 - 1e-9);
+        const double safe2 = safe * safe * (1.0 - 1e-6);
+        if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
+        if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
+        const int kk = k + 1;                                   // scan shell kk
+        for (int dz = -kk; dz <= kk; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= nz) continue;
+            for (int dy = -kk; dy <= kk; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= ny) continue;
+                const int64_t row = ((int64_t)z * ny + y) * nx;
+                const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
+                if (full) {
+                    const int x0 = clampi(cx - kk, 0, nx), x1 = clampi(cx + kk + 1, 0, nx);
+                    if (x1 > x0) scan_run<K>(g, g.cell_start[row + x0], g.cell_start[row + x1], qx, qy, qz, hp);
+                } else {
+                    const int xa = cx - kk, xb = cx + kk;
+                    if (xa >= 0 && xa < nx) scan_run<K>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
+                    if (xb >= 0 && xb < nx) scan_run<K>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- 5x3 column-pivoted Householder QR
+// Restates Eigen 3.3.7 ColPivHouseholderQR::compute + solve (icp_test_runner.cpp:1747) for [q_j] x = -1,
+// including the nonzeroPivots() truncation that decides rank-deficient (coplanar-with-origin / constant-
+// zero column) neighbourhoods.  Columns are swapped with selects so everything stays in registers.
+__device__ __forceinline__ void swap_col(double (&a)[5], double (&b)[5], bool doit) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const double ta = a[i], tb = b[i]; a[i] = doit ? tb : ta; b[i] = doit ? ta : tb; }
+}
+__device__ __forceinline__ void swap_d(double &a, double &b, bool doit) { const double ta = a, tb = b; a = doit ? tb : ta; b = doit ? ta : tb; }
+__device__ __forceinline__ void swap_i(int &a, int &b, bool doit) { const int ta = a, tb = b; a = doit ? tb : ta; b = doit ? ta : tb; }
+
+template <int KCOL>
+__device__ __forceinline__ void householder_step(double (&c0)[5], double (&c1)[5], double (&c2)[5], double (&tau)[3],
+                                                 double (&nu)[3], double (&nd)[3]) {
+    // acts on column KCOL (rows KCOL..4) and updates the trailing columns; c0,c1,c2 are the CURRENT columns
+    double(&ck)[5] = (KCOL == 0) ? c0 : (KCOL == 1 ? c1 : c2);
+    double tail = 0.0;
+#pragma unroll
+    for (int i = KCOL + 1; i < 5; ++i) tail += ck[i] * ck[i];
+    const double a0 = ck[KCOL];
+    double beta, t;
+    if (tail <= 2.2250738585072014e-308) {
+        t = 0.0; beta = a0;
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) ck[i] = 0.0;
+    } else {
+        beta = sqrt(a0 * a0 + tail);
+        if (a0 >= 0.0) beta = -beta;
+        const double den = a0 - beta;
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) ck[i] = ck[i] / den;
+        t = (beta - a0) / beta;
+    }
+    tau[KCOL] = t;
+    ck[KCOL] = beta;
+#pragma unroll
+    for (int j = KCOL + 1; j < 3; ++j) {
+        double(&cj)[5] = (j == 1) ? c1 : c2;
+        if (t != 0.0) {
+            double tmp = cj[KCOL];
+#pragma unroll
+            for (int i = KCOL + 1; i < 5; ++i) tmp += ck[i] * cj[i];
+            cj[KCOL] -= t * tmp;
+#pragma unroll
+            for (int i = KCOL + 1; i < 5; ++i) cj[i] -= t * ck[i] * tmp;
+        }
+        if (nu[j] != 0.0) {   // LAPACK norm downdate (lawn176), as Eigen does
+            double tt = fabs(cj[KCOL]) / nu[j];
+            tt = (1.0 + tt) * (1.0 - tt);
+            tt = tt < 0.0 ? 0.0 : tt;
+            const double ratio = nu[j] / nd[j];
+            if (tt * ratio * ratio <= 1.4901161193847656e-08) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = KCOL + 1; i < 5; ++i) s += cj[i] * cj[i];
+                nd[j] = nu[j] = sqrt(s);
+            } else {
+                nu[j] *= sqrt(tt);
+            }
+        }
+    }
+}
+
+// returns x (plane coefficients, unnormalised); Q row j = neighbour j
+__device__ __forceinline__ void plane_fit_qr(const double (&qx)[5], const double (&qy)[5], const double (&qz)[5], double (&x)[3]) {
+    double c0[5], c1[5], c2[5], tau[3], nu[3], nd[3];
+    int p0 = 0, p1 = 1, p2 = 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { c0[i] = qx[i]; c1[i] = qy[i]; c2[i] = qz[i]; }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { s0 += c0[i] * c0[i]; s1 += c1[i] * c1[i]; s2 += c2[i] * c2[i]; }
+    nu[0] = nd[0] = sqrt(s0); nu[1] = nd[1] = sqrt(s1); nu[2] = nd[2] = sqrt(s2);
+    const double mx = fmax(nu[0], fmax(nu[1], nu[2]));
+    const double eps = 2.220446049250313e-16;
+    const double thr_helper = (mx * eps) * (mx * eps) / 5.0;
+    int nz = 3;
+    // k = 0
+    {
+        const bool b1 = nu[1] > nu[0], b2 = nu[2] > (b1 ? nu[1] : nu[0]);
+        const double big = b2 ? nu[2] : (b1 ? nu[1] : nu[0]);
+        if (big * big < thr_helper * 5.0) nz = 0;
+        const bool sw1 = b1 && !b2, sw2 = b2;
+        swap_col(c0, c1, sw1); swap_d(nu[0], nu[1], sw1); swap_d(nd[0], nd[1], sw1); swap_i(p0, p1, sw1);
+        swap_col(c0, c2, sw2); swap_d(nu[0], nu[2], sw2); swap_d(nd[0], nd[2], sw2); swap_i(p0, p2, sw2);
+        householder_step<0>(c0, c1, c2, tau, nu, nd);
+    }
+    // k = 1
+    {
+        const bool b2 = nu[2] > nu[1];
+        const double big = b2 ? nu[2] : nu[1];
+        if (nz == 3 && big * big < thr_helper * 4.0) nz = 1;
+        swap_col(c1, c2, b2); swap_d(nu[1], nu[2], b2); swap_d(nd[1], nd[2], b2); swap_i(p1, p2, b2);
+        householder_step<1>(c0, c1, c2, tau, nu, nd);
+    }
+    // k = 2
+    {
+        if (nz == 3 && nu[2] * nu[2] < thr_helper * 3.0) nz = 2;
+        householder_step<2>(c0, c1, c2, tau, nu, nd);
+    }
+    // solve: c = Q^T rhs (first nz reflectors), back-substitute the leading nz x nz triangle
+    double c[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
+    if (nz > 0 && tau[0] != 0.0) {
+        double tmp = c[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) tmp += c0[i] * c[i];
+        c[0] -= tau[0] * tmp;
+#pragma unroll
+        for (int i = 1; i < 5; ++i) c[i] -= tau[0] * c0[i] * tmp;
+    }
+    if (nz > 1 && tau[1] != 0.0) {
+        double tmp = c[1];
+#pragma unroll
+        for (int i = 2; i < 5; ++i) tmp += c1[i] * c[i];
+        c[1] -= tau[1] * tmp;
+#pragma unroll
+        for (int i = 2; i < 5; ++i) c[i] -= tau[1] * c1[i] * tmp;
+    }
+    if (nz > 2 && tau[2] != 0.0) {
+        double tmp = c[2];
+#pragma unroll
+        for (int i = 3; i < 5; ++i) tmp += c2[i] * c[i];
+        c[2] -= tau[2] * tmp;
+    }
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    // R = [c0[0] c1[0] c2[0]; 0 c1[1] c2[1]; 0 0 c2[2]]
+    if (nz > 2) y2 = c[2] / c2[2];
+    if (nz > 1) y1 = (c[1] - (nz > 2 ? c2[1] * y2 : 0.0)) / c1[1];
+    if (nz > 0) y0 = (c[0] - (nz > 1 ? c1[0] * y1 : 0.0) - (nz > 2 ? c2[0] * y2 : 0.0)) / c0[0];
+    // x[perm[i]] = y[i]
+    x[0] = (p0 == 0) ? y0 : ((p1 == 0) ? y1 : y2);
+    x[1] = (p0 == 1) ? y0 : ((p1 == 1) ? y1 : y2);
+    x[2] = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
+}
+
+// ---------------------------------------------------------------- wave64 sum in lane 63 via DPP
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    int lo = (int)(uint32_t)b, hi = (int)(uint32_t)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    // for the row-masked broadcasts the disabled rows keep "old" = 0 -> they add 0
+    const double o = __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+    return v + o;
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8   -> lane 15 of each row = row total
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3 -> lane 63 = wave total
+    return v;
+}
+
+// XCD-aware block remap: hardware places block b on XCD b%8; give each XCD a contiguous run of query
+// blocks so spatially adjacent (Morton-ordered) queries share that XCD's L2.  Bijective for any n.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    const uint32_t nx = 8u;
+    const uint32_t q = n / nx, r = n % nx, xcd = b % nx, k = b / nx;
+    // XCD x owns q + (x < r) blocks, laid out back to back
+    const uint32_t base = xcd * q + (xcd < r ? xcd : r);
+    return base + k;
+}
+
+// ---------------------------------------------------------------- the fused linearisation kernel
+// MODE 0: reduction only.  MODE 1: also dump per-point results (parity tests).
+struct DebugDev {
+    int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
+};
+
+template <int MODE>
+static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+                                                       PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
+                                                       double *__restrict__ partials, uint32_t n_blocks_x, DebugDev dbg) {
+    __shared__ double tile[kBlock / 64][kSlots];
+    const uint32_t pose_id = blockIdx.y;
+    const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x);
+    const uint32_t i = vb * kBlock + threadIdx.x;
+    PoseArg P;
+    if (poses) P = poses[pose_id]; else P = pose1;
+
+    double acc[31];
+#pragma unroll
+    for (int k = 0; k < 31; ++k) acc[k] = 0.0;
+
+    uint8_t flag = 0;
+    if (i < n_src) {
+        const float4 s4 = src[i];
+        const double px = s4.x, py = s4.y, pz = s4.z;
+        // utils.hpp:630-636: double transform, float store
+        const float qx = (float)(P.R[0] * px + P.R[1] * py + P.R[2] * pz + P.t[0]);
+        const float qy = (float)(P.R[3] * px + P.R[4] * py + P.R[5] * pz + P.t[1]);
+        const float qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
+        Heap<5> hp;
+        knn_search<5>(g, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
+        const bool have5 = hp.pos[4] != kNoIdx;
+        const bool in_radius = have5 && (double)hp.worst_d2() < a.radius_sq;      // :1726
+        if (MODE == 1) {
+            const uint32_t oi = __float_as_uint(s4.w);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const bool ok = hp.pos[j] != kNoIdx;
+                if (dbg.nn_idx) dbg.nn_idx[5 * (size_t)oi + j] = ok ? (int32_t)(uint32_t)hp.key[j] : -1;
+                if (dbg.nn_d2) dbg.nn_d2[5 * (size_t)oi + j] = ok ? __uint_as_float((uint32_t)(hp.key[j] >> 32)) : __builtin_inff();
+            }
+        }
+        if (in_radius) {
+            acc[30] = 1.0;                                                          // :1731
+            double nqx[5], nqy[5], nqz[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const float4 c = g.pts[hp.pos[j]]; nqx[j] = c.x; nqy[j] = c.y; nqz[j] = c.z; }
+            double x[3];
+            plane_fit_qr(nqx, nqy, nqz, x);
+            const double ps = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            flag = 2;
+            if (!(ps < a.min_norm)) {                                               // :1752
+                const double pa = x[0] / ps, pb = x[1] / ps, pc = x[2] / ps, pd = 1.0 / ps;
+                double maxd = 0.0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {                                       // :1763-1770
+                    double d = pa * nqx[j] + pb * nqy[j] + pc * nqz[j] + pd;
+                    d *= d;
+                    maxd = d > maxd ? d : maxd;
+                }
+                flag = 3;
+                if (maxd < a.max_thick_sq) {                                        // :1773
+                    const double r = pa * (double)qx + pb * (double)qy + pc * (double)qz + pd;   // :1774
+                    double s = 1.0 - a.w_slope * fabs(r);                           // :1776
+                    s = s < 0.0 ? 0.0 : s;
+                    double ds = 0.0;
+                    if (a.use_wd && s > 0.0 && s < 1.0) ds = -a.w_slope * (r > 0.0 ? 1.0 : -1.0);   // :1780-1783
+                    if (MODE == 1) {
+                        const uint32_t oi = __float_as_uint(s4.w);
+                        if (dbg.normal) { dbg.normal[3 * (size_t)oi] = pa; dbg.normal[3 * (size_t)oi + 1] = pb; dbg.normal[3 * (size_t)oi + 2] = pc; }
+                        if (dbg.r) dbg.r[oi] = r;
+                        if (dbg.s) dbg.s[oi] = s;
+                    }
+                    flag = 4;
+                    if (s > a.w_min) {                                              // :1785
+                        flag = 1;
+                        const float cxf = (float)(s * pa), cyf = (float)(s * pb), czf = (float)(s * pc);   // :1787-1789
+                        const float cif = (float)(s * r);                                                    // :1790
+                        const double nx = (double)cxf / s, ny = (double)cyf / s, nz = (double)czf / s;      // :1889
+                        // J_r = [ (p x m)^T , m^T ],  m = R^T n   (math_utils.hpp:102-121)
+                        const double m0 = P.R[0] * nx + P.R[3] * ny + P.R[6] * nz;
+                        const double m1 = P.R[1] * nx + P.R[4] * ny + P.R[7] * nz;
+                        const double m2 = P.R[2] * nx + P.R[5] * ny + P.R[8] * nz;
+                        const double w = s + r * ds;                                                         // :1898
+                        double A[6];
+                        A[0] = w * (py * m2 - pz * m1); A[1] = w * (pz * m0 - px * m2); A[2] = w * (px * m1 - py * m0);
+                        A[3] = w * m0; A[4] = w * m1; A[5] = w * m2;
+                        const double b = -(double)cif;                                                       // :1906
+                        int idx = 0;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+#pragma unroll
+                            for (int k = j; k < 6; ++k) acc[idx++] = A[j] * A[k];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[21 + j] = A[j] * b;
+                        acc[27] = r * r;
+                        acc[28] = b * b;
+                        acc[29] = 1.0;
+                    }
+                }
+            }
+        }
+        if (MODE == 1 && dbg.flag) dbg.flag[__float_as_uint(s4.w)] = flag;
+    }
+
+    // wave64 DPP reduction -> lane 63 -> LDS tile -> block partial (fixed order, no float atomics)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 31; ++k) {
+        const double t = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) tile[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSlots) {
+        double t = 0.0;
+        if (threadIdx.x < 31) {
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) t += tile[w][threadIdx.x];
+        }
+        partials[((size_t)pose_id * n_blocks_x + vb) * kSlots + threadIdx.x] = t;
+    }
+}
+
+// one block per pose: sums the block partials in index order, writes 32 doubles to (pinned) out
+static __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out) {
+    __shared__ double sm[32][kSlots + 1];
+    const uint32_t pose_id = blockIdx.x;
+    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 32 groups of 32 lanes
+    const double *base = partials + (size_t)pose_id * n_blocks * kSlots;
+    double t = 0.0;
+    for (uint32_t b = grp; b < n_blocks; b += 32) t += base[(size_t)b * kSlots + j];
+    sm[grp][j] = t;
+    __syncthreads();
+    if (threadIdx.x < kSlots) {
+        double s = 0.0;
+#pragma unroll
+        for (int gidx = 0; gidx < 32; ++gidx) s += sm[gidx][threadIdx.x];
+        out[(size_t)pose_id * kSlots + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------- plain k-NN kernel (p2p metrics, tests)
+template <int K>
+static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict__ q, uint32_t n, GridDev g, float bound_f, int max_ring,
+                                                 PoseArg pose, int apply_pose, int32_t *__restrict__ idx, float *__restrict__ d2) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 s4 = q[i];
+    float qx = s4.x, qy = s4.y, qz = s4.z;
+    if (apply_pose) {   // pcl::transformPointCloud<PointT,double>: double arithmetic, float store
+        const double px = s4.x, py = s4.y, pz = s4.z;
+        qx = (float)(pose.R[0] * px + pose.R[1] * py + pose.R[2] * pz + pose.t[0]);
+        qy = (float)(pose.R[3] * px + pose.R[4] * py + pose.R[5] * pz + pose.t[1]);
+        qz = (float)(pose.R[6] * px + pose.R[7] * py + pose.R[8] * pz + pose.t[2]);
+    }
+    Heap<K> hp;
+    knn_search<K>(g, qx, qy, qz, bound_f, max_ring, hp);
+    const uint32_t oi = __float_as_uint(s4.w);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool ok = hp.pos[j] != kNoIdx;
+        idx[(size_t)oi * K + j] = ok ? (int32_t)(uint32_t)hp.key[j] : -1;
+        d2[(size_t)oi * K + j] = ok ? __uint_as_float((uint32_t)(hp.key[j] >> 32)) : __builtin_inff();
+    }
+}
+
+// ---------------------------------------------------------------- index build kernels
+static __global__ void k_pack(const float *__restrict__ xyz, int64_t n, int64_t stride, float4 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = make_float4(xyz[i * stride], xyz[i * stride + 1], xyz[i * stride + 2], __uint_as_float((uint32_t)i));
+}
+
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ inline float ord2f(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    union { uint32_t u; float f; } cv; cv.u = u; return cv.f;
+}
+
+// bounds[0..2] = min (ordered-uint), bounds[3..5] = max
+static __global__ void k_bounds(const float4 *__restrict__ p, int64_t n, uint32_t *bounds) {
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 c = p[i];
+        mn[0] = fminf(mn[0], c.x); mn[1] = fminf(mn[1], c.y); mn[2] = fminf(mn[2], c.z);
+        mx[0] = fmaxf(mx[0], c.x); mx[1] = fmaxf(mx[1], c.y); mx[2] = fmaxf(mx[2], c.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&bounds[a], f2ord(mn[a])); atomicMax(&bounds[3 + a], f2ord(mx[a])); }
+    }
+}
+
+static __global__ void k_cell_keys(const float4 *__restrict__ p, int64_t n, GridDev g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = p[i];
+    const int cx = clampi((int)floor(((double)c.x - g.ox) * g.inv_h), 0, g.nx - 1);
+    const int cy = clampi((int)floor(((double)c.y - g.oy) * g.inv_h), 0, g.ny - 1);
+    const int cz = clampi((int)floor(((double)c.z - g.oz) * g.inv_h), 0, g.nz - 1);
+    keys[i] = (uint32_t)(((int64_t)cz * g.ny + cy) * g.nx + cx);
+    vals[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+static __global__ void k_morton_keys(const float4 *__restrict__ p, int64_t n, double ox, double oy, double oz, double inv_q,
+                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = p[i];
+    const double fx = ((double)c.x - ox) * inv_q, fy = ((double)c.y - oy) * inv_q, fz = ((double)c.z - oz) * inv_q;
+    const uint64_t ix = (uint64_t)fmin(fmax(fx, 0.0), 2097151.0), iy = (uint64_t)fmin(fmax(fy, 0.0), 2097151.0),
+                   iz = (uint64_t)fmin(fmax(fz, 0.0), 2097151.0);
+    keys[i] = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+    vals[i] = (uint32_t)i;
+}
+
+static __global__ void k_gather4(const float4 *__restrict__ in, const uint32_t *__restrict__ order, int64_t n, float4 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[order[i]];
+}
+
+// cell_start[c] = first sorted position whose key >= c ; sorted keys ascending
+static __global__ void k_cell_start(const uint32_t *__restrict__ keys, int64_t n, int64_t n_cells, uint32_t *__restrict__ cell_start,
+                             uint32_t *__restrict__ n_occupied) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const int64_t lo = (i == 0) ? 0 : (int64_t)keys[i - 1] + 1;
+    const int64_t hi = (i == n) ? n_cells : (int64_t)keys[i];
+    for (int64_t c = lo; c <= hi; ++c) cell_start[c] = (uint32_t)i;
+    if (i < n && (i == 0 || keys[i] != keys[i - 1])) atomicAdd(n_occupied, 1u);
+}
+
+// reductions for dcreg_p2p_error: sum sqrt(d2), sum d2 [dist<thr], count  (deterministic two-stage)
+static __global__ __launch_bounds__(kBlock) void k_p2p_partial(const float *__restrict__ d2, int64_t n, float thr, double *__restrict__ part) {
+    __shared__ double tile[kBlock / 64][4];
+    double s_d = 0.0, s_sq = 0.0, cnt = 0.0;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const float v = d2[i];
+        if (v < __builtin_inff()) {
+            const float dist = sqrtf(v);            // std::sqrt(float), utils.hpp:557
+            s_d = (double)dist;
+            if ((double)dist < (double)thr) { s_sq = (double)v; cnt = 1.0; }
+        }
+    }
+    s_d = wave_sum_to_lane63(s_d); s_sq = wave_sum_to_lane63(s_sq); cnt = wave_sum_to_lane63(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) { tile[wave][0] = s_d; tile[wave][1] = s_sq; tile[wave][2] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += tile[w][threadIdx.x];
+        part[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+    }
+}
+
+}  // namespace dcreg

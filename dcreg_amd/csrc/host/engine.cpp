@@ -1,0 +1,182 @@
+// Engine seam: the SO(3) point-to-plane ICP loop of TestRunner::Point2PlaneICP_SO3_OpenMP
+// (DCReg/src/icp_test_runner.cpp:1611-2060) with steps 1-5 of every iteration replaced by ONE call into
+// the device seam (dcreg_linearize), and the num_runs loop of TestRunner::runMethod (:331-390) as a
+// lock-step batch over independent trials (dcreg_icp_run_trials).
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/dcreg.h"
+#include "se3.hpp"
+
+namespace dcreg {
+bool invertSpd6(const double H[36], double inv[36]);
+}
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+inline dcreg_lin_params lin_params_of(const dcreg_config &cfg) {
+    dcreg_lin_params p;
+    dcreg_default_lin_params(&p, cfg.search_radius);
+    p.use_weight_derivative = cfg.use_weight_derivative;
+    return p;
+}
+
+// steps 6-9 of one iteration for one state; returns 0 continue, 1 converged, 2 abort (non-finite)
+struct StepOut { dcreg_analysis an; double dx[6]; double H[36]; };
+inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const dcreg_config &cfg, double R[9], double t[3], StepOut &so) {
+    dcreg_unpack_hessian(lo.H_upper, so.H);
+    dcreg_analyze_degeneracy(so.H, detection, handling, &cfg, &so.an);                 // :1922-1923
+    dcreg_solve_degenerate_system(so.H, lo.g, handling, &cfg, &so.an, so.dx);          // :1940
+    for (double v : so.dx) if (!std::isfinite(v)) return 2;                            // :1942-1950
+    dcreg::boxplus(R, t, so.dx, R, t);                                                 // :1953
+    const double dr = std::sqrt(so.dx[0] * so.dx[0] + so.dx[1] * so.dx[1] + so.dx[2] * so.dx[2]);
+    const double dt = std::sqrt(so.dx[3] * so.dx[3] + so.dx[4] * so.dx[4] + so.dx[5] * so.dx[5]);
+    return (dr < cfg.CONVERGENCE_THRESH_ROT && dt < cfg.CONVERGENCE_THRESH_TRANS) ? 1 : 0;   // :1998
+}
+
+inline void covariance_of(bool converged, const double Hlast[36], double cov[36]) {   // :2014-2037
+    for (int i = 0; i < 36; ++i) cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
+    if (!converged) return;
+    double inv[36];
+    if (dcreg::invertSpd6(Hlast, inv)) std::memcpy(cov, inv, sizeof(inv));
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
+                  const dcreg_config *cfg, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
+    if (!ctx || !R0 || !t0 || !cfg || !res) return DCREG_E_INVALID;
+    std::memset(res, 0, sizeof(*res));
+    const auto t_total = Clock::now();
+    double R[9], t[3], Hlast[36];
+    std::memcpy(R, R0, sizeof(R)); std::memcpy(t, t0, sizeof(t));
+    for (int i = 0; i < 36; ++i) Hlast[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    const dcreg_lin_params prm = lin_params_of(*cfg);
+    dcreg_index_info info;
+    dcreg_index_info_get(ctx, &info);
+    if (info.n_source <= 0 || info.n_target <= 0) {   // :1635-1646
+        res->status = 3;
+        std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
+        covariance_of(false, Hlast, res->icp_cov);
+        return DCREG_OK;
+    }
+    for (int it = 0; it < cfg->max_iterations; ++it) {
+        const auto t_iter = Clock::now();
+        dcreg_lin_out lo;
+        const int rc = dcreg_linearize(ctx, R, t, &prm, &lo);
+        if (rc != DCREG_OK) return rc;
+        if (lo.n_eff < 10) {                            // :1847-1854
+            res->iterations = it + 1; res->converged = 0; res->status = 1;
+            break;
+        }
+        StepOut so;
+        const int st = host_step(lo, detection, handling, *cfg, R, t, so);
+        if (st == 2) { res->iterations = it; res->converged = 0; res->status = 2; break; }
+        std::memcpy(Hlast, so.H, sizeof(Hlast));
+        if (log && it < log_capacity) {
+            dcreg_iter_log &L = log[it];
+            std::memset(&L, 0, sizeof(L));
+            L.iter_count = it;
+            L.effective_points = lo.n_eff; L.corr_pt_count = lo.n_pt;
+            L.fitness = (double)lo.n_pt / (double)info.n_source;          // :1856
+            L.rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);             // :1858
+            L.objective_value = 0.5 * lo.sum_b2;                          // :1919
+            for (int i = 0; i < 6; ++i) { L.gradient[i] = -lo.g[i]; L.update_dx[i] = so.dx[i]; }   // :1918
+            dcreg::stateToMatrix(R, t, L.transform_matrix);               // :1954
+            dcreg::poseError(cfg->gt_matrix, L.transform_matrix, &L.trans_error_vs_gt, &L.rot_error_vs_gt);   // :1976
+            std::memcpy(L.H_upper, lo.H_upper, sizeof(L.H_upper));
+            L.analysis = so.an;
+            L.iter_time_ms = ms_since(t_iter);                            // :1973
+        }
+        res->iterations = it + 1;
+        if (st == 1) { res->converged = 1; break; }
+    }
+    std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
+    covariance_of(res->converged != 0, Hlast, res->icp_cov);
+    res->time_ms = ms_since(t_total);
+    return DCREG_OK;
+}
+
+int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const double *t0, int detection, int handling,
+                         const dcreg_config *cfg, dcreg_trial_result *results) {
+    if (!ctx || !R0 || !t0 || !cfg || !results || n_trials < 0) return DCREG_E_INVALID;
+    if (n_trials == 0) return DCREG_OK;
+    const auto t_total = Clock::now();
+    const dcreg_lin_params prm = lin_params_of(*cfg);
+    dcreg_index_info info;
+    dcreg_index_info_get(ctx, &info);
+    std::vector<double> R((size_t)n_trials * 9), t((size_t)n_trials * 3);
+    std::memcpy(R.data(), R0, sizeof(double) * 9 * (size_t)n_trials);
+    std::memcpy(t.data(), t0, sizeof(double) * 3 * (size_t)n_trials);
+    std::vector<int> live((size_t)n_trials);
+    for (int i = 0; i < n_trials; ++i) { live[(size_t)i] = i; std::memset(&results[i], 0, sizeof(results[i])); }
+    if (info.n_source <= 0 || info.n_target <= 0) {
+        for (int i = 0; i < n_trials; ++i) results[i].status = 3;
+        return DCREG_OK;
+    }
+    std::vector<double> Rb, tb;
+    std::vector<dcreg_lin_out> outs;
+    for (int it = 0; it < cfg->max_iterations && !live.empty(); ++it) {
+        const int nl = (int)live.size();
+        Rb.resize((size_t)nl * 9); tb.resize((size_t)nl * 3); outs.resize((size_t)nl);
+        for (int j = 0; j < nl; ++j) {
+            std::memcpy(&Rb[(size_t)j * 9], &R[(size_t)live[(size_t)j] * 9], sizeof(double) * 9);
+            std::memcpy(&tb[(size_t)j * 3], &t[(size_t)live[(size_t)j] * 3], sizeof(double) * 3);
+        }
+        const int rc = dcreg_linearize_batch(ctx, nl, Rb.data(), tb.data(), &prm, outs.data());
+        if (rc != DCREG_OK) return rc;
+        std::vector<int> next;
+        next.reserve((size_t)nl);
+        for (int j = 0; j < nl; ++j) {
+            const int id = live[(size_t)j];
+            dcreg_trial_result &tr = results[id];
+            const dcreg_lin_out &lo = outs[(size_t)j];
+            if (lo.n_eff < 10) { tr.iterations = it + 1; tr.status = 1; continue; }
+            StepOut so;
+            const int st = host_step(lo, detection, handling, *cfg, &R[(size_t)id * 9], &t[(size_t)id * 3], so);
+            if (st == 2) { tr.iterations = it; tr.status = 2; continue; }
+            tr.iterations = it + 1;
+            tr.final_rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);
+            tr.final_fitness = (double)lo.n_pt / (double)info.n_source;
+            tr.corr_num = lo.n_eff;
+            std::memcpy(tr.H_upper, lo.H_upper, sizeof(tr.H_upper));
+            std::memcpy(tr.degenerate_mask, so.an.degenerate_mask, sizeof(tr.degenerate_mask));
+            if (st == 1) { tr.converged = 1; continue; }
+            next.push_back(id);
+        }
+        live.swap(next);
+    }
+    const double total_ms = ms_since(t_total);
+    for (int i = 0; i < n_trials; ++i) {
+        dcreg_trial_result &tr = results[i];
+        dcreg::stateToMatrix(&R[(size_t)i * 9], &t[(size_t)i * 3], tr.final_transform);
+        dcreg::poseError(cfg->gt_matrix, tr.final_transform, &tr.trans_error_m, &tr.rot_error_deg);   // :501-503
+        tr.time_ms = total_ms / (double)n_trials;   // amortised: trials advance together
+    }
+    return DCREG_OK;
+}
+
+size_t dcreg_sizeof(const char *name) {
+    if (!name) return 0;
+    if (!std::strcmp(name, "dcreg_lin_params")) return sizeof(dcreg_lin_params);
+    if (!std::strcmp(name, "dcreg_lin_out")) return sizeof(dcreg_lin_out);
+    if (!std::strcmp(name, "dcreg_lin_debug")) return sizeof(dcreg_lin_debug);
+    if (!std::strcmp(name, "dcreg_index_info")) return sizeof(dcreg_index_info);
+    if (!std::strcmp(name, "dcreg_config")) return sizeof(dcreg_config);
+    if (!std::strcmp(name, "dcreg_analysis")) return sizeof(dcreg_analysis);
+    if (!std::strcmp(name, "dcreg_iter_log")) return sizeof(dcreg_iter_log);
+    if (!std::strcmp(name, "dcreg_icp_result")) return sizeof(dcreg_icp_result);
+    if (!std::strcmp(name, "dcreg_trial_result")) return sizeof(dcreg_trial_result);
+    return 0;
+}
+
+const char *dcreg_version(void) { return "dcreg-mi355x 0.1.0 (gfx950)"; }
+
+}  // extern "C"

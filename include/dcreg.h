@@ -1,0 +1,231 @@
+/*
+ * dcreg.h -- C-ABI of the MI355X-native DCReg hot path (libdcreg_hip.so).
+ *
+ * The reference (JokerJohn/DCReg) has no FFI layer: the point-to-plane ICP inner loop sits behind two
+ * C++ seams.  This header is the drop-in boundary a maintainer binds instead:
+ *
+ *   device seam  (steps 1-5 of one ICP iteration, DCReg/src/icp_test_runner.cpp:1704-1919)
+ *       ICPContext::setTargetCloud           DCReg/include/utils.hpp:393-424     -> dcreg_set_target
+ *       measure_cloud argument               DCReg/include/icp_test_runner.h:92  -> dcreg_set_source
+ *       correspondence + plane fit + A,b + AtA/Atb   icp_test_runner.cpp:1714-1915 -> dcreg_linearize
+ *   solver seam  (host, 6x6)
+ *       DCReg::analyzeDegeneracy             DCReg/include/dcreg.hpp:45-166      -> dcreg_analyze_degeneracy
+ *       DCReg::solveDegenerateSystem         DCReg/include/dcreg.hpp:168-264     -> dcreg_solve_degenerate_system
+ *   engine seam
+ *       TestRunner::Point2PlaneICP_SO3_OpenMP  icp_test_runner.h:92-102, icp_test_runner.cpp:1611-2060
+ *                                                                                 -> dcreg_icp_run
+ *       TestRunner::runMethod num_runs loop  icp_test_runner.cpp:331-390         -> dcreg_icp_run_trials
+ *       calculatePointToPointError           utils.hpp:538-589                   -> dcreg_p2p_error
+ *
+ * Conventions: plain pointers and sizes only; the caller owns host buffers (borrowed for the call);
+ * a ctx owns its device memory, stream and events; return 0 = ok, <0 = error; a ctx is
+ * single-threaded (one per GPU / stream), several may run concurrently.  Results are deterministic
+ * (fixed reduction order, no floating-point atomics).  There is NO CPU fallback: without a usable
+ * HIP device every device-seam call fails with DCREG_E_DEVICE.
+ */
+#ifndef DCREG_H
+#define DCREG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCREG_OK 0
+#define DCREG_E_INVALID (-1)
+#define DCREG_E_NOMEM (-2)
+#define DCREG_E_DEVICE (-3)
+#define DCREG_E_STATE (-4)
+
+/* DetectionMethod / HandlingMethod: numeric values follow DCReg/include/utils.hpp:106-121 */
+enum dcreg_detection {
+    DCREG_NONE_DETE = 0,
+    DCREG_SCHUR_CONDITION_NUMBER = 1,
+    DCREG_FULL_EVD_MIN_EIGENVALUE = 2,
+    DCREG_EVD_SUB_CONDITION = 3,
+    DCREG_FULL_SVD_CONDITION = 4
+};
+enum dcreg_handling {
+    DCREG_NONE_HAND = 0,
+    DCREG_STANDARD_REGULARIZATION = 1,
+    DCREG_ADAPTIVE_REGULARIZATION = 2,
+    DCREG_PRECONDITIONED_CG = 3,
+    DCREG_SOLUTION_REMAPPING = 4,
+    DCREG_TRUNCATED_SVD = 5
+};
+
+typedef struct dcreg_ctx dcreg_ctx;
+
+/* constants of one linearisation; defaults = the literals in icp_test_runner.cpp */
+typedef struct dcreg_lin_params {
+    double search_radius;          /* Config::search_radius, icp_test_runner.cpp:1725 */
+    double max_plane_thickness_sq; /* 0.2*0.2, :1772 */
+    double min_normal_norm;        /* 1e-6,    :1750 */
+    double weight_slope;           /* 0.9,     :1776 */
+    double weight_min;             /* 0.1,     :1785 */
+    int use_weight_derivative;     /* USE_WEIGHT_DERIVATIVE, :1691 (0 = released source, 1 = paper) */
+    int k;                         /* 5 (only value supported) */
+} dcreg_lin_params;
+
+typedef struct dcreg_lin_out {
+    double H_upper[21]; /* A^T A, row-major upper triangle, order [wx wy wz x y z] (hessian_computer.h:89-94) */
+    double g[6];        /* A^T b  (the reference logs gradient = -g, :1918) */
+    double sum_r2;      /* sum r^2 over effective points (:1803) -> rmse */
+    double sum_b2;      /* sum (float(s r))^2 -> objective = 0.5*sum_b2 (:1919) */
+    int64_t n_eff;      /* correspondence_count (:1802) */
+    int64_t n_pt;       /* correspondence_pt_count (:1731) -> fitness */
+} dcreg_lin_out;
+
+/* per-point dump for parity tests (original source order; any pointer may be NULL).
+ * flag: 1 valid, 0 radius/knn gate, 2 |x|<min_normal_norm, 3 plane thickness, 4 weight<=weight_min */
+typedef struct dcreg_lin_debug {
+    int32_t *nn_idx; /* [5*n] original target indices, ascending (d2, idx); -1 = none */
+    float *nn_d2;    /* [5*n] */
+    uint8_t *flag;   /* [n] */
+    double *normal;  /* [3*n] */
+    double *r;       /* [n] */
+    double *s;       /* [n] */
+} dcreg_lin_debug;
+
+typedef struct dcreg_index_info {
+    double cell;        /* grid cell edge (m) */
+    double origin[3];
+    int32_t dims[3];
+    int64_t n_cells;
+    int64_t n_target;
+    int64_t n_source;
+    int32_t max_ring;   /* rings needed to cover search_radius of the last linearisation */
+} dcreg_index_info;
+
+/* ---------------- device seam ---------------- */
+int dcreg_backend_create(dcreg_ctx **out, int device);
+void dcreg_backend_destroy(dcreg_ctx *);
+const char *dcreg_last_error(const dcreg_ctx *);
+/* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream */
+int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
+/* options: "cell" (force grid cell edge, 0 = auto), "cell_factor" (auto = factor * est. 5th-NN distance),
+ * "time_kernels" (1 = bracket every linearisation with HIP events) */
+int dcreg_set_option(dcreg_ctx *, const char *key, double value);
+/* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
+ * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */
+int dcreg_set_target(dcreg_ctx *, const float *xyz, int64_t n, int64_t stride_floats, double search_radius_hint);
+int dcreg_set_target_device(dcreg_ctx *, const float *d_xyz, int64_t n, int64_t stride_floats, double search_radius_hint);
+int dcreg_set_source(dcreg_ctx *, const float *xyz, int64_t n, int64_t stride_floats);
+int dcreg_set_source_device(dcreg_ctx *, const float *d_xyz, int64_t n, int64_t stride_floats);
+int dcreg_default_lin_params(dcreg_lin_params *, double search_radius);
+/* one ICP linearisation (steps 1-5): R row-major 3x3, t 3 */
+int dcreg_linearize(dcreg_ctx *, const double R[9], const double t[3], const dcreg_lin_params *, dcreg_lin_out *);
+/* the same for n_poses independent poses of the same cloud pair in ONE launch (Monte-Carlo trials) */
+int dcreg_linearize_batch(dcreg_ctx *, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *,
+                          dcreg_lin_out *outs);
+int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], const dcreg_lin_params *,
+                          dcreg_lin_out *, dcreg_lin_debug *);
+/* exact k-NN (k = 1 or 5) of host queries against the target index; float sq. distances, (d2, idx) order */
+int dcreg_knn(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_floats, int k, double max_radius,
+              int32_t *idx, float *d2);
+int dcreg_index_info_get(const dcreg_ctx *, dcreg_index_info *);
+/* mean duration (ms, HIP events on the ctx stream) of the linearisation kernels since the last reset */
+int dcreg_kernel_time(dcreg_ctx *, double *ms_total, int64_t *launches, int reset);
+
+/* ---------------- solver seam (host only, no device needed) ---------------- */
+/* Config + ICPParameters subset (utils.hpp:82-171) */
+typedef struct dcreg_config {
+    double search_radius;
+    int max_iterations;
+    double CONVERGENCE_THRESH_ROT, CONVERGENCE_THRESH_TRANS;
+    double DEGENERACY_THRES_COND, DEGENERACY_THRES_EIG;
+    double KAPPA_TARGET, PCG_TOLERANCE;
+    int PCG_MAX_ITER;
+    double STD_REG_GAMMA, ADAPTIVE_REG_ALPHA;
+    int use_weight_derivative;  /* additive key: icp_test_runner.cpp:1691 as a switch */
+    int always_compute_schur;   /* additive key: fill Schur/diag numbers for every method (paper traces) */
+    double gt_matrix[16];       /* row-major */
+} dcreg_config;
+
+/* DegeneracyAnalysisResult (utils.hpp:427-448) */
+typedef struct dcreg_analysis {
+    int isDegenerate;
+    int degenerate_mask[6];
+    double cond_schur_rot, cond_schur_trans;
+    double cond_diag_rot, cond_diag_trans;
+    double cond_full;
+    double cond_full_sub_rot, cond_full_sub_trans;
+    double eigenvalues_full[6];   /* ascending */
+    double eigenvectors_full[36]; /* row-major, column i <-> eigenvalue i */
+    double singular_values[6];    /* descending */
+    double lambda_schur_rot[3], lambda_schur_trans[3];
+    double lambda_sub_rot[3], lambda_sub_trans[3];
+    double schur_V_rot[9], schur_V_trans[9];
+    double aligned_V_rot[9], aligned_V_trans[9];
+    int rot_indices[3], trans_indices[3];
+    double P_preconditioner[36];
+    double W_adaptive[36];
+    int pcg_iterations;
+} dcreg_analysis;
+
+void dcreg_default_config(dcreg_config *);
+int dcreg_analyze_degeneracy(const double H[36], int detection, int handling, const dcreg_config *, dcreg_analysis *);
+int dcreg_solve_degenerate_system(const double H[36], const double g[6], int handling, const dcreg_config *,
+                                  dcreg_analysis *, double x[6]);
+void dcreg_unpack_hessian(const double H_upper[21], double H[36]);
+void dcreg_boxplus(const double R[9], const double t[3], const double dx[6], double R_out[9], double t_out[3]);
+void dcreg_pose6d_to_matrix(double roll, double pitch, double yaw, double x, double y, double z, double T[16]);
+void dcreg_pose_error(const double gt[16], const double T[16], double *trans_m, double *rot_deg);
+
+/* ---------------- engine seam ---------------- */
+/* IterationLogData (utils.hpp:174-249) */
+typedef struct dcreg_iter_log {
+    int iter_count;
+    int64_t effective_points, corr_pt_count;
+    double rmse, fitness, objective_value;
+    double gradient[6];
+    double update_dx[6];
+    double transform_matrix[16];
+    double trans_error_vs_gt, rot_error_vs_gt;
+    double iter_time_ms;
+    double H_upper[21];
+    dcreg_analysis analysis;
+} dcreg_iter_log;
+
+typedef struct dcreg_icp_result {
+    int converged;
+    int iterations;
+    int status;        /* 0 ok, 1 n_eff<10 abort (:1847), 2 non-finite dx abort (:1942), 3 bad input (:1635) */
+    double R[9], t[3];
+    double icp_cov[36];
+    double time_ms;
+} dcreg_icp_result;
+
+int dcreg_icp_run(dcreg_ctx *, const double R0[9], const double t0[3], int detection, int handling,
+                  const dcreg_config *, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *);
+
+/* TestResult subset per trial (utils.hpp:253-303) */
+typedef struct dcreg_trial_result {
+    int converged, iterations, status;
+    double time_ms;
+    double trans_error_m, rot_error_deg;
+    double final_rmse, final_fitness;
+    int64_t corr_num;
+    double final_transform[16];
+    double H_upper[21];
+    int degenerate_mask[6];
+} dcreg_trial_result;
+
+/* n_trials independent ICP runs of the same cloud pair from different initial poses, advanced in
+ * lock-step so every iteration of all live trials is ONE batched launch. */
+int dcreg_icp_run_trials(dcreg_ctx *, int n_trials, const double *R0_9, const double *t0_3, int detection,
+                         int handling, const dcreg_config *, dcreg_trial_result *results);
+
+/* calculatePointToPointError (utils.hpp:538-589): aligned = T * source (float), both directions on the GPU */
+int dcreg_p2p_error(dcreg_ctx *, const double T[16], double error_threshold, double *rmse, double *fitness,
+                    double *chamfer, int64_t *valid_correspondences);
+
+size_t dcreg_sizeof(const char *struct_name);
+const char *dcreg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCREG_H */
