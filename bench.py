@@ -85,7 +85,9 @@ def main():
                              CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0,   # fixed-length runs
                              use_weight_derivative=1, always_compute_schur=1)
     prm = api.default_lin_params(radius, 1)
-    T_init = h.pose6d_matrix(**h.PAPER_INIT)
+    # initial misalignment of every run: a few cm / tenths of a degree (frame-to-frame LiDAR odometry regime);
+    # the synthetic pair converges from it, so every iteration keeps ~all correspondences alive
+    T_init = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
     L = api.load()
     import ctypes as C
     dp = C.POINTER(C.c_double)
@@ -182,25 +184,35 @@ def cpu_baseline(tgt, src, T_init, radius, run_len, method, budget_s):
     """The CPU oracle (oracle/, a C/OpenMP restatement of the reference path; the reference itself needs
     Eigen/PCL/FLANN and cannot be built here) timed on this box's host cores on a bounded sample."""
     from oracle import pyoracle as po
-    threads = os.cpu_count() or 1
     tree = po.KdTree(tgt)                       # kd-tree build is untimed in the reference too (:408-442)
-    cfg = po.default_config(search_radius=radius, max_iterations=1, thresh_rot=0.0, thresh_trans=0.0, kappa_target=10.0,
-                            std_reg_gamma=100.0, use_weight_derivative=1, always_compute_schur=1, num_threads=threads)
-    T = T_init.copy()
-    po.icp_run(tree, src, T, method, cfg)       # warm-up (thread pool, page faults)
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        res, logs = po.icp_run(tree, src, T, method, cfg)
-        T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
-        n += 1
-        if n % run_len == 0:
-            T = T_init.copy()
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 10 * run_len:
-            break
-    return {"value": n / el, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "sample": "%d ICP iterations of the same scan pair (%d-pt source), OpenMP x%d, %.1f s" % (n, len(src), threads, el)}
+    best = None
+    ncpu = os.cpu_count() or 1
+    for threads in sorted({min(8, ncpu), ncpu}):   # 8 mirrors the reference's num_threads(8) (:1714); then all cores
+        cfg = po.default_config(search_radius=radius, max_iterations=1, thresh_rot=0.0, thresh_trans=0.0, kappa_target=10.0,
+                                std_reg_gamma=100.0, use_weight_derivative=1, always_compute_schur=1, num_threads=threads)
+        T = T_init.copy()
+        po.icp_run(tree, src, T, method, cfg)       # warm-up (thread pool, page faults)
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            res, logs = po.icp_run(tree, src, T, method, cfg)
+            T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
+            n += 1
+            if n % run_len == 0:
+                T = T_init.copy()
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 10 * run_len:
+                break
+        cand = {"value": n / el, "unit": "iterations/s", "cores": threads, "kind": "port",
+                "sample": "%d ICP iterations of the same scan pair (%d-pt source), OpenMP x%d, %.1f s" % (n, len(src), threads, el)}
+        if best is None or cand["value"] > best["value"]:
+            other = best
+            best = cand
+            if other is not None:
+                best["sample"] += "; x%d threads gave %.2f it/s" % (other["cores"], other["value"])
+        else:
+            best["sample"] += "; x%d threads gave %.2f it/s" % (threads, cand["value"])
+    return best
 
 
 if __name__ == "__main__":

@@ -64,12 +64,22 @@ struct Heap {
     __device__ __forceinline__ float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)); }
 };
 
+// float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
 __device__ __forceinline__ float dist2_nofma(float qx, float qy, float qz, const float4 &c) {
-    const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
-    float d2 = __fmul_rn(dx, dx);
-    d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
-    d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+#pragma clang fp contract(off)
+    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
     return d2;
+}
+
+// utils.hpp:630-636 pointBodyToGlobal: double arithmetic (separate mul/add, as un-fused x86 code does), float store
+__device__ __forceinline__ void body_to_global(const PoseArg &P, double px, double py, double pz, float &qx, float &qy, float &qz) {
+#pragma clang fp contract(off)
+    qx = (float)(P.R[0] * px + P.R[1] * py + P.R[2] * pz + P.t[0]);
+    qy = (float)(P.R[3] * px + P.R[4] * py + P.R[5] * pz + P.t[1]);
+    qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
 }
 
 template <int K>
@@ -350,9 +360,8 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
         const float4 s4 = src[i];
         const double px = s4.x, py = s4.y, pz = s4.z;
         // utils.hpp:630-636: double transform, float store
-        const float qx = (float)(P.R[0] * px + P.R[1] * py + P.R[2] * pz + P.t[0]);
-        const float qy = (float)(P.R[3] * px + P.R[4] * py + P.R[5] * pz + P.t[1]);
-        const float qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
+        float qx, qy, qz;
+        body_to_global(P, px, py, pz, qx, qy, qz);
         Heap<5> hp;
         knn_search<5>(g, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
         const bool have5 = hp.pos[4] != kNoIdx;
@@ -474,10 +483,7 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
     const float4 s4 = q[i];
     float qx = s4.x, qy = s4.y, qz = s4.z;
     if (apply_pose) {   // pcl::transformPointCloud<PointT,double>: double arithmetic, float store
-        const double px = s4.x, py = s4.y, pz = s4.z;
-        qx = (float)(pose.R[0] * px + pose.R[1] * py + pose.R[2] * pz + pose.t[0]);
-        qy = (float)(pose.R[3] * px + pose.R[4] * py + pose.R[5] * pz + pose.t[1]);
-        qz = (float)(pose.R[6] * px + pose.R[7] * py + pose.R[8] * pz + pose.t[2]);
+        body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
     Heap<K> hp;
     knn_search<K>(g, qx, qy, qz, bound_f, max_ring, hp);

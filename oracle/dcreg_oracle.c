@@ -465,7 +465,7 @@ static void orc_point_row(const orc_kdtree *tree, const float *P, const double R
     row->flag = 1;
 }
 
-#define ORC_CHUNK 1024
+#define ORC_CHUNK 256
 
 int orc_linearize(const orc_kdtree *tree, const float *src, int64_t n_src, int64_t stride,
                   const double R[9], const double t[3], const orc_lin_params *prm,
