@@ -322,7 +322,7 @@ int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_rad
         max_ring = kk;
     } else {
         bound = 3.0e38f;
-        max_ring = std::max({c->grid.nx, c->grid.ny, c->grid.nz}) + 2;   // unbounded: may sweep the whole grid
+        max_ring = -1;   // unbounded: the kernel sweeps as many rings as the grid needs
     }
     PoseArg P{};
     if (pose) P = *pose;

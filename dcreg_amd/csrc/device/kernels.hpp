@@ -100,14 +100,22 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // the ball covers the search radius.
 template <int K>
 __device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, Heap<K> &hp) {
+                                           int max_ring, Heap<K> &hp) {   // max_ring < 0: unbounded
     hp.init(((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
-    // a query farther than max_ring cells from the grid cannot have a neighbour inside the radius
     const double lim = (double)max_ring + 1.0;
-    if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
-    const int cx = (int)floor(fx), cy = (int)floor(fy), cz = (int)floor(fz);
+    if (max_ring >= 0) {
+        // bounded search: a query farther than max_ring cells from the grid has no neighbour inside the radius
+        if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
+    }
+    const double big = 1.0e9;
+    const int cx = (int)floor(fmin(fmax(fx, -big), big)), cy = (int)floor(fmin(fmax(fy, -big), big)),
+              cz = (int)floor(fmin(fmax(fz, -big), big));
     const int nx = g.nx, ny = g.ny, nz = g.nz;
+    if (max_ring < 0) {   // unbounded: enough rings to sweep the whole grid from this cell
+        const int ex = max(abs(cx), abs(cx - (nx - 1))), ey = max(abs(cy), abs(cy - (ny - 1))), ez = max(abs(cz), abs(cz - (nz - 1)));
+        max_ring = max(ex, max(ey, ez)) + 1;
+    }
 
     // ---- rings 0+1: the 3x3 rows of the 3x3x3 block, each row one contiguous run; flattened so the
     // wave iterates max-over-lanes(total candidates) instead of sum-over-rows(max candidates)
@@ -147,12 +155,12 @@ __device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy,
         if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
         if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
         const int kk = k + 1;                                   // scan shell kk
-        for (int dz = -kk; dz <= kk; ++dz) {
-            const int z = cz + dz;
-            if (z < 0 || z >= nz) continue;
-            for (int dy = -kk; dy <= kk; ++dy) {
-                const int y = cy + dy;
-                if (y < 0 || y >= ny) continue;
+        const int z_lo = max(cz - kk, 0), z_hi = min(cz + kk, nz - 1);
+        const int y_lo = max(cy - kk, 0), y_hi = min(cy + kk, ny - 1);
+        for (int z = z_lo; z <= z_hi; ++z) {
+            const int dz = z - cz;
+            for (int y = y_lo; y <= y_hi; ++y) {
+                const int dy = y - cy;
                 const int64_t row = ((int64_t)z * ny + y) * nx;
                 const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
                 if (full) {
