@@ -43,7 +43,8 @@ class LinOut(C.Structure):
 class LinDebug(C.Structure):
     _fields_ = [("nn_idx", C.POINTER(C.c_int32)), ("nn_d2", C.POINTER(C.c_float)),
                 ("flag", C.POINTER(C.c_uint8)), ("normal", C.POINTER(C.c_double)),
-                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double))]
+                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double)), ("stats", C.POINTER(C.c_uint32)),
+                ("clocks", C.POINTER(C.c_uint64))]
 
 
 class IndexInfo(C.Structure):
@@ -318,9 +319,11 @@ class Context:
             return self._out_dict(out)
         n = self.index_info().n_source
         keep = {"nn_idx": np.full((n, 5), -1, np.int32), "nn_d2": np.full((n, 5), np.inf, np.float32),
-                "flag": np.zeros(n, np.uint8), "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n)}
+                "flag": np.zeros(n, np.uint8), "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n),
+                "stats": np.zeros(n, np.uint32), "clocks": np.zeros(((n + 63) // 64 + 4, 8), np.uint64)}
         dbg = LinDebug(keep["nn_idx"].ctypes.data_as(C.POINTER(C.c_int32)), keep["nn_d2"].ctypes.data_as(C.POINTER(C.c_float)),
-                       keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8)), _dp(keep["normal"]), _dp(keep["r"]), _dp(keep["s"]))
+                       keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8)), _dp(keep["normal"]), _dp(keep["r"]), _dp(keep["s"]),
+                       keep["stats"].ctypes.data_as(C.POINTER(C.c_uint32)), keep["clocks"].ctypes.data_as(C.POINTER(C.c_uint64)))
         self._check(self._L.dcreg_linearize_debug(self._h, _dp(R), _dp(t), C.byref(params), C.byref(out), C.byref(dbg)), "dcreg_linearize_debug")
         d = self._out_dict(out)
         d.update(keep)

@@ -82,7 +82,7 @@ static int build_grid_at(dcreg_ctx *c, double h, const double mn[3], const doubl
     g.n_pts = (uint32_t)n;
     if (ensure(c, c->d_keys, c->keys_cap, (size_t)n) || ensure(c, c->d_keys2, c->keys2_cap, (size_t)n) ||
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
-        ensure(c, c->d_cell_start, c->cell_cap, (size_t)n_cells + 1) || ensure(c, c->d_tgt, c->tgt_cap, (size_t)n))
+        ensure(c, c->d_cell_start, c->cell_cap, (size_t)n_cells + 1) || ensure(c, c->d_tgt, c->tgt_cap, (size_t)n + 8))
         return DCREG_E_NOMEM;
     hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_tgt_raw, n, g, c->d_keys, c->d_vals);
     int bits = 1;
@@ -90,6 +90,7 @@ static int build_grid_at(dcreg_ctx *c, double h, const double mn[3], const doubl
     int rc = sort_pairs_u32(c, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2, (size_t)n, bits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_tgt_raw, c->d_vals2, n, c->d_tgt);
+    HIP_TRY(c, hipMemsetAsync(c->d_tgt + n, 0, 8 * sizeof(float4), c->stream));   // tail padding read by the chunked scan
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, c->d_cell_start, c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(occupied, c->d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -184,7 +185,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = upload_cloud(c, xyz, n, stride, on_device, c->d_src_raw, c->src_raw_cap);
     if (rc) return rc;
-    // Morton order in the body frame (pose independent)
+    // Hilbert-curve order in the body frame (pose independent: a rigid motion keeps neighbours neighbours)
     double mn[3], mx[3];
     rc = device_bounds(c, c->d_src_raw, n, mn, mx);
     if (rc) return rc;
@@ -194,7 +195,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
         ensure(c, c->d_src, c->src_cap, (size_t)n))
         return DCREG_E_NOMEM;
-    hipLaunchKernelGGL(k_morton_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
+    hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
     rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
@@ -234,14 +235,15 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     LinArgs a;
     int rc = make_lin_args(c, p, a);
     if (rc) return rc;
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
     const uint32_t nbx = blocks_for(c->n_src, kBlock);
     if (ensure(c, c->d_partials, c->partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     if ((size_t)n_poses > c->out_cap) {
         if (c->h_out) (void)hipHostFree(c->h_out);
         c->h_out = nullptr; c->out_cap = 0;
         const size_t cap = std::max<size_t>((size_t)n_poses, 64);
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_out, cap * kSlots * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_out, cap * kSlots * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_out, 0, cap * kSlots * sizeof(double));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_out, c->h_out, 0));
         c->out_cap = cap;
     }
@@ -273,14 +275,20 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (dbg_host->normal) dd.normal = (double *)alloc(sizeof(double) * 3 * n, 0);
         if (dbg_host->r) dd.r = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
+        if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
+        if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 8 * ((n + 63) / 64 + 4), 0);
     }
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
-    if (dbg_host)
-        hipLaunchKernelGGL(k_linearize<1>, grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
-    else
-        hipLaunchKernelGGL(k_linearize<0>, grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(1024), 0, c->stream, c->d_partials, nbx, c->d_out);
+    if (dbg_host) {
+        if (c->opt_tile) hipLaunchKernelGGL((k_linearize<1, 1>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+        else hipLaunchKernelGGL((k_linearize<1, 0>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+    } else {
+        if (c->opt_tile) hipLaunchKernelGGL((k_linearize<0, 1>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+        else hipLaunchKernelGGL((k_linearize<0, 0>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+    }
+    const unsigned long long seq = ++c->seq;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(1024), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (dbg_host) {
         if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
@@ -289,10 +297,28 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (dd.normal) HIP_TRY(c, hipMemcpyAsync(dbg_host->normal, dd.normal, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.r) HIP_TRY(c, hipMemcpyAsync(dbg_host->r, dd.r, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.s) HIP_TRY(c, hipMemcpyAsync(dbg_host->s, dd.s, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.stats) HIP_TRY(c, hipMemcpyAsync(dbg_host->stats, dd.stats, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+        if (dd.clocks) HIP_TRY(c, hipMemcpyAsync(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 8 * ((n + 63) / 64), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (dbg_host || c->opt_time_kernels || !c->opt_spin) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        // hot path: spin on the sequence numbers the finalize kernel publishes into pinned host memory
+        for (int i = 0; i < n_poses; ++i) {
+            volatile unsigned long long *flag = (volatile unsigned long long *)(c->h_out + (size_t)i * kSlots + 31);
+            uint64_t spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                __builtin_ia32_pause();
+                if (++spins > (1ull << 26)) {   // ~seconds: surface a device fault instead of hanging
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
+                    break;
+                }
+            }
+        }
+    }
     for (void *p2 : tmp_dev) (void)hipFree(p2);
-    HIP_TRY(c, hipGetLastError());
+    if (dbg_host) HIP_TRY(c, hipGetLastError());
     if (c->opt_time_kernels) {
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -402,6 +428,8 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
     else if (k == "time_kernels") c->opt_time_kernels = v != 0.0;
+    else if (k == "tile") c->opt_tile = v != 0.0;
+    else if (k == "spin") c->opt_spin = v != 0.0;
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;
 }

@@ -58,6 +58,10 @@ struct dcreg_ctx {
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
     bool opt_time_kernels = false;
+    bool opt_spin = true;          // wait for results by spinning on pinned memory instead of hipStreamSynchronize
+    bool need_set_device = true;
+    unsigned long long seq = 0;
+    bool opt_tile = true;          // per-wave LDS tiles (false: global-gather path, for A/B)
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
 

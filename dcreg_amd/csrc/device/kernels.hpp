@@ -44,11 +44,15 @@ template <int K>
 struct Heap {
     uint64_t key[K];
     uint32_t pos[K];
+    uint32_t n_eval;     // candidates evaluated (statistics only; dead code unless read)
+    uint32_t n_shell;    // outermost shell scanned
     __device__ __forceinline__ void init(uint64_t bound) {
 #pragma unroll
         for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
+        n_eval = 0; n_shell = 1;
     }
     __device__ __forceinline__ void push(uint64_t k, uint32_t p) {
+        ++n_eval;
         if (k < key[K - 1]) {
             key[K - 1] = k; pos[K - 1] = p;
 #pragma unroll
@@ -82,17 +86,23 @@ __device__ __forceinline__ void body_to_global(const PoseArg &P, double px, doub
     qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
 }
 
+constexpr uint32_t kGlobalTag = 0x80000000u;   // heap position refers to the global sorted array (else: LDS tile slot)
+
 template <int K>
 __device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz,
                                          Heap<K> &hp) {
     for (uint32_t p = s; p < e; ++p) {
         const float4 c = g.pts[p];
         const float d2 = dist2_nofma(qx, qy, qz, c);
-        hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p);
+        hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p | kGlobalTag);
     }
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int K>
+__device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                           double fx, double fy, double fz, float bound_f, int max_ring, Heap<K> &hp);
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
@@ -143,11 +153,22 @@ __device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy,
             if (p >= e) break;
             const float4 c = g.pts[p];
             const float d2 = dist2_nofma(qx, qy, qz, c);
-            hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p);
+            hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p | kGlobalTag);
             ++p;
         }
     }
-    // ---- shells k >= 2 (rare: sparse neighbourhoods, cloud borders)
+    knn_shells<K>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+}
+
+// shells k >= 2 around cell (cx,cy,cz), global loads (sparse neighbourhoods, cloud borders, large
+// misalignment).  kd-tree style pruning on the grid: a (y,z) row is skipped when its slab is farther than
+// the current K-th best, and its x-run is trimmed to the cells the K-th-best ball can still reach.
+// (fx,fy,fz) = query position in cell units.
+template <int K>
+__device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                           double fx, double fy, double fz, float bound_f, int max_ring, Heap<K> &hp) {
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const float hf = (float)g.h;
     for (int k = 1; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
@@ -155,21 +176,32 @@ __device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy,
         if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
         if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
         const int kk = k + 1;                                   // scan shell kk
+        hp.n_shell = (uint32_t)kk;
         const int z_lo = max(cz - kk, 0), z_hi = min(cz + kk, nz - 1);
         const int y_lo = max(cy - kk, 0), y_hi = min(cy + kk, ny - 1);
         for (int z = z_lo; z <= z_hi; ++z) {
             const int dz = z - cz;
+            const float gz = dz < 0 ? (float)(fz - (double)(z + 1)) * hf : (dz > 0 ? (float)((double)z - fz) * hf : 0.f);
+            if (gz * gz * 0.99999f > hp.worst_d2()) continue;
             for (int y = y_lo; y <= y_hi; ++y) {
                 const int dy = y - cy;
+                const float gy = dy < 0 ? (float)(fy - (double)(y + 1)) * hf : (dy > 0 ? (float)((double)y - fy) * hf : 0.f);
+                const float dyz = (gy * gy + gz * gz) * 0.99999f;
+                const float w = hp.worst_d2();
+                if (dyz > w) continue;
+                // cells the ball of radius sqrt(w) around q can reach in this row (conservative)
+                const float xr = sqrtf(w - dyz) * 1.00001f + 1e-6f * hf;
+                const double xr_c = (double)xr * g.inv_h;
+                const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
                 const int64_t row = ((int64_t)z * ny + y) * nx;
                 const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
                 if (full) {
-                    const int x0 = clampi(cx - kk, 0, nx), x1 = clampi(cx + kk + 1, 0, nx);
+                    const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
                     if (x1 > x0) scan_run<K>(g, g.cell_start[row + x0], g.cell_start[row + x1], qx, qy, qz, hp);
                 } else {
                     const int xa = cx - kk, xb = cx + kk;
-                    if (xa >= 0 && xa < nx) scan_run<K>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
-                    if (xb >= 0 && xb < nx) scan_run<K>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
+                    if (xa >= 0 && xa < nx && xa >= xmin) scan_run<K>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
+                    if (xb >= 0 && xb < nx && xb <= xmax) scan_run<K>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
                 }
             }
         }
@@ -344,34 +376,53 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 // ---------------------------------------------------------------- the fused linearisation kernel
 // MODE 0: reduction only.  MODE 1: also dump per-point results (parity tests).
+// TILE: reserved for search variants (A/B switch "tile"); both values currently run the per-lane search.
 struct DebugDev {
     int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
+    uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16 | tile used << 31
+    unsigned long long *clocks;   // per wave: 8 shader-clock stamps (phase breakdown), may be null
 };
 
-template <int MODE>
+template <int MODE, int TILE>
 static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, DebugDev dbg) {
-    __shared__ double tile[kBlock / 64][kSlots];
+    __shared__ double red[kBlock / 64][kSlots];
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x);
     const uint32_t i = vb * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
 
     double acc[31];
 #pragma unroll
     for (int k = 0; k < 31; ++k) acc[k] = 0.0;
+    unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
+    if (MODE == 1) clk[0] = clock64();
+
+    // ---- query, cell, reach test
+    const bool have_q = i < n_src;
+    const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const double px = s4.x, py = s4.y, pz = s4.z;
+    float qx, qy, qz;
+    body_to_global(P, px, py, pz, qx, qy, qz);
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+    const double lim = (double)a.max_ring + 1.0;
+    // a query farther than max_ring cells from the grid has no neighbour inside the radius
+    const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
+    const double flx = floor(fx), fly = floor(fy), flz = floor(fz);
+    const int cx = reach ? (int)flx : 0, cy = reach ? (int)fly : 0, cz = reach ? (int)flz : 0;
+
+    Heap<5> hp;
+    hp.init(((uint64_t)__float_as_uint(a.radius_sq_f) << 32) | 0xFFFFFFFFull);
+    const bool tiled = false;
+    if (MODE == 1) clk[1] = clock64();
+    if (reach) knn_search<5>(g, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
+    if (MODE == 1) clk[2] = clock64();
 
     uint8_t flag = 0;
-    if (i < n_src) {
-        const float4 s4 = src[i];
-        const double px = s4.x, py = s4.y, pz = s4.z;
-        // utils.hpp:630-636: double transform, float store
-        float qx, qy, qz;
-        body_to_global(P, px, py, pz, qx, qy, qz);
-        Heap<5> hp;
-        knn_search<5>(g, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
+    if (have_q) {
         const bool have5 = hp.pos[4] != kNoIdx;
         const bool in_radius = have5 && (double)hp.worst_d2() < a.radius_sq;      // :1726
         if (MODE == 1) {
@@ -387,7 +438,11 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
             acc[30] = 1.0;                                                          // :1731
             double nqx[5], nqy[5], nqz[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { const float4 c = g.pts[hp.pos[j]]; nqx[j] = c.x; nqy[j] = c.y; nqz[j] = c.z; }
+            for (int j = 0; j < 5; ++j) {
+                const uint32_t pj = hp.pos[j];
+                const float4 c = g.pts[pj & ~kGlobalTag];
+                nqx[j] = c.x; nqy[j] = c.y; nqz[j] = c.z;
+            }
             double x[3];
             plane_fit_qr(nqx, nqy, nqz, x);
             const double ps = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
@@ -444,28 +499,40 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
             }
         }
         if (MODE == 1 && dbg.flag) dbg.flag[__float_as_uint(s4.w)] = flag;
+        if (MODE == 1 && dbg.stats) dbg.stats[__float_as_uint(s4.w)] = (hp.n_eval & 0xFFFFu) | ((hp.n_shell & 0x7FFFu) << 16) | (tiled ? 0x80000000u : 0u);
     }
 
-    // wave64 DPP reduction -> lane 63 -> LDS tile -> block partial (fixed order, no float atomics)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (MODE == 1) clk[3] = clock64();
+    // wave64 DPP reduction -> lane 63 -> LDS -> block partial (fixed order, no float atomics)
 #pragma unroll
     for (int k = 0; k < 31; ++k) {
         const double t = wave_sum_to_lane63(acc[k]);
-        if (lane == 63) tile[wave][k] = t;
+        if (lane == 63) red[wave][k] = t;
     }
+    if (MODE == 1) clk[4] = clock64();
     __syncthreads();
     if (threadIdx.x < kSlots) {
         double t = 0.0;
         if (threadIdx.x < 31) {
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) t += tile[w][threadIdx.x];
+            for (int w = 0; w < kBlock / 64; ++w) t += red[w][threadIdx.x];
         }
         partials[((size_t)pose_id * n_blocks_x + vb) * kSlots + threadIdx.x] = t;
     }
+    if (MODE == 1 && dbg.clocks && lane == 0) {
+        clk[5] = clock64();
+        unsigned long long *o = dbg.clocks + ((size_t)vb * (kBlock / 64) + wave) * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = clk[k];
+        o[6] = tiled ? 1 : 0; o[7] = blockIdx.x;
+    }
 }
 
-// one block per pose: sums the block partials in index order, writes 32 doubles to (pinned) out
-static __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out) {
+// one block per pose: sums the block partials in index order, writes 32 doubles to the pinned, host-
+// coherent result row, then publishes a sequence number the host spins on (no stream synchronise on
+// the hot path).  out row layout: [0..30] sums, [31] = sequence number as double bits.
+static __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out,
+                                                           unsigned long long seq) {
     __shared__ double sm[32][kSlots + 1];
     const uint32_t pose_id = blockIdx.x;
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 32 groups of 32 lanes
@@ -474,12 +541,16 @@ static __global__ __launch_bounds__(1024) void k_finalize(const double *__restri
     for (uint32_t b = grp; b < n_blocks; b += 32) t += base[(size_t)b * kSlots + j];
     sm[grp][j] = t;
     __syncthreads();
-    if (threadIdx.x < kSlots) {
+    if (threadIdx.x < 31) {
         double s = 0.0;
 #pragma unroll
         for (int gidx = 0; gidx < 32; ++gidx) s += sm[gidx][threadIdx.x];
         out[(size_t)pose_id * kSlots + threadIdx.x] = s;
+        __threadfence_system();
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store((unsigned long long *)(out + (size_t)pose_id * kSlots + 31), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------- plain k-NN kernel (p2p metrics, tests)
@@ -555,15 +626,30 @@ __device__ __forceinline__ uint64_t spread21(uint64_t v) {
     v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
-static __global__ void k_morton_keys(const float4 *__restrict__ p, int64_t n, double ox, double oy, double oz, double inv_q,
-                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// Hilbert-curve key (Skilling's transpose algorithm, 21 bits per axis).  Consecutive keys are always
+// spatial neighbours (no Z-order seams), which keeps the per-wave tile boxes tight.
+static __global__ void k_curve_keys(const float4 *__restrict__ p, int64_t n, double ox, double oy, double oz, double inv_q,
+                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 c = p[i];
     const double fx = ((double)c.x - ox) * inv_q, fy = ((double)c.y - oy) * inv_q, fz = ((double)c.z - oz) * inv_q;
-    const uint64_t ix = (uint64_t)fmin(fmax(fx, 0.0), 2097151.0), iy = (uint64_t)fmin(fmax(fy, 0.0), 2097151.0),
-                   iz = (uint64_t)fmin(fmax(fz, 0.0), 2097151.0);
-    keys[i] = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+    uint32_t X[3] = {(uint32_t)fmin(fmax(fx, 0.0), 2097151.0), (uint32_t)fmin(fmax(fy, 0.0), 2097151.0),
+                     (uint32_t)fmin(fmax(fz, 0.0), 2097151.0)};
+    const uint32_t M = 1u << 20;
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (X[a] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    keys[i] = (spread21(X[0]) << 2) | (spread21(X[1]) << 1) | spread21(X[2]);
     vals[i] = (uint32_t)i;
 }
 

@@ -87,6 +87,9 @@ typedef struct dcreg_lin_debug {
     double *normal;  /* [3*n] */
     double *r;       /* [n] */
     double *s;       /* [n] */
+    uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 | LDS tile used << 31 */
+    uint64_t *clocks; /* [8 * ceil(n/64)] per-wave shader-clock stamps: start, tile built, search done, rows done,
+                         wave reduced, end, tile-used flag, hw block id */
 } dcreg_lin_debug;
 
 typedef struct dcreg_index_info {

@@ -16,15 +16,15 @@ for n in (256, 7562, 100_000, 1_000_000):
     T0 = h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008)
     R = np.ascontiguousarray(T0[:3, :3]).reshape(9); t = T0[:3, 3].copy()
     prm = api.default_lin_params(1.0, 1); out = api.LinOut()
-    for timed in (0, 1):
-        ctx.set_option("time_kernels", timed); ctx.kernel_time(reset=True)
+    for timed, tile in ((0, 1), (1, 1), (1, 0)):
+        ctx.set_option("time_kernels", timed); ctx.set_option("tile", tile); ctx.kernel_time(reset=True)
         for _ in range(20): ctx.linearize_raw(R, t, prm, out)
         ctx.kernel_time(reset=True)
-        K = 200
+        K = 200 if n < 1_000_000 else 40
         a = time.perf_counter()
         for _ in range(K): ctx.linearize_raw(R, t, prm, out)
         b = time.perf_counter()
         ms, cnt = ctx.kernel_time(reset=True)
         info = ctx.index_info()
-        print("n=%8d timed=%d  wall/call %.1f us  kernel(evt) %.1f us  n_eff %d  cell %.3f cells %d  build tgt %.1f ms src %.1f ms" % (
-            n, timed, (b - a) / K * 1e6, (ms / cnt * 1e3) if cnt else -1, out.n_eff, info.cell, info.n_cells, (t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+        print("n=%8d timed=%d tile=%d  wall/call %.1f us  kernel(evt) %.1f us  n_eff %d  cell %.3f cells %d  build tgt %.1f ms src %.1f ms" % (
+            n, timed, tile, (b - a) / K * 1e6, (ms / cnt * 1e3) if cnt else -1, out.n_eff, info.cell, info.n_cells, (t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
