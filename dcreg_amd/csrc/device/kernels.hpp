@@ -104,12 +104,26 @@ template <int K>
 __device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, Heap<K> &hp);
 
+// Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
+// Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
+// divergent candidate loop costs one ds_read instead of a 9-way register select.
+struct RunList {
+    uint32_t s[9][kBlock];
+    uint32_t e[9][kBlock];
+    float gap2[9][kBlock];     // squared distance from the query to the row's (y,z) slab
+};
+
+template <int K>
+__device__ __forceinline__ void push_point(Heap<K> &hp, float qx, float qy, float qz, const float4 &c, uint32_t p) {
+    hp.push(((uint64_t)__float_as_uint(dist2_nofma(qx, qy, qz, c)) << 32) | (uint64_t)__float_as_uint(c.w), p | kGlobalTag);
+}
+
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
 // closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
 // the ball covers the search radius.
 template <int K>
-__device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy, float qz, float bound_f,
+__device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
                                            int max_ring, Heap<K> &hp) {   // max_ring < 0: unbounded
     hp.init(((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
@@ -119,42 +133,66 @@ __device__ __forceinline__ void knn_search(const GridDev &g, float qx, float qy,
         if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
     }
     const double big = 1.0e9;
-    const int cx = (int)floor(fmin(fmax(fx, -big), big)), cy = (int)floor(fmin(fmax(fy, -big), big)),
-              cz = (int)floor(fmin(fmax(fz, -big), big));
+    const double flx = floor(fmin(fmax(fx, -big), big)), fly = floor(fmin(fmax(fy, -big), big)), flz = floor(fmin(fmax(fz, -big), big));
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     if (max_ring < 0) {   // unbounded: enough rings to sweep the whole grid from this cell
         const int ex = max(abs(cx), abs(cx - (nx - 1))), ey = max(abs(cy), abs(cy - (ny - 1))), ez = max(abs(cz), abs(cz - (nz - 1)));
         max_ring = max(ex, max(ey, ez)) + 1;
     }
 
-    // ---- rings 0+1: the 3x3 rows of the 3x3x3 block, each row one contiguous run; flattened so the
-    // wave iterates max-over-lanes(total candidates) instead of sum-over-rows(max candidates)
+    // ---- rings 0+1, phase A: the 9 (y,z) rows of the 3x3x3 block, each one contiguous x-run; all 18 table
+    // loads are issued together, empty / out-of-reach rows are dropped, nearest rows come first
+    const int tid = threadIdx.x;
+    int nrun = 0;
     {
         const int x0 = clampi(cx - 1, 0, nx), x1 = clampi(cx + 2, 0, nx);   // [x0, x1)
+        const float hf = (float)g.h;
+        const float fry = (float)(fy - fly), frz = (float)(fz - flz);
+        const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
+        // visiting order (dy,dz): centre, 4 edge rows, 4 corner rows
+        constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
         uint32_t rs[9], re[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+            const int y = cy + DY[r], z = cz + DZ[r];
             const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz;
             const int64_t row = ok ? ((int64_t)z * ny + y) * nx : 0;
             rs[r] = ok ? g.cell_start[row + x0] : 0u;
             re[r] = ok ? g.cell_start[row + x1] : 0u;
         }
-        int r = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const float gy = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.f), gz = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.f);
+            const float g2 = (gy * gy + gz * gz) * 0.99999f;
+            if (re[r] > rs[r] && !(g2 > bound_f)) {
+                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2[nrun][tid] = g2;
+                ++nrun;
+            }
+        }
+    }
+    // ---- phase B: flattened walk over the runs (the wave iterates max-over-lanes of the total, not the
+    // sum of per-row maxima), 4 candidates in flight per trip
+    {
+        int ri = 0;
         uint32_t p = 0, e = 0;
         while (true) {
-            while (p >= e && r < 9) {
-                // static selection keeps rs/re in registers
-                uint32_t s_ = 0, e_ = 0;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { if (k == r) { s_ = rs[k]; e_ = re[k]; } }
-                p = s_; e = e_; ++r;
+            while (p >= e && ri < nrun) {
+                const float g2 = rl.gap2[ri][tid];
+                const uint32_t s_ = rl.s[ri][tid], e_ = rl.e[ri][tid];
+                ++ri;
+                if (g2 > hp.worst_d2()) continue;     // every point of this row is farther than the K-th best
+                p = s_; e = e_;
             }
             if (p >= e) break;
-            const float4 c = g.pts[p];
-            const float d2 = dist2_nofma(qx, qy, qz, c);
-            hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p | kGlobalTag);
-            ++p;
+            const uint32_t last = e - 1;
+            const float4 c0 = g.pts[p], c1 = g.pts[min(p + 1, last)], c2 = g.pts[min(p + 2, last)], c3 = g.pts[min(p + 3, last)];
+            push_point<K>(hp, qx, qy, qz, c0, p);
+            if (p + 1 < e) push_point<K>(hp, qx, qy, qz, c1, p + 1);
+            if (p + 2 < e) push_point<K>(hp, qx, qy, qz, c2, p + 2);
+            if (p + 3 < e) push_point<K>(hp, qx, qy, qz, c3, p + 3);
+            p += 4;
         }
     }
     knn_shells<K>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
@@ -388,6 +426,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, DebugDev dbg) {
     __shared__ double red[kBlock / 64][kSlots];
+    __shared__ RunList runs;
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x);
     const uint32_t i = vb * kBlock + threadIdx.x;
@@ -418,7 +457,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     hp.init(((uint64_t)__float_as_uint(a.radius_sq_f) << 32) | 0xFFFFFFFFull);
     const bool tiled = false;
     if (MODE == 1) clk[1] = clock64();
-    if (reach) knn_search<5>(g, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
+    if (reach) knn_search<5>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
     if (MODE == 1) clk[2] = clock64();
 
     uint8_t flag = 0;
@@ -557,6 +596,7 @@ static __global__ __launch_bounds__(1024) void k_finalize(const double *__restri
 template <int K>
 static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict__ q, uint32_t n, GridDev g, float bound_f, int max_ring,
                                                  PoseArg pose, int apply_pose, int32_t *__restrict__ idx, float *__restrict__ d2) {
+    __shared__ RunList runs;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 s4 = q[i];
@@ -565,7 +605,7 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
         body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
     Heap<K> hp;
-    knn_search<K>(g, qx, qy, qz, bound_f, max_ring, hp);
+    knn_search<K>(g, runs, qx, qy, qz, bound_f, max_ring, hp);
     const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
