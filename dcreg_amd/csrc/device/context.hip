@@ -69,9 +69,16 @@ static int device_bounds(dcreg_ctx *c, const float4 *pts, int64_t n, double mn[3
     return DCREG_OK;
 }
 
+struct GridDst {   // where a grid build puts its products
+    const float4 *raw; int64_t n;
+    float4 **sorted; size_t *sorted_cap;
+    uint32_t **cell_start; size_t *cell_cap;
+    GridDev *grid; int64_t *n_cells;
+};
+
 // builds keys/sort/cell_start for the given cell edge; returns number of occupied cells
-static int build_grid_at(dcreg_ctx *c, double h, const double mn[3], const double mx[3], uint32_t *occupied) {
-    const int64_t n = c->n_tgt;
+static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double mn[3], const double mx[3], uint32_t *occupied) {
+    const int64_t n = d.n;
     GridDev g{};
     g.h = h; g.inv_h = 1.0 / h;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
@@ -82,24 +89,24 @@ static int build_grid_at(dcreg_ctx *c, double h, const double mn[3], const doubl
     g.n_pts = (uint32_t)n;
     if (ensure(c, c->d_keys, c->keys_cap, (size_t)n) || ensure(c, c->d_keys2, c->keys2_cap, (size_t)n) ||
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
-        ensure(c, c->d_cell_start, c->cell_cap, (size_t)n_cells + 1) || ensure(c, c->d_tgt, c->tgt_cap, (size_t)n + 8))
+        ensure(c, *d.cell_start, *d.cell_cap, (size_t)n_cells + 1) || ensure(c, *d.sorted, *d.sorted_cap, (size_t)n + 8))
         return DCREG_E_NOMEM;
-    hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_tgt_raw, n, g, c->d_keys, c->d_vals);
+    hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, d.raw, n, g, c->d_keys, c->d_vals);
     int bits = 1;
     while (((int64_t)1 << bits) < n_cells && bits < 32) ++bits;
     int rc = sort_pairs_u32(c, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2, (size_t)n, bits);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_tgt_raw, c->d_vals2, n, c->d_tgt);
-    HIP_TRY(c, hipMemsetAsync(c->d_tgt + n, 0, 8 * sizeof(float4), c->stream));   // tail padding read by the chunked scan
+    hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, d.raw, c->d_vals2, n, *d.sorted);
+    HIP_TRY(c, hipMemsetAsync(*d.sorted + n, 0, 8 * sizeof(float4), c->stream));   // tail padding
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, c->d_cell_start, c->d_scratch);
+    hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, *d.cell_start, c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(occupied, c->d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    g.cell_start = c->d_cell_start;
-    g.pts = c->d_tgt;
-    c->grid = g;
-    c->n_cells = n_cells;
+    g.cell_start = *d.cell_start;
+    g.pts = *d.sorted;
+    *d.grid = g;
+    *d.n_cells = n_cells;
     return DCREG_OK;
 }
 
@@ -113,11 +120,11 @@ static double cap_cell_for_budget(double h, const double mn[3], const double mx[
     return h;
 }
 
-static int build_index(dcreg_ctx *c, double radius_hint) {
-    const int64_t n = c->n_tgt;
-    if (n <= 0) { c->fail("target cloud is empty"); return DCREG_E_INVALID; }
+static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint32_t *occupied_out) {
+    const int64_t n = d.n;
+    if (n <= 0) { c->fail("cloud is empty"); return DCREG_E_INVALID; }
     double mn[3], mx[3];
-    int rc = device_bounds(c, c->d_tgt_raw, n, mn, mx);
+    int rc = device_bounds(c, d.raw, n, mn, mx);
     if (rc) return rc;
     for (int a = 0; a < 3; ++a) if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) { c->fail("target cloud has non-finite coordinates"); return DCREG_E_INVALID; }
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
@@ -127,7 +134,7 @@ static int build_index(dcreg_ctx *c, double radius_hint) {
     uint32_t occ = 0;
     double h = c->opt_cell > 0.0 ? c->opt_cell : h_cap;
     h = cap_cell_for_budget(h, mn, mx, max_cells);
-    rc = build_grid_at(c, h, mn, mx, &occ);
+    rc = build_grid_at(c, d, h, mn, mx, &occ);
     if (rc) return rc;
     if (c->opt_cell <= 0.0) {
         // density-adaptive cell: aim at `target_occ` points per occupied cell (surface data: occupancy ~ h^2)
@@ -139,14 +146,28 @@ static int build_index(dcreg_ctx *c, double radius_hint) {
             h2 = std::max(h2, h_cap / 64.0);
             h2 = cap_cell_for_budget(h2, mn, mx, max_cells);
             if (h2 >= h1 * 0.95) break;
-            rc = build_grid_at(c, h2, mn, mx, &occ);
+            rc = build_grid_at(c, d, h2, mn, mx, &occ);
             if (rc) return rc;
             const double m2 = (double)n / std::max<uint32_t>(occ, 1);
             if (m2 < m1 && h2 < h1) expo = std::min(3.0, std::max(1.0, std::log(m1 / m2) / std::log(h1 / h2)));
             h1 = h2; m1 = m2;
         }
     }
-    c->occupied_cells = occ;
+    if (occupied_out) *occupied_out = occ;
+    return DCREG_OK;
+}
+
+static GridDst target_dst(dcreg_ctx *c) {
+    return GridDst{c->d_tgt_raw, c->n_tgt, &c->d_tgt, &c->tgt_cap, &c->d_cell_start, &c->cell_cap, &c->grid, &c->n_cells};
+}
+
+// grid over the body-frame source cloud (backward pass of dcreg_p2p_error); built lazily, once per source
+int build_aux_index(dcreg_ctx *c) {
+    if (c->aux_valid) return DCREG_OK;
+    GridDst d{c->d_src_raw, c->n_src, &c->d_aux, &c->aux_cap, &c->d_aux_cell_start, &c->aux_cell_cap, &c->aux_grid, &c->aux_n_cells};
+    int rc = build_index(c, d, c->radius_hint, nullptr);
+    if (rc) return rc;
+    c->aux_valid = true;
     return DCREG_OK;
 }
 
@@ -174,7 +195,7 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) return rc;
     c->n_tgt = n;
     c->radius_hint = radius_hint;
-    rc = build_index(c, radius_hint);
+    rc = build_index(c, target_dst(c), radius_hint, &c->occupied_cells);
     if (rc) { c->n_tgt = 0; return rc; }
     return DCREG_OK;
 }
@@ -202,6 +223,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
+    c->aux_valid = false;
     return DCREG_OK;
 }
 
@@ -287,9 +309,9 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (c->opt_tile) hipLaunchKernelGGL((k_linearize<0, 1>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
         else hipLaunchKernelGGL((k_linearize<0, 0>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
     }
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
     const unsigned long long seq = ++c->seq;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(1024), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
-    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (dbg_host) {
         if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.nn_d2) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_d2, dd.nn_d2, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, c->stream));
@@ -335,7 +357,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
 }
 
 // k-NN of arbitrary queries (host pointer) or of the transformed source cloud (q == nullptr)
-int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
+int launch_knn(dcreg_ctx *c, const GridDev &grid, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
                int32_t *d_idx, float *d_d2) {
     float bound = INFINITY;
     int max_ring;
@@ -344,7 +366,7 @@ int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_rad
         float rf = (float)r2; if ((double)rf < r2) rf = std::nextafterf(rf, INFINITY);
         bound = std::nextafterf(rf, INFINITY);
         int kk = 1;
-        while (kk < 100000) { const double s = (double)kk * c->grid.h * (1.0 - 1e-9); if (s * s * (1.0 - 1e-6) >= (double)bound) break; ++kk; }
+        while (kk < 100000) { const double s = (double)kk * grid.h * (1.0 - 1e-9); if (s * s * (1.0 - 1e-6) >= (double)bound) break; ++kk; }
         max_ring = kk;
     } else {
         bound = 3.0e38f;
@@ -353,9 +375,9 @@ int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_rad
     PoseArg P{};
     if (pose) P = *pose;
     if (k == 1)
-        hipLaunchKernelGGL(k_knn<1>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, c->grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
+        hipLaunchKernelGGL(k_knn<1>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
     else
-        hipLaunchKernelGGL(k_knn<5>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, c->grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
+        hipLaunchKernelGGL(k_knn<5>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
     HIP_TRY(c, hipGetLastError());
     return DCREG_OK;
 }
@@ -405,7 +427,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_partials, c->d_poses, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->h_out) (void)hipHostFree(c->h_out);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
@@ -465,7 +487,7 @@ int dcreg_knn(dcreg_ctx *c, const float *q, int64_t n, int64_t stride, int k, do
     int rc = upload_cloud(c, q, n, stride, false, c->d_aligned, c->aligned_cap);
     if (rc) return rc;
     if (ensure(c, c->d_nn_idx, c->nn_idx_cap, (size_t)n * k) || ensure(c, c->d_nn_d2, c->nn_d2_cap, (size_t)n * k)) return DCREG_E_NOMEM;
-    rc = launch_knn(c, c->d_aligned, n, k, max_radius, nullptr, c->d_nn_idx, c->d_nn_d2);
+    rc = launch_knn(c, c->grid, c->d_aligned, n, k, max_radius, nullptr, c->d_nn_idx, c->d_nn_d2);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(idx, c->d_nn_idx, sizeof(int32_t) * (size_t)n * k, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d2, c->d_nn_d2, sizeof(float) * (size_t)n * k, hipMemcpyDeviceToHost, c->stream));

@@ -30,6 +30,13 @@ struct dcreg_ctx {
     double radius_hint = 0.0;
     int last_max_ring = 0;
 
+    // auxiliary grid over the body-frame source (backward pass of dcreg_p2p_error)
+    float4 *d_aux = nullptr; size_t aux_cap = 0;
+    uint32_t *d_aux_cell_start = nullptr; size_t aux_cell_cap = 0;
+    dcreg::GridDev aux_grid{};
+    int64_t aux_n_cells = 0;
+    bool aux_valid = false;
+
     // source
     int64_t n_src = 0;
     float4 *d_src_raw = nullptr; size_t src_raw_cap = 0;
@@ -71,6 +78,6 @@ struct dcreg_ctx {
 namespace dcreg {
 int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
                      dcreg_lin_out *outs, dcreg_lin_debug *dbg_host);
-int launch_knn(dcreg_ctx *c, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
+int launch_knn(dcreg_ctx *c, const GridDev &grid, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
                int32_t *d_idx, float *d_d2);
 }  // namespace dcreg

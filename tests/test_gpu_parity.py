@@ -256,3 +256,43 @@ def test_full_size_properties_1m(ctx):
     gi, gd = ctx.knn(q, k=5, max_radius=1.0)
     oi, od = tree.knn(q, k=5)
     assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_p2p_error_matches_oracle_and_golden(ctx, cyl):
+    """dcreg_p2p_error (utils.hpp:538-589) vs the oracle and the committed all_results.csv (release run)."""
+    pts, tree = cyl
+    ctx.set_target(pts, 1.0)
+    ctx.set_source(pts)
+    for method in ("ME-SR", "ME-TReg"):
+        res, logs = ctx.icp_run(h.pose6d_matrix(**h.RELEASE_INIT), method, _cfg(False))
+        T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
+        rmse, fit, chamfer, valid = ctx.p2p_error(T, 0.2)
+        aligned = (pts.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        ormse, ofit, ochamfer, ovalid = po.p2p_error(aligned, tree, 0.2)
+        assert valid == ovalid
+        assert np.isclose(rmse, ormse, rtol=1e-6) and np.isclose(fit, ofit, rtol=1e-12) and np.isclose(chamfer, ochamfer, rtol=1e-5)
+        allr = [r for r in h.golden_rows("release", "all_results.csv") if r["Method"] == method][0]
+        assert np.isclose(rmse, float(allr["P2P_RMSE"]), rtol=5e-5)
+        assert np.isclose(fit, float(allr["P2P_Fitness"]), rtol=5e-5)
+        assert np.isclose(chamfer, float(allr["Chamfer_Distance"]), rtol=5e-5)
+
+
+def test_montecarlo_driver_on_gpu(ctx, cyl):
+    """The Monte-Carlo driver fed by the batched GPU engine equals trial-by-trial oracle runs."""
+    from dcreg_amd import montecarlo as mc
+    pts, tree = cyl
+    ctx.set_target(pts, 1.0)
+    ctx.set_source(pts)
+    cfg = _cfg(True, max_iterations=12)
+    base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+    recs, stats = mc.run_montecarlo(lambda T0s: ctx.icp_run_trials(T0s, "Ours", cfg), base, 9, seed=7, trans_amp=0.3,
+                                    rot_amp_rad=h.deg2rad(1.0), batch=4)
+    assert recs.shape == (9, mc.REC) and stats["total_runs"] == 9
+    ocfg = _ocfg(True, max_iterations=12)
+    for k in range(9):
+        ores, ologs = po.icp_run(tree, pts, mc.trial_pose(base, k, 7, 0.3, h.deg2rad(1.0)), "Ours", ocfg)
+        assert recs[k, mc.R_CONV] == ores.converged and recs[k, mc.R_ITERS] == ores.iterations
+        T = recs[k, mc.R_T:mc.R_T + 16].reshape(4, 4)
+        assert np.allclose(T[:3, :3].reshape(9), ores.R[:], atol=1e-9) and np.allclose(T[:3, 3], ores.t[:], atol=1e-9)
+        if ologs:
+            assert recs[k, mc.R_CORR] == ologs[-1].n_eff

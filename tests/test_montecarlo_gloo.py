@@ -1,0 +1,100 @@
+"""Multi-process (gloo, world_size 2) test of the trial sharding + statistics gather used for the multi-GPU
+Monte-Carlo path.  On CPU the per-trial ICP is played by the oracle (tests may use it); on the GPU node the
+same driver is fed by Context.icp_run_trials and the gather runs over RCCL."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+
+import helpers as h
+from dcreg_amd import montecarlo as mc
+
+N_TRIALS = 7
+BASE = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+
+
+def _oracle_runner():
+    from oracle import pyoracle as po
+    pts = h.cylinder_cloud()
+    tree = po.KdTree(pts)
+    cfg = po.default_config(search_radius=1.0, max_iterations=12, thresh_trans=1e-3, thresh_rot=1e-5, kappa_target=10.0,
+                            std_reg_gamma=100.0, use_weight_derivative=1, always_compute_schur=1, num_threads=2)
+
+    def run(T0s):
+        out = []
+        for T0 in T0s:
+            res, logs = po.icp_run(tree, pts, T0, "Ours", cfg)
+            T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
+            te, re_ = po.pose_error(np.eye(4), T)
+            last = logs[-1] if logs else None
+            out.append(types.SimpleNamespace(
+                converged=res.converged, iterations=res.iterations, status=res.status, time_ms=1.0, trans_error_m=te,
+                rot_error_deg=re_, final_rmse=last.rmse if last else 0.0, final_fitness=last.fitness if last else 0.0,
+                corr_num=last.n_eff if last else 0, final_transform=T.reshape(16), H_upper=np.array(last.H_upper[:]) if last else np.zeros(21),
+                degenerate_mask=np.array(last.an.mask[:]) if last else np.zeros(6)))
+        return out
+    return run
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs, stats = mc.run_montecarlo(_oracle_runner(), BASE, N_TRIALS, seed=123, trans_amp=0.3, rot_amp_rad=h.deg2rad(1.0),
+                                    rank=rank, world=world, dist=dist, batch=2)
+    q.put((rank, recs, stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trial_poses_are_seeded_and_rank_independent():
+    a = mc.trial_pose(BASE, 5, 123, 0.3, 0.01)
+    b = mc.trial_pose(BASE, 5, 123, 0.3, 0.01)
+    c = mc.trial_pose(BASE, 6, 123, 0.3, 0.01)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.allclose(a[:3, :3] @ a[:3, :3].T, np.eye(3), atol=1e-14)
+    assert np.max(np.abs(a[:3, 3] - np.array(BASE[:3]))) <= 0.3
+    idx = [mc.shard_indices(10, r, 4) for r in range(4)]
+    assert sorted(np.concatenate(idx).tolist()) == list(range(10))
+    assert np.allclose(mc.pose6d_matrix(*BASE), h.pose6d_matrix(*BASE[:3], *BASE[3:]))
+
+
+def test_statistics_definitions():
+    recs = np.zeros((4, mc.REC))
+    recs[:, mc.R_CONV] = [1, 0, 1, 1]
+    recs[:, mc.R_TERR] = [0.1, 0.2, 0.3, 0.4]
+    recs[:, mc.R_RERR] = [1.0, 2.0, 3.0, 4.0]
+    recs[:, mc.R_TIME] = [5, 5, 5, 5]
+    recs[:, mc.R_ITERS] = [10, 30, 8, 12]
+    st = mc.method_statistics(recs)
+    assert st["success_rate"] == 0.75 and st["total_runs"] == 4
+    assert np.isclose(st["mean_trans_error"], 0.25) and np.isclose(st["std_trans_error"], np.std([0.1, 0.2, 0.3, 0.4]))  # population std
+    assert st["min_rot_error"] == 1.0 and st["max_rot_error"] == 4.0 and st["std_time_ms"] == 0.0
+    assert st["mean_iterations"] == 15.0
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_equals_single_process():
+    import torch.multiprocessing as tmp
+    single_recs, single_stats = mc.run_montecarlo(_oracle_runner(), BASE, N_TRIALS, seed=123, trans_amp=0.3,
+                                                  rot_amp_rad=h.deg2rad(1.0))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, recs, stats in got:
+        assert recs.shape == (N_TRIALS, mc.REC)
+        assert np.array_equal(recs[:, mc.R_TRIAL], np.arange(N_TRIALS))
+        # identical trial results no matter which rank computed them (deterministic), hence identical statistics
+        assert np.array_equal(np.delete(recs, mc.R_TIME, 1), np.delete(single_recs, mc.R_TIME, 1))
+        assert stats == single_stats
+    assert 0 < single_stats["converged_runs"] <= N_TRIALS
