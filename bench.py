@@ -88,33 +88,28 @@ def main():
     # initial misalignment of every run: a few cm / tenths of a degree (frame-to-frame LiDAR odometry regime);
     # the synthetic pair converges from it, so every iteration keeps ~all correspondences alive
     T_init = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
-    L = api.load()
     import ctypes as C
+    L = api.load()
     dp = C.POINTER(C.c_double)
+    R0 = np.ascontiguousarray(T_init[:3, :3]).reshape(9).copy()
+    t0 = T_init[:3, 3].copy()
+    res = api.IcpResult()
+    state = {"done": 0}
 
-    state = {"R": np.ascontiguousarray(T_init[:3, :3]).reshape(9).copy(), "t": T_init[:3, 3].copy(), "it": 0,
-             "n_eff": 0, "last": None}
-    out = api.LinOut()
-    an = api.Analysis()
-    Hm = np.empty(36)
-    dx = np.empty(6)
-    Rn, tn = np.empty(9), np.empty(3)
-
-    def step():
-        """one ICP iteration: device linearisation + host analyse/solve/update (icp_test_runner.cpp:1704-1953)"""
-        if state["it"] == run_len:                  # next run of the same pair from the initial pose
-            state["R"][:] = T_init[:3, :3].reshape(9); state["t"][:] = T_init[:3, 3]; state["it"] = 0
-        rc = ctx.linearize_raw(state["R"], state["t"], prm, out)
-        if rc != 0:
-            raise RuntimeError("dcreg_linearize failed")
-        L.dcreg_unpack_hessian(out.H_upper, Hm.ctypes.data_as(dp))
-        L.dcreg_analyze_degeneracy(Hm.ctypes.data_as(dp), api.DETECTION[det], api.HANDLING[hand], C.byref(cfg), C.byref(an))
-        L.dcreg_solve_degenerate_system(Hm.ctypes.data_as(dp), out.g, api.HANDLING[hand], C.byref(cfg), C.byref(an), dx.ctypes.data_as(dp))
-        L.dcreg_boxplus(state["R"].ctypes.data_as(dp), state["t"].ctypes.data_as(dp), dx.ctypes.data_as(dp),
-                        Rn.ctypes.data_as(dp), tn.ctypes.data_as(dp))
-        state["R"][:] = Rn; state["t"][:] = tn
-        state["it"] += 1
-        state["n_eff"] = out.n_eff
+    def run_steps(k):
+        """k ICP iterations through the product's engine seam (dcreg_icp_run: device linearisation + host
+        Schur analysis / PCG / SE(3) update per iteration, all in C++), as runs of `run_len` iterations from the
+        initial pose; convergence thresholds are 0 so every run has exactly its max_iterations iterations."""
+        left = k
+        while left > 0:
+            n = min(run_len, left)
+            cfg.max_iterations = n
+            rc = L.dcreg_icp_run(ctx._h, R0.ctypes.data_as(dp), t0.ctypes.data_as(dp), api.DETECTION[det], api.HANDLING[hand],
+                                 C.byref(cfg), None, 0, C.byref(res))
+            if rc != 0 or res.iterations != n:
+                raise RuntimeError("dcreg_icp_run failed: rc=%d iterations=%d status=%d %s" % (rc, res.iterations, res.status, L.dcreg_last_error(ctx._h)))
+            left -= n
+        state["done"] += k
 
     def fence():
         torch.cuda.synchronize()
@@ -122,16 +117,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     ctx.set_option("time_kernels", 1)
     ctx.kernel_time(reset=True)
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    t_start = time.perf_counter()
+    run_steps(args.steps)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t_start
     kern_ms, kern_n = ctx.kernel_time(reset=True)
     ctx.set_option("time_kernels", 0)
     if dist is not None:
@@ -140,9 +133,10 @@ def main():
         elapsed = float(tmax.item())
 
     # final statistics gather (the only collective): per-rank pose error / rmse / correspondences
-    T_fin = np.eye(4); T_fin[:3, :3] = state["R"].reshape(3, 3); T_fin[:3, 3] = state["t"]
+    T_fin = np.eye(4); T_fin[:3, :3] = np.array(res.R[:]).reshape(3, 3); T_fin[:3, 3] = res.t[:]
     te, re_ = api.pose_error(np.eye(4), T_fin)
-    rec = torch.tensor([te, re_, float(state["n_eff"]), kern_ms / max(kern_n, 1)], dtype=torch.float64, device="cuda")
+    last = ctx.linearize(T_fin[:3, :3], T_fin[:3, 3], prm)
+    rec = torch.tensor([te, re_, float(last["n_eff"]), kern_ms / max(kern_n, 1)], dtype=torch.float64, device="cuda")
     if dist is not None:
         allrec = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
@@ -166,7 +160,7 @@ def main():
             "correspondence_queries_per_s": iters_per_s * len(src),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_linearize<0> (fused 5-NN + plane fit + J^T J reduction) + k_finalize",
+                         "kernel": "k_linearize (fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r reduction)",
                          "kernel_us_avg": kern_us, "algorithmic_bytes_per_launch": algo_bytes},
             "final_stats": {"mean_trans_error_m": float(np.mean(recs[:, 0])), "mean_rot_error_deg": float(np.mean(recs[:, 1])),
                             "mean_correspondences": float(np.mean(recs[:, 2]))},

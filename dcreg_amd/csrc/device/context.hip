@@ -322,7 +322,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (dd.stats) HIP_TRY(c, hipMemcpyAsync(dbg_host->stats, dd.stats, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.clocks) HIP_TRY(c, hipMemcpyAsync(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 8 * ((n + 63) / 64), hipMemcpyDeviceToHost, c->stream));
     }
-    if (dbg_host || c->opt_time_kernels || !c->opt_spin) {
+    if (dbg_host || !c->opt_spin) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else {
         // hot path: spin on the sequence numbers the finalize kernel publishes into pinned host memory
@@ -343,7 +343,9 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     if (dbg_host) HIP_TRY(c, hipGetLastError());
     if (c->opt_time_kernels) {
         float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        hipError_t te = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        if (te == hipErrorNotReady) { HIP_TRY(c, hipEventSynchronize(c->ev1)); te = hipEventElapsedTime(&ms, c->ev0, c->ev1); }
+        HIP_TRY(c, te);
         c->kernel_ms_total += ms; c->kernel_launches += 1;
     }
     for (int i = 0; i < n_poses; ++i) {

@@ -1,0 +1,81 @@
+"""Turn gpurun_out/prof_<tag>_<workload>/ (rocprofv3 CSVs) into profiles/<tag>_<workload>.{md,json}."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, wl = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern), recursive=True)
+    return g[0] if g else None
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()[:60]
+
+out = {"tag": tag, "workload": wl}
+md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
+      "Command: `python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload %s` under", 
+      "`rocprofv3 --kernel-trace --stats` and separate `--pmc` passes (scripts/collect_profiles.sh).", ""]
+md[2] = md[2] % wl
+bp = os.path.join(src, "bench_plain.json")
+if os.path.exists(bp) and os.path.getsize(bp):
+    try:
+        b = json.loads(open(bp).read().strip().split("\n")[-1])
+        out["bench_unprofiled"] = {k: b[k] for k in ("value", "ms_per_step", "roofline", "correspondence_queries_per_s") if k in b}
+        md += ["Un-profiled bench line: value %.1f it/s, %.3f ms/step, kernel (HIP events) %.2f us, roofline frac %.4f" % (
+            b["value"], b["ms_per_step"], b["roofline"]["kernel_us_avg"], b["roofline"]["frac"]), ""]
+    except Exception as e:
+        md += ["(bench line unreadable: %s)" % e, ""]
+kt = one("trace/**/*kernel_trace.csv")
+if kt:
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    md += ["## Kernel trace (ns)", "", "| kernel | calls | avg | min | max | total |", "|---|---|---|---|---|---|"]
+    ks = {}
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        md.append("| %s | %d | %.0f | %d | %d | %d |" % (k, len(v), sum(v) / len(v), min(v), max(v), sum(v)))
+        ks[k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)}
+    out["kernel_trace"] = ks
+    md.append("")
+def counters(sub):
+    f = one(sub + "/**/*counter_collection.csv")
+    res = collections.defaultdict(lambda: collections.defaultdict(list))
+    if f:
+        for r in csv.DictReader(open(f)):
+            res[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return res
+pm = {}
+for sub in ("fetch", "write", "sq1", "sq2", "tcc"):
+    for k, v in counters(sub).items():
+        if "k_linearize" in k or "k_finalize" in k:
+            for cn, vals in v.items():
+                pm.setdefault(k, {})[cn] = sum(vals) / len(vals)
+out["pmc_per_dispatch"] = pm
+if pm:
+    md += ["## PMC counters, mean per dispatch", ""]
+    for k, v in pm.items():
+        md.append("**%s**" % k)
+        md.append("")
+        md += ["| counter | value |", "|---|---|"] + ["| %s | %.4g |" % (a, b) for a, b in sorted(v.items())] + [""]
+    lin = next((v for k, v in pm.items() if "k_linearize" in k), None)
+    if lin and "FETCH_SIZE" in lin:
+        fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
+        raw = (fetch_kb + write_kb) * 1024.0
+        corr = (2.0 * fetch_kb + write_kb) * 1024.0
+        out["traffic"] = {"fetch_kb": fetch_kb, "write_kb": write_kb, "bytes_raw": raw, "bytes_fetch_x2": corr,
+                          "note": "FETCH_SIZE/WRITE_SIZE are KB at the L2<->fabric boundary (Infinity-Cache hits included). gfx950 "
+                                  "under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM); this kernel's reads are 16-byte "
+                                  "gathers + 4-byte table reads, for which the factor is uncalibrated: both figures are given."}
+        md += ["## HBM-side traffic of k_linearize per launch", "",
+               "FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB -> %.2f MB raw, %.2f MB with the guide's x2 read correction." % (fetch_kb, write_kb, raw / 1e6, corr / 1e6), ""]
+    if lin and "SQ_WAVES" in lin:
+        w = lin["SQ_WAVES"]
+        md += ["## Per-wave instruction mix of k_linearize", "",
+               "waves %.0f; per wave: VALU %.0f, SALU %.0f, LDS %.0f, VMEM_RD %.0f; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (
+                   w, lin.get("SQ_INSTS_VALU", 0) / w, lin.get("SQ_INSTS_SALU", 0) / w, lin.get("SQ_INSTS_LDS", 0) / w,
+                   lin.get("SQ_INSTS_VMEM_RD", 0) / w, lin.get("SQ_WAIT_ANY", 0) / max(lin.get("SQ_WAVE_CYCLES", 1), 1)), ""]
+        out["per_wave"] = {"valu": lin.get("SQ_INSTS_VALU", 0) / w, "salu": lin.get("SQ_INSTS_SALU", 0) / w}
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+open(os.path.join(ROOT, "profiles", "%s_%s.md" % (tag, wl)), "w").write("\n".join(md) + "\n")
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, wl)), "w"), indent=1)
+print("\n".join(md))
