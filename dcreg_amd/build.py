@@ -9,6 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdcreg_hip.so")
 OBJDIR = os.path.join(HERE, "build")
+BINDIR = os.path.join(HERE, "bin")
+RUNNER = os.path.join(BINDIR, "icp_test_runner")
 
 SOURCES = [
     "device/context.hip",
@@ -54,6 +56,16 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
     if force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # the experiment driver (icp_test_runner surface) on top of the C-ABI
+    os.makedirs(BINDIR, exist_ok=True)
+    rsrc = os.path.join(CSRC, "runner", "test_runner.cpp")
+    rdeps = [rsrc, os.path.join(CSRC, "runner", "yaml_lite.hpp"), os.path.join(CSRC, "runner", "pcd_io.hpp"), hdrs[-1], LIB]
+    if force or _newer(RUNNER, rdeps):
+        cmd = [hipcc, "-x", "c++", "-O2", "-std=c++17", rsrc, "-x", "none", "-o", RUNNER, "-L" + LIBDIR, "-ldcreg_hip",
+               "-Wl,-rpath,$ORIGIN/../lib", "-Wall"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -1,0 +1,78 @@
+"""The icp_test_runner executable (YAML + PCD + report writers on top of the C-ABI) vs the reference's
+committed output files.  CPU part: the YAML-subset parser and PCD reader are exercised through the binary's
+config loading (no GPU -> clean failure).  GPU part: full runs diffed against tests/golden/*."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as h
+
+RUNNER = os.path.join(h.REPO, "dcreg_amd", "bin", "icp_test_runner")
+
+
+def _run(cfg, outdir):
+    return subprocess.run([RUNNER, os.path.join(h.REPO, "configs", cfg), outdir], cwd=h.REPO, capture_output=True, text=True, timeout=900)
+
+
+def test_runner_parses_config_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    assert os.path.exists(RUNNER), "run __graft_entry__.build() first"
+    p = _run("icp.yaml", str(tmp_path))
+    assert "CONVERGENCE_THRESH_TRANS: 0.001" in p.stdout and "STD_REG_GAMMA: 100" in p.stdout and "KAPPA_TARGET: 10" in p.stdout
+    assert "Loaded point clouds - Source: 7562 points, Target: 7562 points" in p.stdout
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and "no CPU fallback" in p.stderr
+    bad = subprocess.run([RUNNER, "/nonexistent.yaml"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Failed to load configuration" in bad.stderr
+
+
+def _rows(path, method=None):
+    rows = h.read_csv_rows(path)
+    return [r for r in rows if method is None or r["Method"] == method]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,family", [("icp.yaml", "release"), ("icp_paper.yaml", "paper")])
+def test_runner_outputs_match_committed_files(cfg, family, tmp_path):
+    out = str(tmp_path) + "/"
+    p = _run(cfg, out)
+    assert p.returncode == 0, p.stderr[-2000:]
+    if family == "release":
+        assert "XICP" in p.stdout and "skipped" in p.stdout          # out-of-scope engine is reported, not run
+    methods = ["FCN-SR", "ME-SR", "ME-TReg", "ME-TSVD"] + (["Ours"] if family == "paper" else [])
+    ours = _rows(out + "all_results.csv")
+    assert [r["Method"] for r in ours] == methods                     # std::map (lexicographic) order
+    tol = 5e-5
+    for m in methods:
+        a = [r for r in ours if r["Method"] == m][0]
+        g = _rows(os.path.join(h.GOLDEN, family, "all_results.csv"), m)[0]
+        assert a["Converged"] == g["Converged"] and a["Iterations"] == g["Iterations"]
+        for k in ("Trans_Error_m", "Rot_Error_deg", "ICP_RMSE", "ICP_Fitness", "P2P_RMSE", "P2P_Fitness", "Chamfer_Distance"):
+            assert np.isclose(float(a[k]), float(g[k]), rtol=tol), (m, k, a[k], g[k])
+        # per-iteration files: same rows, numeric columns equal to the golden's printed precision
+        for fname, skip, atol in (("iteration_history.csv", (), 2e-6), ("condition_numbers_detailed.csv", (), None),
+                                  ("iteration_details_with_dx.csv", ("Time_ms",), 2e-6)):
+            A, G = _rows(out + fname, m), _rows(os.path.join(h.GOLDEN, family, fname), m)
+            assert len(A) == len(G), (fname, m)
+            assert list(A[0].keys()) == list(G[0].keys()), fname
+            for ra, rg in zip(A, G):
+                for k in rg:
+                    if k in ("Method",) + skip:
+                        continue
+                    va, vg = float(ra[k]), float(rg[k])
+                    if np.isnan(vg):
+                        assert np.isnan(va), (fname, m, k)
+                    elif atol is None:
+                        assert np.isclose(va, vg, rtol=3e-5, atol=1e-9), (fname, m, k, va, vg)
+                    else:
+                        scale = max(1.0, abs(vg))
+                        loose = 3e-4 if k.startswith("grad") else (2e-5 if k in ("P2P_RMSE", "Chamfer_Distance", "Trans_Error_m") else atol)
+                        assert abs(va - vg) <= loose * scale, (fname, m, k, va, vg)
+    txt = open(out + "statistics_summary.txt").read()
+    gold = open(os.path.join(h.GOLDEN, family, "statistics_summary.txt")).read()
+    assert txt.splitlines()[0] == gold.splitlines()[0] and "Detailed Statistics:" in txt
+    for line in gold.splitlines():
+        if line.strip().startswith("Converged:"):
+            assert line in txt
