@@ -38,21 +38,26 @@ struct LinArgs {
     int max_ring;                 // rings needed to cover the radius
 };
 
-// ---------------------------------------------------------------- k-NN heap (sorted, K entries)
-// key = (float bits of d2) << 32 | original index  -> total order (d2, idx), ties -> lower index.
-template <int K>
-struct Heap {
+// ---------------------------------------------------------------- k-NN heaps (sorted, K entries)
+constexpr uint32_t kGlobalTag = 0x80000000u;   // heap positions carry this tag (reserved for LDS-resident variants)
+
+// Exact heap: key = (float bits of d2) << 32 | original index -> total order (d2, idx), ties -> lower index.
+template <int K_>
+struct HeapExact {
+    static constexpr int K = K_;
     uint64_t key[K];
     uint32_t pos[K];
     uint32_t n_eval;     // candidates evaluated (statistics only; dead code unless read)
     uint32_t n_shell;    // outermost shell scanned
-    __device__ __forceinline__ void init(uint64_t bound) {
+    __device__ __forceinline__ void init(float bound_f) {
+        const uint64_t bound = ((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull;
 #pragma unroll
         for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
         n_eval = 0; n_shell = 1;
     }
-    __device__ __forceinline__ void push(uint64_t k, uint32_t p) {
+    __device__ __forceinline__ void push(float d2, uint32_t idx, uint32_t p) {
         ++n_eval;
+        const uint64_t k = ((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)idx;
         if (k < key[K - 1]) {
             key[K - 1] = k; pos[K - 1] = p;
 #pragma unroll
@@ -66,6 +71,49 @@ struct Heap {
         }
     }
     __device__ __forceinline__ float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)); }
+    __device__ __forceinline__ float dist(int j) const { return __uint_as_float((uint32_t)(key[j] >> 32)); }
+    __device__ __forceinline__ bool full() const { return pos[K - 1] != kNoIdx; }
+};
+
+// Fast heap: 32-bit keys (d2 only, strict <), half the insertion cost of the exact heap.  It yields the
+// exact neighbour SET unless some candidate outside the final heap has d2 == the K-th best d2; that case
+// is detected exactly (smallest rejected d2 / last evicted d2) and the caller re-runs the exact heap.
+// Order among equal d2 inside the heap is fixed afterwards (canonical (d2, idx) order).
+template <int K_>
+struct HeapFast {
+    static constexpr int K = K_;
+    float d[K];
+    uint32_t pos[K];
+    float rej_min, evict_last;
+    uint32_t n_eval, n_shell;
+    __device__ __forceinline__ void init(float bound_f) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { d[i] = bound_f; pos[i] = kNoIdx; }
+        rej_min = __builtin_inff(); evict_last = __builtin_inff();
+        n_eval = 0; n_shell = 1;
+    }
+    __device__ __forceinline__ void push(float d2, uint32_t /*idx*/, uint32_t p) {
+        ++n_eval;
+        const bool better = d2 < d[K - 1];
+        rej_min = fminf(rej_min, better ? __builtin_inff() : d2);
+        if (better) {
+            evict_last = d[K - 1];
+            d[K - 1] = d2; pos[K - 1] = p;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool sw = d[j] < d[j - 1];
+                const float da = d[j - 1], db = d[j];
+                const uint32_t pa = pos[j - 1], pb = pos[j];
+                d[j - 1] = sw ? db : da; d[j] = sw ? da : db;
+                pos[j - 1] = sw ? pb : pa; pos[j] = sw ? pa : pb;
+            }
+        }
+    }
+    __device__ __forceinline__ float worst_d2() const { return d[K - 1]; }
+    __device__ __forceinline__ float dist(int j) const { return d[j]; }
+    __device__ __forceinline__ bool full() const { return pos[K - 1] != kNoIdx; }
+    // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
+    __device__ __forceinline__ bool boundary_tie() const { return full() && (rej_min == d[K - 1] || evict_last == d[K - 1]); }
 };
 
 // float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
@@ -86,23 +134,19 @@ __device__ __forceinline__ void body_to_global(const PoseArg &P, double px, doub
     qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
 }
 
-constexpr uint32_t kGlobalTag = 0x80000000u;   // heap position refers to the global sorted array (else: LDS tile slot)
-
-template <int K>
-__device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz,
-                                         Heap<K> &hp) {
+template <class H>
+__device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
     for (uint32_t p = s; p < e; ++p) {
         const float4 c = g.pts[p];
-        const float d2 = dist2_nofma(qx, qy, qz, c);
-        hp.push(((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)__float_as_uint(c.w), p | kGlobalTag);
+        hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p | kGlobalTag);
     }
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <int K>
+template <class H>
 __device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, Heap<K> &hp);
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
 
 // Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
 // Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
@@ -113,19 +157,19 @@ struct RunList {
     float gap2[9][kBlock];     // squared distance from the query to the row's (y,z) slab
 };
 
-template <int K>
-__device__ __forceinline__ void push_point(Heap<K> &hp, float qx, float qy, float qz, const float4 &c, uint32_t p) {
-    hp.push(((uint64_t)__float_as_uint(dist2_nofma(qx, qy, qz, c)) << 32) | (uint64_t)__float_as_uint(c.w), p | kGlobalTag);
+template <class H>
+__device__ __forceinline__ void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p) {
+    hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p | kGlobalTag);
 }
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
 // closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
 // the ball covers the search radius.
-template <int K>
+template <class H>
 __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, Heap<K> &hp) {   // max_ring < 0: unbounded
-    hp.init(((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull);
+                                           int max_ring, H &hp) {   // max_ring < 0: unbounded
+    hp.init(bound_f);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)max_ring + 1.0;
     if (max_ring >= 0) {
@@ -173,11 +217,12 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
         }
     }
     // ---- phase B: flattened walk over the runs (the wave iterates max-over-lanes of the total, not the
-    // sum of per-row maxima), 4 candidates in flight per trip
+    // sum of per-row maxima), 4 candidates per trip, software-pipelined: the loads of trip t+1 are issued
+    // before the 4 insertions of trip t, so L2 latency hides behind the insertion code.
     {
         int ri = 0;
         uint32_t p = 0, e = 0;
-        while (true) {
+        auto advance = [&]() {      // position (p,e) on the next candidate; false when the list is exhausted
             while (p >= e && ri < nrun) {
                 const float g2 = rl.gap2[ri][tid];
                 const uint32_t s_ = rl.s[ri][tid], e_ = rl.e[ri][tid];
@@ -185,26 +230,33 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
                 if (g2 > hp.worst_d2()) continue;     // every point of this row is farther than the K-th best
                 p = s_; e = e_;
             }
-            if (p >= e) break;
-            const uint32_t last = e - 1;
-            const float4 c0 = g.pts[p], c1 = g.pts[min(p + 1, last)], c2 = g.pts[min(p + 2, last)], c3 = g.pts[min(p + 3, last)];
-            push_point<K>(hp, qx, qy, qz, c0, p);
-            if (p + 1 < e) push_point<K>(hp, qx, qy, qz, c1, p + 1);
-            if (p + 2 < e) push_point<K>(hp, qx, qy, qz, c2, p + 2);
-            if (p + 3 < e) push_point<K>(hp, qx, qy, qz, c3, p + 3);
+            return p < e;
+        };
+        bool have = advance();
+        float4 c0, c1, c2, c3;
+        if (have) { const uint32_t last = e - 1; c0 = g.pts[p]; c1 = g.pts[min(p + 1, last)]; c2 = g.pts[min(p + 2, last)]; c3 = g.pts[min(p + 3, last)]; }
+        while (have) {
+            const uint32_t cp = p, ce = e;
+            const float4 d0 = c0, d1 = c1, d2_ = c2, d3 = c3;
             p += 4;
+            have = advance();
+            if (have) { const uint32_t last = e - 1; c0 = g.pts[p]; c1 = g.pts[min(p + 1, last)]; c2 = g.pts[min(p + 2, last)]; c3 = g.pts[min(p + 3, last)]; }
+            push_point<H>(hp, qx, qy, qz, d0, cp);
+            if (cp + 1 < ce) push_point<H>(hp, qx, qy, qz, d1, cp + 1);
+            if (cp + 2 < ce) push_point<H>(hp, qx, qy, qz, d2_, cp + 2);
+            if (cp + 3 < ce) push_point<H>(hp, qx, qy, qz, d3, cp + 3);
         }
     }
-    knn_shells<K>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
 // shells k >= 2 around cell (cx,cy,cz), global loads (sparse neighbourhoods, cloud borders, large
 // misalignment).  kd-tree style pruning on the grid: a (y,z) row is skipped when its slab is farther than
 // the current K-th best, and its x-run is trimmed to the cells the K-th-best ball can still reach.
 // (fx,fy,fz) = query position in cell units.
-template <int K>
+template <class H>
 __device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, Heap<K> &hp) {
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
     for (int k = 1; k < max_ring; ++k) {
@@ -235,14 +287,70 @@ __device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy,
                 const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
                 if (full) {
                     const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
-                    if (x1 > x0) scan_run<K>(g, g.cell_start[row + x0], g.cell_start[row + x1], qx, qy, qz, hp);
+                    if (x1 > x0) scan_run<H>(g, g.cell_start[row + x0], g.cell_start[row + x1], qx, qy, qz, hp);
                 } else {
                     const int xa = cx - kk, xb = cx + kk;
-                    if (xa >= 0 && xa < nx && xa >= xmin) scan_run<K>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
-                    if (xb >= 0 && xb < nx && xb <= xmax) scan_run<K>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
+                    if (xa >= 0 && xa < nx && xa >= xmin) scan_run<H>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
+                    if (xb >= 0 && xb < nx && xb <= xmax) scan_run<H>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------- exact K-NN of one query (fast path + fallback)
+// Runs the 32-bit-key search; if (and only if) a point outside the result ties with the K-th best distance,
+// re-runs the exact 64-bit-key search for this lane.  Output: neighbours in canonical (d2, idx) order.
+template <int K>
+struct KnnResult {
+    float d2[K];
+    uint32_t idx[K];     // original target index
+    float4 pt[K];        // neighbour coordinates (w = idx bits)
+    bool full;           // K neighbours found under the bound
+    uint32_t n_eval, n_shell;
+};
+
+template <int K>
+__device__ __forceinline__ void knn_exact(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring,
+                                          KnnResult<K> &res) {
+    uint32_t pos[K];
+    {
+        HeapFast<K> hf;
+        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
+        res.full = hf.full();
+        res.n_eval = hf.n_eval; res.n_shell = hf.n_shell;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { res.d2[j] = hf.d[j]; pos[j] = hf.pos[j]; }
+        if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo
+            HeapExact<K> he;
+            knn_search<HeapExact<K>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
+            res.n_eval += he.n_eval;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { res.d2[j] = he.dist(j); pos[j] = he.pos[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool ok = pos[j] != kNoIdx;
+        res.pt[j] = ok ? g.pts[pos[j] & ~kGlobalTag] : make_float4(0.f, 0.f, 0.f, 0.f);
+        res.idx[j] = ok ? __float_as_uint(res.pt[j].w) : kNoIdx;
+        if (!ok) res.d2[j] = __builtin_inff();
+    }
+    // canonical order among equal distances (lower index first); entries are already sorted by d2
+    bool any_eq = false;
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) any_eq |= (res.d2[j] == res.d2[j + 1]) && res.idx[j + 1] != kNoIdx;
+    if (any_eq) {
+#pragma unroll
+        for (int a = 0; a + 1 < K; ++a)
+#pragma unroll
+            for (int b = 0; b + 1 < K - a; ++b) {
+                const bool sw = res.d2[b] == res.d2[b + 1] && res.idx[b] > res.idx[b + 1];
+                const uint32_t ia = res.idx[b], ib = res.idx[b + 1];
+                const float4 pa = res.pt[b], pb = res.pt[b + 1];
+                res.idx[b] = sw ? ib : ia; res.idx[b + 1] = sw ? ia : ib;
+                res.pt[b] = sw ? pb : pa; res.pt[b + 1] = sw ? pa : pb;
+            }
     }
 }
 
@@ -453,35 +561,31 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     const double flx = floor(fx), fly = floor(fy), flz = floor(fz);
     const int cx = reach ? (int)flx : 0, cy = reach ? (int)fly : 0, cz = reach ? (int)flz : 0;
 
-    Heap<5> hp;
-    hp.init(((uint64_t)__float_as_uint(a.radius_sq_f) << 32) | 0xFFFFFFFFull);
+    KnnResult<5> nn;
+    nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
     const bool tiled = false;
     if (MODE == 1) clk[1] = clock64();
-    if (reach) knn_search<5>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, hp);
+    if (reach) knn_exact<5>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, nn);
     if (MODE == 1) clk[2] = clock64();
 
     uint8_t flag = 0;
     if (have_q) {
-        const bool have5 = hp.pos[4] != kNoIdx;
-        const bool in_radius = have5 && (double)hp.worst_d2() < a.radius_sq;      // :1726
+        const bool have5 = reach && nn.full;
+        const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
         if (MODE == 1) {
             const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const bool ok = hp.pos[j] != kNoIdx;
-                if (dbg.nn_idx) dbg.nn_idx[5 * (size_t)oi + j] = ok ? (int32_t)(uint32_t)hp.key[j] : -1;
-                if (dbg.nn_d2) dbg.nn_d2[5 * (size_t)oi + j] = ok ? __uint_as_float((uint32_t)(hp.key[j] >> 32)) : __builtin_inff();
+                const bool ok = reach && nn.idx[j] != kNoIdx;
+                if (dbg.nn_idx) dbg.nn_idx[5 * (size_t)oi + j] = ok ? (int32_t)nn.idx[j] : -1;
+                if (dbg.nn_d2) dbg.nn_d2[5 * (size_t)oi + j] = ok ? nn.d2[j] : __builtin_inff();
             }
         }
         if (in_radius) {
             acc[30] = 1.0;                                                          // :1731
             double nqx[5], nqy[5], nqz[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const uint32_t pj = hp.pos[j];
-                const float4 c = g.pts[pj & ~kGlobalTag];
-                nqx[j] = c.x; nqy[j] = c.y; nqz[j] = c.z;
-            }
+            for (int j = 0; j < 5; ++j) { nqx[j] = nn.pt[j].x; nqy[j] = nn.pt[j].y; nqz[j] = nn.pt[j].z; }
             double x[3];
             plane_fit_qr(nqx, nqy, nqz, x);
             const double ps = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
@@ -538,7 +642,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
             }
         }
         if (MODE == 1 && dbg.flag) dbg.flag[__float_as_uint(s4.w)] = flag;
-        if (MODE == 1 && dbg.stats) dbg.stats[__float_as_uint(s4.w)] = (hp.n_eval & 0xFFFFu) | ((hp.n_shell & 0x7FFFu) << 16) | (tiled ? 0x80000000u : 0u);
+        if (MODE == 1 && dbg.stats) dbg.stats[__float_as_uint(s4.w)] = (nn.n_eval & 0xFFFFu) | ((nn.n_shell & 0x7FFFu) << 16) | (tiled ? 0x80000000u : 0u);
     }
 
     if (MODE == 1) clk[3] = clock64();
@@ -576,8 +680,15 @@ static __global__ __launch_bounds__(1024) void k_finalize(const double *__restri
     const uint32_t pose_id = blockIdx.x;
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 32 groups of 32 lanes
     const double *base = partials + (size_t)pose_id * n_blocks * kSlots;
-    double t = 0.0;
-    for (uint32_t b = grp; b < n_blocks; b += 32) t += base[(size_t)b * kSlots + j];
+    // 8 independent accumulators -> 8 loads in flight per lane (fixed association order, deterministic)
+    double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t b = grp;
+    for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] += base[(size_t)(b + u * 32) * kSlots + j];
+    }
+    for (int u = 0; b < n_blocks; b += 32, ++u) t8[u] += base[(size_t)b * kSlots + j];
+    const double t = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
     sm[grp][j] = t;
     __syncthreads();
     if (threadIdx.x < 31) {
@@ -604,14 +715,14 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
     if (apply_pose) {   // pcl::transformPointCloud<PointT,double>: double arithmetic, float store
         body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
-    Heap<K> hp;
-    knn_search<K>(g, runs, qx, qy, qz, bound_f, max_ring, hp);
+    KnnResult<K> nn;
+    knn_exact<K>(g, runs, qx, qy, qz, bound_f, max_ring, nn);
     const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const bool ok = hp.pos[j] != kNoIdx;
-        idx[(size_t)oi * K + j] = ok ? (int32_t)(uint32_t)hp.key[j] : -1;
-        d2[(size_t)oi * K + j] = ok ? __uint_as_float((uint32_t)(hp.key[j] >> 32)) : __builtin_inff();
+        const bool ok = nn.idx[j] != kNoIdx;
+        idx[(size_t)oi * K + j] = ok ? (int32_t)nn.idx[j] : -1;
+        d2[(size_t)oi * K + j] = ok ? nn.d2[j] : __builtin_inff();
     }
 }
 
