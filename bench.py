@@ -29,7 +29,11 @@ WORKLOADS = {
     "c4_corridor_1m": ("corridor", 1_000_000, 1.0, 50),
     "c3_planes_200k": ("planes", 200_000, 0.5, 30),
     "c1_fixture_7562": ("fixture", 7562, 1.0, 30),
+    # Monte-Carlo: 256 independent trials of the fixture pair advance in lock-step; ONE step = one batched launch
+    # = 256 ICP iterations (dcreg_icp_run_trials / dcreg_linearize_batch)
+    "c5_montecarlo_fixture": ("fixture", 7562, 1.0, 30),
 }
+MC_BATCH = 256
 
 
 def make_pair(scene, n, seed):
@@ -94,9 +98,36 @@ def main():
     R0 = np.ascontiguousarray(T_init[:3, :3]).reshape(9).copy()
     t0 = T_init[:3, 3].copy()
     res = api.IcpResult()
-    state = {"done": 0}
+    state = {"done": 0, "mc_iters": 0}
+
+    mc = args.workload.startswith("c5_")
+    if mc:
+        from dcreg_amd import montecarlo as mcm
+        base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+        T0s = np.stack([mcm.trial_pose(base, k + 1000 * rank, 2024, 0.3, h.deg2rad(1.0)) for k in range(MC_BATCH)])
+        R0s = np.ascontiguousarray(T0s[:, :3, :3]).reshape(MC_BATCH, 9)
+        t0s = np.ascontiguousarray(T0s[:, :3, 3]).reshape(MC_BATCH, 3)
+        trial_res = (api.TrialResult * MC_BATCH)()
+
+    def run_steps_mc(k):
+        """k lock-step iterations of MC_BATCH independent trials (each iteration = one batched launch)."""
+        left = k
+        while left > 0:
+            n = min(run_len, left)
+            cfg.max_iterations = n
+            rc = L.dcreg_icp_run_trials(ctx._h, MC_BATCH, R0s.ctypes.data_as(dp), t0s.ctypes.data_as(dp), api.DETECTION[det],
+                                        api.HANDLING[hand], C.byref(cfg), trial_res)
+            if rc != 0:
+                raise RuntimeError("dcreg_icp_run_trials failed: %s" % L.dcreg_last_error(ctx._h))
+            state["mc_iters"] += sum(trial_res[i].iterations for i in range(MC_BATCH))   # trials that abort stop counting
+            left -= n
 
     def run_steps(k):
+        if mc:
+            return run_steps_mc(k)
+        return run_steps_single(k)
+
+    def run_steps_single(k):
         """k ICP iterations through the product's engine seam (dcreg_icp_run: device linearisation + host
         Schur analysis / PCG / SE(3) update per iteration, all in C++), as runs of `run_len` iterations from the
         initial pose; convergence thresholds are 0 so every run has exactly its max_iterations iterations."""
@@ -121,6 +152,7 @@ def main():
     ctx.set_option("time_kernels", 1)
     ctx.kernel_time(reset=True)
     fence()
+    mc_before = state["mc_iters"]
     t_start = time.perf_counter()
     run_steps(args.steps)
     fence()
@@ -145,9 +177,10 @@ def main():
         recs = rec.cpu().numpy()[None, :]
 
     if rank == 0:
-        iters_per_s = n_gpus * args.steps / elapsed
+        per_step = (state["mc_iters"] - mc_before) / args.steps if mc else 1
+        iters_per_s = n_gpus * args.steps * per_step / elapsed
         kern_us = float(np.mean(recs[:, 3])) * 1e3
-        algo_bytes = BYTES_PER_QUERY * n_pts
+        algo_bytes = BYTES_PER_QUERY * n_pts * per_step
         achieved = algo_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         result = {
             "metric": "ICP iterations/sec", "value": iters_per_s, "unit": "iterations/s",
@@ -157,7 +190,7 @@ def main():
             "config": {"workload": "%s: %d-pt source x %d-pt target, radius %.2f, runs of %d ICP iterations, method %s "
                                    "(Schur detection + PCG), one scan pair per GPU" % (args.workload, len(src), len(tgt), radius, run_len, args.method),
                        "n_src": int(len(src)), "n_tgt": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells)},
-            "correspondence_queries_per_s": iters_per_s * len(src),
+            "correspondence_queries_per_s": iters_per_s * len(src), "icp_iterations_per_step": per_step,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_linearize (fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r reduction)",

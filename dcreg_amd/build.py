@@ -50,12 +50,12 @@ def build(force=False, verbose=False):
             cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
                    "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
             if s.endswith(".cpp"):
-                cmd[1:1] = ["-x", "c++"]   # pure host translation units
+                cmd[1:1] = ["-x", "c++", "-fopenmp"]   # pure host translation units (OpenMP: per-trial host steps)
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -2,6 +2,9 @@
 // (DCReg/src/icp_test_runner.cpp:1611-2060) with steps 1-5 of every iteration replaced by ONE call into
 // the device seam (dcreg_linearize), and the num_runs loop of TestRunner::runMethod (:331-390) as a
 // lock-step batch over independent trials (dcreg_icp_run_trials).
+#include <omp.h>
+
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -132,8 +135,10 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
         }
         const int rc = dcreg_linearize_batch(ctx, nl, Rb.data(), tb.data(), &prm, outs.data());
         if (rc != DCREG_OK) return rc;
-        std::vector<int> next;
-        next.reserve((size_t)nl);
+        // host steps 6-9 of every live trial are independent: spread them over host threads
+        std::vector<int> keep((size_t)nl, 0);
+        const int nthreads = std::max(1, std::min({omp_get_max_threads(), 32, nl / 8}));
+#pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int j = 0; j < nl; ++j) {
             const int id = live[(size_t)j];
             dcreg_trial_result &tr = results[id];
@@ -149,8 +154,11 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
             std::memcpy(tr.H_upper, lo.H_upper, sizeof(tr.H_upper));
             std::memcpy(tr.degenerate_mask, so.an.degenerate_mask, sizeof(tr.degenerate_mask));
             if (st == 1) { tr.converged = 1; continue; }
-            next.push_back(id);
+            keep[(size_t)j] = 1;
         }
+        std::vector<int> next;
+        next.reserve((size_t)nl);
+        for (int j = 0; j < nl; ++j) if (keep[(size_t)j]) next.push_back(live[(size_t)j]);
         live.swap(next);
     }
     const double total_ms = ms_since(t_total);
