@@ -181,6 +181,7 @@ def main():
         iters_per_s = n_gpus * args.steps * per_step / elapsed
         kern_us = float(np.mean(recs[:, 3])) * 1e3
         algo_bytes = BYTES_PER_QUERY * n_pts * per_step
+        traffic = measured_traffic(args.workload)
         achieved = algo_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         result = {
             "metric": "ICP iterations/sec", "value": iters_per_s, "unit": "iterations/s",
@@ -192,7 +193,7 @@ def main():
                        "n_src": int(len(src)), "n_tgt": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells)},
             "correspondence_queries_per_s": iters_per_s * len(src), "icp_iterations_per_step": per_step,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_linearize (fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r reduction)",
                          "kernel_us_avg": kern_us, "algorithmic_bytes_per_launch": algo_bytes},
             "final_stats": {"mean_trans_error_m": float(np.mean(recs[:, 0])), "mean_rot_error_deg": float(np.mean(recs[:, 1])),
@@ -205,6 +206,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def measured_traffic(workload):
+    """HBM-side bytes per k_linearize launch from the rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE,
+    separate passes, KB -> bytes, read side x2 per the gfx950 note in MI355X_MICROARCH.md), recorded by
+    scripts/collect_profiles.sh + scripts/summarize_profiles.py under profiles/.  None if no profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % workload))):
+        try:
+            t = json.load(open(f)).get("traffic")
+            if t:
+                best = t["bytes_fetch_x2"]
+        except Exception:
+            pass
+    return best
 
 
 def cpu_baseline(tgt, src, T_init, radius, run_len, method, budget_s):
