@@ -68,7 +68,7 @@ struct dcreg_ctx {
     bool opt_spin = true;          // wait for results by spinning on pinned memory instead of hipStreamSynchronize
     bool need_set_device = true;
     unsigned long long seq = 0;
-    bool opt_tile = true;          // per-wave LDS tiles (false: global-gather path, for A/B)
+    int opt_lanes = 0;             // lanes per query: 0 = auto, else 1 / 2 / 4 / 8
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
 

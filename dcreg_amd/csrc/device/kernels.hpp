@@ -77,19 +77,19 @@ struct HeapExact {
 
 // Fast heap: 32-bit keys (d2 only, strict <), half the insertion cost of the exact heap.  It yields the
 // exact neighbour SET unless some candidate outside the final heap has d2 == the K-th best d2; that case
-// is detected exactly (smallest rejected d2 / last evicted d2) and the caller re-runs the exact heap.
+// is detected exactly (smallest rejected d2 / smallest evicted d2) and the caller re-runs the exact heap.
 // Order among equal d2 inside the heap is fixed afterwards (canonical (d2, idx) order).
 template <int K_>
 struct HeapFast {
     static constexpr int K = K_;
     float d[K];
     uint32_t pos[K];
-    float rej_min, evict_last;
+    float rej_min, evict_min;
     uint32_t n_eval, n_shell;
     __device__ __forceinline__ void init(float bound_f) {
 #pragma unroll
         for (int i = 0; i < K; ++i) { d[i] = bound_f; pos[i] = kNoIdx; }
-        rej_min = __builtin_inff(); evict_last = __builtin_inff();
+        rej_min = __builtin_inff(); evict_min = __builtin_inff();
         n_eval = 0; n_shell = 1;
     }
     __device__ __forceinline__ void push(float d2, uint32_t /*idx*/, uint32_t p) {
@@ -97,7 +97,7 @@ struct HeapFast {
         const bool better = d2 < d[K - 1];
         rej_min = fminf(rej_min, better ? __builtin_inff() : d2);
         if (better) {
-            evict_last = d[K - 1];
+            evict_min = fminf(evict_min, d[K - 1]);
             d[K - 1] = d2; pos[K - 1] = p;
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
@@ -113,7 +113,20 @@ struct HeapFast {
     __device__ __forceinline__ float dist(int j) const { return d[j]; }
     __device__ __forceinline__ bool full() const { return pos[K - 1] != kNoIdx; }
     // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
-    __device__ __forceinline__ bool boundary_tie() const { return full() && (rej_min == d[K - 1] || evict_last == d[K - 1]); }
+    __device__ __forceinline__ bool boundary_tie() const { return full() && (rej_min == d[K - 1] || evict_min == d[K - 1]); }
+    // fold the heap of the lane `lane ^ step` into this one (sub-wave cooperative search); both lanes end up equal
+    __device__ __forceinline__ void merge_xor(int step) {
+        float od[K]; uint32_t op[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { od[j] = __shfl_xor(d[j], step); op[j] = __shfl_xor(pos[j], step); }
+        const float orej = __shfl_xor(rej_min, step), oev = __shfl_xor(evict_min, step);
+        const uint32_t oe = __shfl_xor(n_eval, step), os = __shfl_xor(n_shell, step);
+        rej_min = fminf(rej_min, orej); evict_min = fminf(evict_min, oev);
+        const uint32_t mine = n_eval;
+#pragma unroll
+        for (int j = 0; j < K; ++j) if (op[j] != kNoIdx) push(od[j], 0u, op[j]);
+        n_eval = mine + oe; n_shell = max(n_shell, os);   // statistics: pushes of the merge are not candidates
+    }
 };
 
 // float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
@@ -166,9 +179,11 @@ __device__ __forceinline__ void push_point(H &hp, float qx, float qy, float qz, 
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
 // closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
 // the ball covers the search radius.
+// `lanes` lanes share one query: this lane (`sub`) tests every lanes-th group of 4 candidates of each run and stops
+// before the shells when `do_shells` is false (the group leader runs them after the heaps have been merged).
 template <class H>
 __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, H &hp) {   // max_ring < 0: unbounded
+                                           int max_ring, H &hp, int lanes = 1, int sub = 0, bool do_shells = true) {   // max_ring < 0: unbounded
     hp.init(bound_f);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)max_ring + 1.0;
@@ -232,21 +247,23 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
             }
             return p < e;
         };
+        const uint32_t off = 4u * (uint32_t)sub, stride = 4u * (uint32_t)lanes;
         bool have = advance();
         float4 c0, c1, c2, c3;
-        if (have) { const uint32_t last = e - 1; c0 = g.pts[p]; c1 = g.pts[min(p + 1, last)]; c2 = g.pts[min(p + 2, last)]; c3 = g.pts[min(p + 3, last)]; }
+        if (have) { const uint32_t last = e - 1, q = p + off; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
         while (have) {
-            const uint32_t cp = p, ce = e;
+            const uint32_t cp = p + off, ce = e;
             const float4 d0 = c0, d1 = c1, d2_ = c2, d3 = c3;
-            p += 4;
+            p += stride;
             have = advance();
-            if (have) { const uint32_t last = e - 1; c0 = g.pts[p]; c1 = g.pts[min(p + 1, last)]; c2 = g.pts[min(p + 2, last)]; c3 = g.pts[min(p + 3, last)]; }
-            push_point<H>(hp, qx, qy, qz, d0, cp);
+            if (have) { const uint32_t last = e - 1, q = p + off; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
+            if (cp < ce) push_point<H>(hp, qx, qy, qz, d0, cp);
             if (cp + 1 < ce) push_point<H>(hp, qx, qy, qz, d1, cp + 1);
             if (cp + 2 < ce) push_point<H>(hp, qx, qy, qz, d2_, cp + 2);
             if (cp + 3 < ce) push_point<H>(hp, qx, qy, qz, d3, cp + 3);
         }
     }
+    if (!do_shells) return;
     knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
@@ -310,18 +327,36 @@ struct KnnResult {
     uint32_t n_eval, n_shell;
 };
 
-template <int K>
+// G lanes of a wave (G = 1, 2, 4, 8; consecutive lanes) cooperate on one query: each scans a 1/G share of the
+// candidates, the heaps are merged with a xor butterfly, and the group leader (sub == 0) finishes (shells, ties).
+// Non-leader lanes return with res.full == false.
+template <int K, int G>
 __device__ __forceinline__ void knn_exact(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring,
-                                          KnnResult<K> &res) {
+                                          int sub, KnnResult<K> &res) {
     uint32_t pos[K];
+    res.full = false; res.n_eval = 0; res.n_shell = 1;
     {
         HeapFast<K> hf;
-        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
+        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, G, sub, G == 1);
+        if (G > 1) {
+#pragma unroll
+            for (int step = 1; step < G; step <<= 1) hf.merge_xor(step);
+            if (sub != 0) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) { res.d2[j] = __builtin_inff(); res.idx[j] = kNoIdx; res.pt[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                return;
+            }
+            // leader: shells around the query's cell with the merged heap
+            const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+            int mr = max_ring;
+            const int cx = (int)floor(fx), cy = (int)floor(fy), cz = (int)floor(fz);
+            knn_shells<HeapFast<K>>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, mr, hf);
+        }
         res.full = hf.full();
         res.n_eval = hf.n_eval; res.n_shell = hf.n_shell;
 #pragma unroll
         for (int j = 0; j < K; ++j) { res.d2[j] = hf.d[j]; pos[j] = hf.pos[j]; }
-        if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo
+        if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo by this lane alone
             HeapExact<K> he;
             knn_search<HeapExact<K>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
             res.n_eval += he.n_eval;
@@ -522,14 +557,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 // ---------------------------------------------------------------- the fused linearisation kernel
 // MODE 0: reduction only.  MODE 1: also dump per-point results (parity tests).
-// TILE: reserved for search variants (A/B switch "tile"); both values currently run the per-lane search.
+// G: lanes per query (1, 2, 4, 8).  G > 1 shortens one wave's serial search chain but multiplies the waves that run
+// the plane fit / reductions; measured slower at every size (profiles/r01_search_ablation.md), so G = 1 is the default
+// and the other instantiations are kept only behind the "lanes_per_query" option.
 struct DebugDev {
     int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
     uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16 | tile used << 31
     unsigned long long *clocks;   // per wave: 8 shader-clock stamps (phase breakdown), may be null
 };
 
-template <int MODE, int TILE>
+template <int MODE, int G>
 static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, DebugDev dbg) {
@@ -537,7 +574,9 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     __shared__ RunList runs;
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x);
-    const uint32_t i = vb * kBlock + threadIdx.x;
+    const uint32_t gt = vb * kBlock + threadIdx.x;
+    const uint32_t i = gt / G;                                   // query of this lane
+    const int sub = (int)(gt % G);                               // position inside the query's lane group
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
@@ -563,13 +602,13 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
 
     KnnResult<5> nn;
     nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
-    const bool tiled = false;
+    const bool tiled = G > 1;
     if (MODE == 1) clk[1] = clock64();
-    if (reach) knn_exact<5>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, nn);
+    if (reach) knn_exact<5, G>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, sub, nn);
     if (MODE == 1) clk[2] = clock64();
 
     uint8_t flag = 0;
-    if (have_q) {
+    if (have_q && sub == 0) {
         const bool have5 = reach && nn.full;
         const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
         if (MODE == 1) {
@@ -662,7 +701,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
         }
         partials[((size_t)pose_id * n_blocks_x + vb) * kSlots + threadIdx.x] = t;
     }
-    if (MODE == 1 && dbg.clocks && lane == 0) {
+    if (MODE == 1 && G == 1 && dbg.clocks && lane == 0) {   // (the stamp buffer is sized for one lane per query)
         clk[5] = clock64();
         unsigned long long *o = dbg.clocks + ((size_t)vb * (kBlock / 64) + wave) * 8;
 #pragma unroll
@@ -716,7 +755,7 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
         body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
     KnnResult<K> nn;
-    knn_exact<K>(g, runs, qx, qy, qz, bound_f, max_ring, nn);
+    knn_exact<K, 1>(g, runs, qx, qy, qz, bound_f, max_ring, 0, nn);
     const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
