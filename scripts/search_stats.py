@@ -25,7 +25,7 @@ src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
 ctx.set_option("cell_factor", 2.0)
 ctx.set_target(tgt, 1.0); ctx.set_source(src)
 T0 = h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008)
-for tile in (1, 0):
+for tile in (1,):
     ctx.set_option("tile", tile)
     for rep in range(2):
         out = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(1.0, 1), debug=True)
@@ -33,10 +33,7 @@ for tile in (1, 0):
     c1 = np.where(ck[:, 1] > 0, ck[:, 1], ck[:, 0])
     ph = np.stack([c1 - ck[:, 0], ck[:, 2] - c1, ck[:, 3] - ck[:, 2], ck[:, 4] - ck[:, 3], ck[:, 5] - ck[:, 4], ck[:, 5] - ck[:, 0]], 1)
     names = ["tile-build", "search", "planefit+row", "wave-reduce", "block-reduce", "TOTAL"]
-    print("tile", tile, "tiled frac %.3f" % ck[:, 6].mean())
+    pa, pb, psh = ck[:, 6] & 0xFFFFF, (ck[:, 6] >> 20) & 0xFFFFF, (ck[:, 6] >> 40) & 0xFFFFF
+    print("tile", tile, "search split (lane 0 of each wave): phase A (table loads + run list) mean %d, phase B (candidates) mean %d, shells check mean %d cycles" % (pa.mean(), pb.mean(), psh.mean()))
     for k, nm in enumerate(names):
         print("   %-13s mean %7d  p50 %7d  p99 %7d  max %7d cycles" % (nm, ph[:, k].mean(), np.percentile(ph[:, k], 50), np.percentile(ph[:, k], 99), ph[:, k].max()))
-    for flagv in (0, 1):
-        m = ck[:, 6] == flagv
-        if m.any():
-            print("   waves with tiled=%d: n=%d search mean %d  total mean %d max %d" % (flagv, m.sum(), ph[m, 1].mean(), ph[m, 5].mean(), ph[m, 5].max()))
