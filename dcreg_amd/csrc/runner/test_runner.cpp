@@ -385,6 +385,58 @@ private:
                 }
             }
         }
+        // ---- degeneracy_analysis_first_iter.txt (num_runs == 1), :1030-1197
+        if (config_.num_runs == 1) {
+            std::ofstream f(config_.output_folder + "degeneracy_analysis_first_iter.txt");
+            f << "Degeneracy Analysis Results (First Iteration)\n============================================\n\n";
+            for (const auto &kv : detailed_results_) {
+                if (kv.second.empty()) continue;
+                const auto &r = kv.second[0];
+                if (r.iteration_data.empty()) { f << "Method: " << kv.first << " - No iteration data available\n\n"; continue; }
+                const dcreg_analysis &a = r.iteration_data[0].analysis;
+                f << "Method: " << kv.first << "\n  Condition Numbers:\n" << std::fixed << std::setprecision(2);
+                f << "    Schur Rot: " << a.cond_schur_rot << "\n    Schur Trans: " << a.cond_schur_trans << "\n    Diag Rot: " << a.cond_diag_rot
+                  << "\n    Diag Trans: " << a.cond_diag_trans << "\n    SVD Diag Rot: " << a.cond_full_sub_rot << "\n    SVD Diag Trans: " << a.cond_full_sub_trans
+                  << "\n    Full SVD: " << a.cond_full << "\n";
+                f << "  Eigenvalues (Full): " << std::setprecision(3);
+                for (double v : a.eigenvalues_full) f << v << " ";
+                f << "\n  Degenerate Mask (wxwywz xyz): ";
+                for (int m : a.degenerate_mask) f << (m ? "1" : "0") << " ";
+                f << "\n  Is Degenerate: " << (a.isDegenerate ? "Yes" : "No") << "\n\n" << std::setprecision(6);
+                if (kv.first.find("PCG") != std::string::npos || kv.first == "Ours") {
+                    // the reference logs P with rows/columns permuted by the alignment indices
+                    int perm[6];
+                    for (int i = 0; i < 3; ++i) { perm[i] = a.rot_indices[i]; perm[3 + i] = 3 + a.trans_indices[i]; }
+                    f << "  Preconditioner Matrix P:\n";
+                    for (int i = 0; i < 6; ++i) {
+                        f << "    ";
+                        for (int j = 0; j < 6; ++j) f << std::setw(12) << a.P_preconditioner[perm[i] * 6 + perm[j]] << " ";
+                        f << "\n";
+                    }
+                    f << "\n";
+                }
+                if ((kv.first == "Ours" || kv.first.find("SCHUR") != std::string::npos) && a.isDegenerate) {
+                    f << "  Alignment Analysis:\n";
+                    for (int blk = 0; blk < 2; ++blk) {
+                        f << (blk ? "    Translation Axes:\n" : "    Rotation Axes:\n");
+                        const int *idx = blk ? a.trans_indices : a.rot_indices;
+                        const double *lam = blk ? a.lambda_schur_trans : a.lambda_schur_rot;
+                        const double *V = blk ? a.aligned_V_trans : a.aligned_V_rot;
+                        const char *names = blk ? "XYZ" : "RPY";
+                        for (int i = 0; i < 3; ++i) {
+                            const double v[3] = {V[0 * 3 + i], V[1 * 3 + i], V[2 * 3 + i]};
+                            const double ang = std::acos(std::min(1.0, std::max(0.0, std::fabs(v[i])))) * 180.0 / M_PI;
+                            const double sabs = std::max(1e-9, std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]));
+                            f << "      [" << i << "]~" << names[i] << " (orig_idx=" << idx[i] << "): \xCE\xBB=" << lam[idx[i]] << ", Angle=" << ang << "\xC2\xB0, "
+                              << 100 * std::fabs(v[0]) / sabs << "%" << names[0] << "+" << 100 * std::fabs(v[1]) / sabs << "%" << names[1] << "+"
+                              << 100 * std::fabs(v[2]) / sabs << "%" << names[2] << "\n";
+                        }
+                    }
+                    f << " \n";
+                }
+            }
+            f << "\n\n";
+        }
         // ---- all_results.csv, :996-1028
         {
             std::ofstream f(config_.output_folder + "all_results.csv");

@@ -70,6 +70,19 @@ def test_runner_outputs_match_committed_files(cfg, family, tmp_path):
                         scale = max(1.0, abs(vg))
                         loose = 3e-4 if k.startswith("grad") else (2e-5 if k in ("P2P_RMSE", "Chamfer_Distance", "Trans_Error_m") else atol)
                         assert abs(va - vg) <= loose * scale, (fname, m, k, va, vg)
+    # degeneracy_analysis_first_iter.txt: same text, numbers equal to the printed precision (paper run has "Ours")
+    import re
+    ours_txt = open(out + "degeneracy_analysis_first_iter.txt").read()
+    gold_txt = open(os.path.join(h.GOLDEN, family, "degeneracy_analysis_first_iter.txt")).read()
+    num = re.compile(r"-?\d+\.\d+|-?\d+")
+    for m in methods:
+        blk = lambda t: t.split("Method: " + m + "\n")[1].split("Method: ")[0]
+        bo, bg = blk(ours_txt), blk(gold_txt)
+        assert num.sub("#", bo).split() == num.sub("#", bg).split(), m          # identical wording / layout
+        vo, vg = [float(x) for x in num.findall(bo)], [float(x) for x in num.findall(bg)]
+        assert len(vo) == len(vg)
+        for a, b in zip(vo, vg):
+            assert abs(a - b) <= 2e-5 * max(1.0, abs(b)) + 2e-6, (m, a, b)
     txt = open(out + "statistics_summary.txt").read()
     gold = open(os.path.join(h.GOLDEN, family, "statistics_summary.txt")).read()
     assert txt.splitlines()[0] == gold.splitlines()[0] and "Detailed Statistics:" in txt
