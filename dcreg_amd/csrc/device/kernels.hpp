@@ -428,9 +428,9 @@ __device__ __forceinline__ void householder_step(double (&c0)[5], double (&c1)[5
     } else {
         beta = sqrt(a0 * a0 + tail);
         if (a0 >= 0.0) beta = -beta;
-        const double den = a0 - beta;
+        const double inv_den = 1.0 / (a0 - beta);      // one reciprocal + multiplies (fp64 division is ~11 instructions)
 #pragma unroll
-        for (int i = KCOL + 1; i < 5; ++i) ck[i] = ck[i] / den;
+        for (int i = KCOL + 1; i < 5; ++i) ck[i] = ck[i] * inv_den;
         t = (beta - a0) / beta;
     }
     tau[KCOL] = t;
@@ -556,6 +556,36 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
     return v;
 }
 
+// Transposed wave reduction of 32 per-lane values: a halving butterfly.  At step `bit` every lane keeps half of its
+// values (those whose index has that bit equal to the lane's bit) and adds the partner lane's copies, so the
+// number of live values halves while the number of lanes summed doubles: 16+8+4+2+1 exchanges instead of 32 x 6.
+// After the five halving steps lane l holds value (l & 31) summed over its 32-lane half; one more exchange adds
+// the halves.  Result: EVERY lane l returns the wave total of value (l & 31).  Fixed order -> deterministic.
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), m);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+template <int N, int BIT>
+__device__ __forceinline__ void halve_step(double (&v)[32], int lane) {
+    const bool up = (lane >> BIT) & 1;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const double keep = up ? v[2 * i + 1] : v[2 * i];
+        const double send = up ? v[2 * i] : v[2 * i + 1];
+        v[i] = keep + shfl_xor_f64(send, 1 << BIT);
+    }
+}
+__device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32], int lane) {
+    // index bit b of the value ends up selected by lane bit b: process index bit 0 with lane bit 0 first
+    halve_step<32, 0>(v, lane);   // v[i] now = value 2i + b0
+    halve_step<16, 1>(v, lane);   // value 4i + 2 b1 + b0
+    halve_step<8, 2>(v, lane);
+    halve_step<4, 3>(v, lane);
+    halve_step<2, 4>(v, lane);    // v[0] = value (lane & 31) over the lanes sharing bit 5
+    return v[0] + shfl_xor_f64(v[0], 32);
+}
+
 // XCD-aware block remap: hardware places block b on XCD b%8; give each XCD a contiguous run of query
 // blocks so spatially adjacent (Morton-ordered) queries share that XCD's L2.  Bijective for any n.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
@@ -642,7 +672,8 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
             const double ps = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
             flag = 2;
             if (!(ps < a.min_norm)) {                                               // :1752
-                const double pa = x[0] / ps, pb = x[1] / ps, pc = x[2] / ps, pd = 1.0 / ps;
+                const double pd = 1.0 / ps;
+                const double pa = x[0] * pd, pb = x[1] * pd, pc = x[2] * pd;
                 double maxd = 0.0;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {                                       // :1763-1770
@@ -668,7 +699,8 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
                         flag = 1;
                         const float cxf = (float)(s * pa), cyf = (float)(s * pb), czf = (float)(s * pc);   // :1787-1789
                         const float cif = (float)(s * r);                                                    // :1790
-                        const double nx = (double)cxf / s, ny = (double)cyf / s, nz = (double)czf / s;      // :1889
+                        const double inv_s = 1.0 / s;
+                        const double nx = (double)cxf * inv_s, ny = (double)cyf * inv_s, nz = (double)czf * inv_s;   // :1889
                         // J_r = [ (p x m)^T , m^T ],  m = R^T n   (math_utils.hpp:102-121)
                         const double m0 = P.R[0] * nx + P.R[3] * ny + P.R[6] * nz;
                         const double m1 = P.R[1] * nx + P.R[4] * ny + P.R[7] * nz;
@@ -697,11 +729,15 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     }
 
     if (MODE == 1) clk[3] = clock64();
-    // wave64 DPP reduction -> lane 63 -> LDS -> block partial (fixed order, no float atomics)
+    // transposed wave64 reduction -> lane l holds the wave total of slot (l & 31) -> LDS -> block partial
+    // (fixed order, no float atomics)
+    {
+        double v[32];
 #pragma unroll
-    for (int k = 0; k < 31; ++k) {
-        const double t = wave_sum_to_lane63(acc[k]);
-        if (lane == 63) red[wave][k] = t;
+        for (int k = 0; k < 31; ++k) v[k] = acc[k];
+        v[31] = 0.0;
+        const double t = wave_transpose_reduce32(v, lane);
+        if (lane < 32) red[wave][lane] = t;
     }
     if (MODE == 1) clk[4] = clock64();
     __syncthreads();
