@@ -306,7 +306,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE_, G_) \
-    hipLaunchKernelGGL((k_linearize<MODE_, G_>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd)
+    hipLaunchKernelGGL((k_linearize<MODE_, G_>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd)
     if (dbg_host) {
         switch (G) { case 8: DCREG_LAUNCH_LIN(1, 8); break; case 4: DCREG_LAUNCH_LIN(1, 4); break; case 2: DCREG_LAUNCH_LIN(1, 2); break; default: DCREG_LAUNCH_LIN(1, 1); }
     } else {
@@ -458,6 +458,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "time_kernels") c->opt_time_kernels = v != 0.0;
     else if (k == "tile" || k == "lanes_per_query") c->opt_lanes = (int)v;   // 0 = auto, else 1/2/4/8
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;
 }

@@ -9,6 +9,7 @@ from dcreg_amd import api
 
 ctx = dcreg_amd.Context(0)
 CF = float(os.environ.get('CF', '2.0'))
+ctx.set_option('lds_pad', float(os.environ.get('PAD', '0')))
 ctx.set_option('cell_factor', CF)
 print('cell_factor', CF)
 for n in (7562, 100_000, 1_000_000):
