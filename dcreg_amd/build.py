@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
             cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
-                   "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+                   "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("DCREG_EXTRA_FLAGS", "").split()
             if s.endswith(".cpp"):
                 cmd[1:1] = ["-x", "c++", "-fopenmp"]   # pure host translation units (OpenMP: per-trial host steps)
             if verbose:
