@@ -5,8 +5,8 @@ tag, wl = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, wl))
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern), recursive=True)
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return g[-1] if g else None    # newest run (gpurun_out accumulates earlier runs)
 
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()[:60]
