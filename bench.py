@@ -245,7 +245,7 @@ def cpu_baseline(tgt, src, T_init, radius, run_len, method, budget_s):
             if n % run_len == 0:
                 T = T_init.copy()
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 10 * run_len:
+            if el > budget_s / 2 or n >= 100 * run_len:
                 break
         cand = {"value": n / el, "unit": "iterations/s", "cores": threads, "kind": "port",
                 "sample": "%d ICP iterations of the same scan pair (%d-pt source), OpenMP x%d, %.1f s" % (n, len(src), threads, el)}
