@@ -258,10 +258,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     int rc = make_lin_args(c, p, a);
     if (rc) return rc;
     if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
-    // lanes per query: 1 unless explicitly overridden (G > 1 measured slower at every cloud size)
-    int G = c->opt_lanes;
-    if (G != 2 && G != 4 && G != 8) G = 1;
-    const uint32_t nbx = blocks_for(c->n_src * G, kBlock);
+    const uint32_t nbx = blocks_for(c->n_src, kBlock);
     if (ensure(c, c->d_partials, c->partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     if ((size_t)n_poses > c->out_cap) {
         if (c->h_out) (void)hipHostFree(c->h_out);
@@ -305,14 +302,10 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     }
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
-#define DCREG_LAUNCH_LIN(MODE_, G_) \
-    hipLaunchKernelGGL((k_linearize<MODE_, G_>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd)
-    if (dbg_host) {
-        switch (G) { case 8: DCREG_LAUNCH_LIN(1, 8); break; case 4: DCREG_LAUNCH_LIN(1, 4); break; case 2: DCREG_LAUNCH_LIN(1, 2); break; default: DCREG_LAUNCH_LIN(1, 1); }
-    } else {
-        switch (G) { case 8: DCREG_LAUNCH_LIN(0, 8); break; case 4: DCREG_LAUNCH_LIN(0, 4); break; case 2: DCREG_LAUNCH_LIN(0, 2); break; default: DCREG_LAUNCH_LIN(0, 1); }
-    }
-#undef DCREG_LAUNCH_LIN
+    if (dbg_host)
+        hipLaunchKernelGGL((k_linearize<1>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+    else
+        hipLaunchKernelGGL((k_linearize<0>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
     const unsigned long long seq = ++c->seq;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(1024), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
@@ -456,7 +449,6 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
     else if (k == "time_kernels") c->opt_time_kernels = v != 0.0;
-    else if (k == "tile" || k == "lanes_per_query") c->opt_lanes = (int)v;   // 0 = auto, else 1/2/4/8
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }

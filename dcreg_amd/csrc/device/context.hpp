@@ -69,7 +69,6 @@ struct dcreg_ctx {
     bool need_set_device = true;
     unsigned long long seq = 0;
     int opt_lds_pad = 0;
-    int opt_lanes = 0;             // lanes per query: 0 = auto, else 1 / 2 / 4 / 8
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
 

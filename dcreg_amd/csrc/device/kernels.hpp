@@ -39,7 +39,6 @@ struct LinArgs {
 };
 
 // ---------------------------------------------------------------- k-NN heaps (sorted, K entries)
-constexpr uint32_t kGlobalTag = 0x80000000u;   // heap positions carry this tag (reserved for LDS-resident variants)
 
 // Exact heap: key = (float bits of d2) << 32 | original index -> total order (d2, idx), ties -> lower index.
 template <int K_>
@@ -116,23 +115,6 @@ struct HeapFast {
     __device__ __forceinline__ bool full() const { return pos[K - 1] != kNoIdx; }
     // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
     __device__ __forceinline__ bool boundary_tie() const { return full() && (rej_tie || evict_last == d[K - 1]); }
-    // fold the heap of the lane `lane ^ step` into this one (sub-wave cooperative search); both lanes end up equal
-    __device__ __forceinline__ void merge_xor(int step) {
-        float od[K]; uint32_t op[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) { od[j] = __shfl_xor(d[j], step); op[j] = __shfl_xor(pos[j], step); }
-        const bool orej = __shfl_xor((int)rej_tie, step) != 0;
-        const float oev = __shfl_xor(evict_last, step);
-        const uint32_t oe = __shfl_xor(n_eval, step), os = __shfl_xor(n_shell, step);
-        // conservative union: any tie either lane saw against ITS K-th best may tie with the merged one
-        float worst_seen = fminf(evict_last, oev);
-        const uint32_t mine = n_eval;
-#pragma unroll
-        for (int j = 0; j < K; ++j) if (op[j] != kNoIdx) push(od[j], 0u, op[j]);
-        rej_tie |= orej;
-        evict_last = fminf(evict_last, worst_seen);
-        n_eval = mine + oe; n_shell = max(n_shell, os);   // statistics: pushes of the merge are not candidates
-    }
 };
 
 // float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
@@ -157,7 +139,7 @@ template <class H>
 __device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
     for (uint32_t p = s; p < e; ++p) {
         const float4 c = g.pts[p];
-        hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p | kGlobalTag);
+        hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p);
     }
 }
 
@@ -178,19 +160,16 @@ struct RunList {
 
 template <class H>
 __device__ __forceinline__ void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p) {
-    hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p | kGlobalTag);
+    hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p);
 }
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
 // closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
 // the ball covers the search radius.
-// `lanes` lanes share one query: this lane (`sub`) tests every lanes-th group of 4 candidates of each run and stops
-// before the shells when `do_shells` is false (the group leader runs them after the heaps have been merged).
 template <class H>
 __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, H &hp, int lanes = 1, int sub = 0, bool do_shells = true,
-                                           unsigned long long *stamp = nullptr) {   // max_ring < 0: unbounded
+                                           int max_ring, H &hp, unsigned long long *stamp = nullptr) {   // max_ring < 0: unbounded
     hp.init(bound_f);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)max_ring + 1.0;
@@ -254,18 +233,17 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
             }
             return p < e;
         };
-        const uint32_t off = 4u * (uint32_t)sub, stride = 4u * (uint32_t)lanes;
         // software-pipelined: the loads of trip t+1 are issued before the insertions of trip t (measured:
         // 33.7 k vs 41.8 k cycles for this phase without the overlap)
         bool have = advance();
         float4 c0, c1, c2, c3;
-        if (have) { const uint32_t last = e - 1, q = p + off; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
+        if (have) { const uint32_t last = e - 1, q = p; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
         while (have) {
-            const uint32_t cp = p + off, ce = e;
+            const uint32_t cp = p, ce = e;
             const float4 d0 = c0, d1 = c1, d2_ = c2, d3 = c3;
-            p += stride;
+            p += 4;
             have = advance();
-            if (have) { const uint32_t last = e - 1, q = p + off; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
+            if (have) { const uint32_t last = e - 1, q = p; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
             if (cp < ce) push_point<H>(hp, qx, qy, qz, d0, cp);
             if (cp + 1 < ce) push_point<H>(hp, qx, qy, qz, d1, cp + 1);
             if (cp + 2 < ce) push_point<H>(hp, qx, qy, qz, d2_, cp + 2);
@@ -273,7 +251,6 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
         }
     }
     if (stamp) stamp[1] = clock64();
-    if (!do_shells) return;
     knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
@@ -337,37 +314,19 @@ struct KnnResult {
     uint32_t n_eval, n_shell;
 };
 
-// G lanes of a wave (G = 1, 2, 4, 8; consecutive lanes) cooperate on one query: each scans a 1/G share of the
-// candidates, the heaps are merged with a xor butterfly, and the group leader (sub == 0) finishes (shells, ties).
-// Non-leader lanes return with res.full == false.
-template <int K, int G>
+template <int K>
 __device__ __forceinline__ void knn_exact(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring,
-                                          int sub, KnnResult<K> &res, unsigned long long *stamp = nullptr) {
+                                          KnnResult<K> &res, unsigned long long *stamp = nullptr) {
     uint32_t pos[K];
-    res.full = false; res.n_eval = 0; res.n_shell = 1;
     {
         HeapFast<K> hf;
-        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, G, sub, G == 1, stamp);
+        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, stamp);
         if (stamp) stamp[2] = clock64();
-        if (G > 1) {
-#pragma unroll
-            for (int step = 1; step < G; step <<= 1) hf.merge_xor(step);
-            if (sub != 0) {
-#pragma unroll
-                for (int j = 0; j < K; ++j) { res.d2[j] = __builtin_inff(); res.idx[j] = kNoIdx; res.pt[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-                return;
-            }
-            // leader: shells around the query's cell with the merged heap
-            const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
-            int mr = max_ring;
-            const int cx = (int)floor(fx), cy = (int)floor(fy), cz = (int)floor(fz);
-            knn_shells<HeapFast<K>>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, mr, hf);
-        }
         res.full = hf.full();
         res.n_eval = hf.n_eval; res.n_shell = hf.n_shell;
 #pragma unroll
         for (int j = 0; j < K; ++j) { res.d2[j] = hf.d[j]; pos[j] = hf.pos[j]; }
-        if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo by this lane alone
+        if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo
             HeapExact<K> he;
             knn_search<HeapExact<K>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
             res.n_eval += he.n_eval;
@@ -378,7 +337,7 @@ __device__ __forceinline__ void knn_exact(const GridDev &g, RunList &rl, float q
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const bool ok = pos[j] != kNoIdx;
-        res.pt[j] = ok ? g.pts[pos[j] & ~kGlobalTag] : make_float4(0.f, 0.f, 0.f, 0.f);
+        res.pt[j] = ok ? g.pts[pos[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
         res.idx[j] = ok ? __float_as_uint(res.pt[j].w) : kNoIdx;
         if (!ok) res.d2[j] = __builtin_inff();
     }
@@ -598,16 +557,13 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 
 // ---------------------------------------------------------------- the fused linearisation kernel
 // MODE 0: reduction only.  MODE 1: also dump per-point results (parity tests).
-// G: lanes per query (1, 2, 4, 8).  G > 1 shortens one wave's serial search chain but multiplies the waves that run
-// the plane fit / reductions; measured slower at every size (profiles/r01_search_ablation.md), so G = 1 is the default
-// and the other instantiations are kept only behind the "lanes_per_query" option.
 struct DebugDev {
     int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
-    uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16 | tile used << 31
+    uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16
     unsigned long long *clocks;   // per wave: 8 shader-clock stamps (phase breakdown), may be null
 };
 
-template <int MODE, int G>
+template <int MODE>
 static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, DebugDev dbg) {
@@ -615,9 +571,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     __shared__ RunList runs;
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x);
-    const uint32_t gt = vb * kBlock + threadIdx.x;
-    const uint32_t i = gt / G;                                   // query of this lane
-    const int sub = (int)(gt % G);                               // position inside the query's lane group
+    const uint32_t i = vb * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
@@ -643,14 +597,13 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
 
     KnnResult<5> nn;
     nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
-    const bool tiled = G > 1;
     if (MODE == 1) clk[1] = clock64();
     unsigned long long sst[3] = {0, 0, 0};
-    if (reach) knn_exact<5, G>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, sub, nn, MODE == 1 ? sst : nullptr);
+    if (reach) knn_exact<5>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, nn, MODE == 1 ? sst : nullptr);
     if (MODE == 1) clk[2] = clock64();
 
     uint8_t flag = 0;
-    if (have_q && sub == 0) {
+    if (have_q) {
         const bool have5 = reach && nn.full;
         const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
         if (MODE == 1) {
@@ -725,7 +678,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
             }
         }
         if (MODE == 1 && dbg.flag) dbg.flag[__float_as_uint(s4.w)] = flag;
-        if (MODE == 1 && dbg.stats) dbg.stats[__float_as_uint(s4.w)] = (nn.n_eval & 0xFFFFu) | ((nn.n_shell & 0x7FFFu) << 16) | (tiled ? 0x80000000u : 0u);
+        if (MODE == 1 && dbg.stats) dbg.stats[__float_as_uint(s4.w)] = (nn.n_eval & 0xFFFFu) | ((nn.n_shell & 0x7FFFu) << 16);
     }
 
     if (MODE == 1) clk[3] = clock64();
@@ -749,7 +702,7 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
         }
         partials[((size_t)pose_id * n_blocks_x + vb) * kSlots + threadIdx.x] = t;
     }
-    if (MODE == 1 && G == 1 && dbg.clocks && lane == 0) {   // (the stamp buffer is sized for one lane per query)
+    if (MODE == 1 && dbg.clocks && lane == 0) {
         clk[5] = clock64();
         unsigned long long *o = dbg.clocks + ((size_t)vb * (kBlock / 64) + wave) * 8;
 #pragma unroll
@@ -804,7 +757,7 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
         body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
     KnnResult<K> nn;
-    knn_exact<K, 1>(g, runs, qx, qy, qz, bound_f, max_ring, 0, nn);
+    knn_exact<K>(g, runs, qx, qy, qz, bound_f, max_ring, nn);
     const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
     for (int j = 0; j < K; ++j) {

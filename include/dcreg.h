@@ -87,9 +87,9 @@ typedef struct dcreg_lin_debug {
     double *normal;  /* [3*n] */
     double *r;       /* [n] */
     double *s;       /* [n] */
-    uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 | LDS tile used << 31 */
+    uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 */
     uint64_t *clocks; /* [8 * ceil(n/64)] per-wave shader-clock stamps: start, tile built, search done, rows done,
-                         wave reduced, end, tile-used flag, hw block id */
+                         wave reduced, end, packed search sub-phases, hw block id */
 } dcreg_lin_debug;
 
 typedef struct dcreg_index_info {
@@ -109,8 +109,8 @@ const char *dcreg_last_error(const dcreg_ctx *);
 /* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream */
 int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
 /* options: "cell" (force grid cell edge, 0 = auto), "cell_factor" (auto = factor * est. 5th-NN distance),
- * "time_kernels" (1 = bracket every linearisation with HIP events), "lanes_per_query" (0 = auto, 1/2/4/8 lanes of a
- * wave cooperate on one source point), "spin" (1 = wait on the pinned result flag instead of hipStreamSynchronize) */
+ * "time_kernels" (1 = bracket every linearisation with HIP events), "spin" (1 = wait on the pinned result flag instead
+ * of hipStreamSynchronize, default), "lds_pad" (extra dynamic LDS bytes per block, occupancy experiments) */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
  * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */

@@ -20,8 +20,8 @@ for n in (7562, 100_000, 1_000_000):
     T0 = h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008 if n != 1_000_000 else 0.0004)
     R = np.ascontiguousarray(T0[:3, :3]).reshape(9); t = T0[:3, 3].copy()
     prm = api.default_lin_params(1.0, 1); out = api.LinOut()
-    for timed, tile in ((1, 1), (1, 2), (1, 4), (1, 8), (0, 0)):
-        ctx.set_option("time_kernels", timed); ctx.set_option("tile", tile); ctx.kernel_time(reset=True)
+    for timed, tile in ((1, 1), (0, 1)):
+        ctx.set_option("time_kernels", timed); ctx.kernel_time(reset=True)
         for _ in range(20): ctx.linearize_raw(R, t, prm, out)
         ctx.kernel_time(reset=True)
         K = 200 if n < 1_000_000 else 40

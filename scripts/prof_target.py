@@ -19,7 +19,6 @@ tgt = gen(args.n, seed=1)
 rng = np.random.default_rng(0)
 src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
 ctx = dcreg_amd.Context(0)
-ctx.set_option("tile", args.tile)
 if args.cell_factor > 0:
     ctx.set_option("cell_factor", args.cell_factor)
 ctx.set_target(tgt, 1.0)

@@ -15,7 +15,7 @@ for name, gen, n in (("cyl100k", lambda: h.scene_cylinder(100_000, seed=1, noise
         ctx.set_target(tgt, 1.0); ctx.set_source(src)
         T0 = h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008)
         out = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(1.0, 1), debug=True)
-        st = out["stats"]; ev = st & 0xFFFF; sh = (st >> 16) & 0x7FFF; tl = st >> 31
+        st = out["stats"]; ev = st & 0xFFFF; sh = (st >> 16) & 0x7FFF; tl = st >> 31  # (unused)
         print(name, "cf", cf, "cell %.3f" % ctx.index_info().cell, "n_eff", out["n_eff"], "tile frac %.3f" % tl.mean(), "eval mean %.1f p50 %d p99 %d max %d" % (ev.mean(), np.percentile(ev, 50), np.percentile(ev, 99), ev.max()),
               "shell>1 frac %.5f" % (sh > 1).mean(), "max shell", sh.max(), flush=True)
 
@@ -26,7 +26,6 @@ ctx.set_option("cell_factor", 2.0)
 ctx.set_target(tgt, 1.0); ctx.set_source(src)
 T0 = h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008)
 for tile in (1,):
-    ctx.set_option("tile", tile)
     for rep in range(2):
         out = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(1.0, 1), debug=True)
     ck = out["clocks"][: (len(src) + 63) // 64].astype(np.int64)

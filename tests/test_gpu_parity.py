@@ -71,23 +71,6 @@ def test_fixture_linearize_matches_oracle_and_golden(ctx, cyl, init, wd):
         assert gpu["n_eff"] == 197
 
 
-@pytest.mark.parametrize("lanes", [2, 4, 8])
-def test_lanes_per_query_variants_are_exact(ctx, cyl, lanes):
-    """Experimental sub-wave cooperative search: same neighbours, same sums as the default path."""
-    pts, tree = cyl
-    ctx.set_target(pts, 1.0)
-    ctx.set_source(pts)
-    T0 = h.pose6d_matrix(**h.PAPER_INIT)
-    ref = po.linearize(tree, pts, T0[:3, :3], T0[:3, 3], po.default_lin_params(1.0, 1), debug=True)
-    try:
-        ctx.set_option("lanes_per_query", lanes)
-        gpu = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(1.0, 1), debug=True)
-    finally:
-        ctx.set_option("lanes_per_query", 0)
-    assert_lin_equal(gpu, ref)
-    assert_debug_equal(gpu, ref)
-
-
 def test_deterministic_bitwise(ctx, cyl):
     pts, _ = cyl
     ctx.set_target(pts, 1.0)
