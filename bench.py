@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--method", default="Ours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="backend option (dcreg_backend_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
     args = ap.parse_args()
 
     import torch
@@ -81,6 +83,9 @@ def main():
     scene, n_pts, radius, run_len = WORKLOADS[args.workload]
     tgt, src = make_pair(scene, n_pts, seed=100 + rank)        # every rank: its own scan pair
     ctx = dcreg_amd.Context(local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        ctx.set_option(k, float(v))
     ctx.set_target(tgt, radius)
     ctx.set_source(src)
     info = ctx.index_info()

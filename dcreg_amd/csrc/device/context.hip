@@ -197,6 +197,7 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     c->radius_hint = radius_hint;
     rc = build_index(c, target_dst(c), radius_hint, &c->occupied_cells);
     if (rc) { c->n_tgt = 0; return rc; }
+    c->prev_valid = false;   // positions refer to the old sort order
     return DCREG_OK;
 }
 
@@ -224,6 +225,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
     c->aux_valid = false;
+    c->prev_valid = false;
     return DCREG_OK;
 }
 
@@ -260,10 +262,22 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
     const uint32_t nbx = blocks_for(c->n_src, kBlock);
     if (ensure(c, c->d_partials, c->partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
-    if ((size_t)n_poses > c->out_cap) {
+    // one pose: the kernel finishes the reduction itself (chunk rows -> pinned memory); many poses: k_finalize
+    const bool fused = (n_poses == 1);
+    const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
+    const size_t n_rows = fused ? (size_t)n_chunks : (size_t)n_poses;      // result rows the host waits for
+    if (fused) {   // tickets: zero when (re)allocated, afterwards every completed launch leaves them zero
+        const size_t had = c->tickets_cap;
+        if (ensure(c, c->d_tickets, c->tickets_cap, (size_t)n_chunks)) return DCREG_E_NOMEM;
+        if (c->tickets_cap != had || c->tickets_dirty) {
+            HIP_TRY(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * c->tickets_cap, c->stream));
+            c->tickets_dirty = false;
+        }
+    }
+    if (n_rows > c->out_cap) {
         if (c->h_out) (void)hipHostFree(c->h_out);
         c->h_out = nullptr; c->out_cap = 0;
-        const size_t cap = std::max<size_t>((size_t)n_poses, 64);
+        const size_t cap = std::max<size_t>(n_rows, 64);
         HIP_TRY(c, hipHostMalloc((void **)&c->h_out, cap * kSlots * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(c->h_out, 0, cap * kSlots * sizeof(double));
         HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_out, c->h_out, 0));
@@ -283,6 +297,16 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     DebugDev dd{};
     std::vector<void *> tmp_dev;
     const int64_t n = c->n_src;
+    a.prev = nullptr; a.prev_stride = 0;
+    if (c->opt_warm && n_poses == 1) {
+        if (!c->prev_valid) {
+            const size_t stride = ((size_t)n + 63) & ~(size_t)63;
+            if (ensure(c, c->d_prev, c->prev_cap, 5 * stride)) return DCREG_E_NOMEM;
+            HIP_TRY(c, hipMemsetAsync(c->d_prev, 0xFF, sizeof(uint32_t) * 5 * stride, c->stream));
+            c->prev_stride = stride; c->prev_valid = true;
+        }
+        a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
+    }
     if (dbg_host) {
         auto alloc = [&](size_t bytes, int fill) -> void * {
             void *p2 = nullptr;
@@ -300,15 +324,19 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
         if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 8 * ((n + 63) / 64 + 4), 0);
     }
+    const unsigned long long seq = ++c->seq;
+    FinArgs fin{c->d_tickets, c->d_out, seq};
+    if (fused) c->tickets_dirty = true;    // cleared again once this launch is known to have completed
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
     if (dbg_host)
-        hipLaunchKernelGGL((k_linearize<1>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+        hipLaunchKernelGGL((k_linearize<1, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
+    else if (fused)
+        hipLaunchKernelGGL((k_linearize<0, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
     else
-        hipLaunchKernelGGL((k_linearize<0>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, dd);
+        hipLaunchKernelGGL((k_linearize<0, false>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
     if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
-    const unsigned long long seq = ++c->seq;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(1024), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
+    if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
     if (dbg_host) {
         if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.nn_d2) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_d2, dd.nn_d2, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, c->stream));
@@ -322,8 +350,8 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     if (dbg_host || !c->opt_spin) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else {
-        // hot path: spin on the sequence numbers the finalize kernel publishes into pinned host memory
-        for (int i = 0; i < n_poses; ++i) {
+        // hot path: spin on the sequence numbers the kernels publish into pinned host memory
+        for (size_t i = 0; i < n_rows; ++i) {
             volatile unsigned long long *flag = (volatile unsigned long long *)(c->h_out + (size_t)i * kSlots + 31);
             uint64_t spins = 0;
             while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
@@ -336,6 +364,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
             }
         }
     }
+    c->tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
     for (void *p2 : tmp_dev) (void)hipFree(p2);
     if (dbg_host) HIP_TRY(c, hipGetLastError());
     if (c->opt_time_kernels) {
@@ -345,8 +374,16 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         HIP_TRY(c, te);
         c->kernel_ms_total += ms; c->kernel_launches += 1;
     }
+    double total[kSlots];
+    if (fused) {   // add the chunk rows in index order (fixed order: deterministic)
+        for (int k = 0; k < 31; ++k) total[k] = 0.0;
+        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+            const double *row = c->h_out + (size_t)ch * kSlots;
+            for (int k = 0; k < 31; ++k) total[k] += row[k];
+        }
+    }
     for (int i = 0; i < n_poses; ++i) {
-        const double *o = c->h_out + (size_t)i * kSlots;
+        const double *o = fused ? total : c->h_out + (size_t)i * kSlots;
         std::memcpy(outs[i].H_upper, o, 21 * sizeof(double));
         std::memcpy(outs[i].g, o + 21, 6 * sizeof(double));
         outs[i].sum_r2 = o[27]; outs[i].sum_b2 = o[28];
@@ -426,7 +463,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_partials, c->d_poses, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_tickets};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->h_out) (void)hipHostFree(c->h_out);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
@@ -450,6 +487,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
     else if (k == "time_kernels") c->opt_time_kernels = v != 0.0;
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;

@@ -40,7 +40,11 @@ struct dcreg_ctx {
     // source
     int64_t n_src = 0;
     float4 *d_src_raw = nullptr; size_t src_raw_cap = 0;
-    float4 *d_src = nullptr; size_t src_cap = 0;           // Morton-sorted
+    float4 *d_src = nullptr; size_t src_cap = 0;           // Hilbert-sorted
+    // warm start: sorted-target positions of every source point's last exact neighbour set, [5][prev_stride]
+    uint32_t *d_prev = nullptr; size_t prev_cap = 0;
+    size_t prev_stride = 0;
+    bool prev_valid = false;       // false -> cleared to "none" before the next single-pose linearisation
 
     // build scratch
     float *d_stage = nullptr; size_t stage_cap = 0;
@@ -52,6 +56,8 @@ struct dcreg_ctx {
 
     // linearisation
     double *d_partials = nullptr; size_t partials_cap = 0;
+    unsigned int *d_tickets = nullptr; size_t tickets_cap = 0;
+    bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
     dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
     std::vector<dcreg::PoseArg> h_poses;
     double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped
@@ -69,6 +75,7 @@ struct dcreg_ctx {
     bool need_set_device = true;
     unsigned long long seq = 0;
     int opt_lds_pad = 0;
+    bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
 

@@ -15,6 +15,9 @@
 
 namespace dcreg {
 
+#ifndef DCREG_TRIP_W
+#define DCREG_TRIP_W 4
+#endif
 constexpr int kBlock = 256;          // 4 waves
 constexpr int kSlots = 32;           // doubles per partial row
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
@@ -36,6 +39,8 @@ struct LinArgs {
     double max_thick_sq, min_norm, w_slope, w_min;
     int use_wd;
     int max_ring;                 // rings needed to cover the radius
+    uint32_t *prev;               // [5][prev_stride] sorted-target positions of each query's last neighbour set, or null
+    uint32_t prev_stride;
 };
 
 // ---------------------------------------------------------------- k-NN heaps (sorted, K entries)
@@ -191,28 +196,34 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
     const int tid = threadIdx.x;
     int nrun = 0;
     {
-        const int x0 = clampi(cx - 1, 0, nx), x1 = clampi(cx + 2, 0, nx);   // [x0, x1)
         const float hf = (float)g.h;
-        const float fry = (float)(fy - fly), frz = (float)(fz - flz);
+        const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
+        const float gxl = frx * hf, gxh = (1.f - frx) * hf;
         const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
         // visiting order (dy,dz): centre, 4 edge rows, 4 corner rows
         constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
         constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
         uint32_t rs[9], re[9];
+        float g2s[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
+            const float gy = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.f), gz = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.f);
+            const float g2 = (gy * gy + gz * gz) * 0.99999f;
+            g2s[r] = g2;
+            // x-cells of this row the ball of radius sqrt(bound) can reach (conservative): a tight bound (warm
+            // start) trims the three-cell run to one or two cells, or drops the row
+            const float xr = sqrtf(fmaxf(bound_f - g2, 0.f)) * 1.00001f + 1e-6f * hf;
+            const int x0 = clampi(cx - (gxl <= xr ? 1 : 0), 0, nx), x1 = clampi(cx + 1 + (gxh <= xr ? 1 : 0), 0, nx);   // [x0, x1)
             const int y = cy + DY[r], z = cz + DZ[r];
-            const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz;
+            const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz && !(g2 > bound_f);
             const int64_t row = ok ? ((int64_t)z * ny + y) * nx : 0;
             rs[r] = ok ? g.cell_start[row + x0] : 0u;
             re[r] = ok ? g.cell_start[row + x1] : 0u;
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            const float gy = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.f), gz = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.f);
-            const float g2 = (gy * gy + gz * gz) * 0.99999f;
-            if (re[r] > rs[r] && !(g2 > bound_f)) {
-                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2[nrun][tid] = g2;
+            if (re[r] > rs[r]) {
+                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2[nrun][tid] = g2s[r];
                 ++nrun;
             }
         }
@@ -236,18 +247,28 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
         // software-pipelined: the loads of trip t+1 are issued before the insertions of trip t (measured:
         // 33.7 k vs 41.8 k cycles for this phase without the overlap)
         bool have = advance();
-        float4 c0, c1, c2, c3;
-        if (have) { const uint32_t last = e - 1, q = p; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
+        constexpr int W = DCREG_TRIP_W;
+        float4 cn[W];
+        if (have) {
+            const uint32_t last = e - 1;
+#pragma unroll
+            for (int u = 0; u < W; ++u) cn[u] = g.pts[min(p + u, last)];
+        }
         while (have) {
             const uint32_t cp = p, ce = e;
-            const float4 d0 = c0, d1 = c1, d2_ = c2, d3 = c3;
-            p += 4;
+            float4 cc[W];
+#pragma unroll
+            for (int u = 0; u < W; ++u) cc[u] = cn[u];
+            p += W;
             have = advance();
-            if (have) { const uint32_t last = e - 1, q = p; c0 = g.pts[min(q, last)]; c1 = g.pts[min(q + 1, last)]; c2 = g.pts[min(q + 2, last)]; c3 = g.pts[min(q + 3, last)]; }
-            if (cp < ce) push_point<H>(hp, qx, qy, qz, d0, cp);
-            if (cp + 1 < ce) push_point<H>(hp, qx, qy, qz, d1, cp + 1);
-            if (cp + 2 < ce) push_point<H>(hp, qx, qy, qz, d2_, cp + 2);
-            if (cp + 3 < ce) push_point<H>(hp, qx, qy, qz, d3, cp + 3);
+            if (have) {
+                const uint32_t last = e - 1;
+#pragma unroll
+                for (int u = 0; u < W; ++u) cn[u] = g.pts[min(p + u, last)];
+            }
+#pragma unroll
+            for (int u = 0; u < W; ++u)
+                if (cp + u < ce) push_point<H>(hp, qx, qy, qz, cc[u], cp + u);
         }
     }
     if (stamp) stamp[1] = clock64();
@@ -310,6 +331,7 @@ struct KnnResult {
     float d2[K];
     uint32_t idx[K];     // original target index
     float4 pt[K];        // neighbour coordinates (w = idx bits)
+    uint32_t pos[K];     // position in the sorted target (kNoIdx = none)
     bool full;           // K neighbours found under the bound
     uint32_t n_eval, n_shell;
 };
@@ -337,6 +359,7 @@ __device__ __forceinline__ void knn_exact(const GridDev &g, RunList &rl, float q
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const bool ok = pos[j] != kNoIdx;
+        res.pos[j] = pos[j];
         res.pt[j] = ok ? g.pts[pos[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
         res.idx[j] = ok ? __float_as_uint(res.pt[j].w) : kNoIdx;
         if (!ok) res.d2[j] = __builtin_inff();
@@ -563,11 +586,63 @@ struct DebugDev {
     unsigned long long *clocks;   // per wave: 8 shader-clock stamps (phase breakdown), may be null
 };
 
-template <int MODE>
+// Single-pose launches finish inside the kernel (no second launch): blocks are grouped in chunks of kChunk consecutive
+// partial rows; the last block to finish in a chunk (ticket counter) sums that chunk's rows in a fixed order and writes
+// the chunk row, stamped with the launch's sequence number, straight into pinned host-coherent memory.  The host spins on
+// the stamps and adds the few chunk rows in index order.  WHO sums is timing dependent, WHAT is summed in which order is
+// not: the result is deterministic.  Batched launches (many poses, few blocks each) use k_finalize instead: a ticket
+// per block costs more there than the second launch (measured, profiles/r01_search_ablation.md addendum 5).
+constexpr int kChunk = 64;
+struct FinArgs {
+    unsigned int *tickets;         // [n_chunks], zero between launches (the last arrival resets its ticket)
+    double *out;                   // pinned, device-mapped: [n_chunks][kSlots]; slot 31 = sequence number
+    unsigned long long seq;
+};
+
+// Cross-block traffic of the tree uses agent-scope (sc1, write-through / L2-coherent) relaxed atomics plus an explicit
+// s_waitcnt instead of __threadfence(): a release fence on gfx950 is a full L2 write-back (buffer_wbl2), measured at
+// +10 us per launch when every block executes one.
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_system(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// sum of `count` (<= kChunk) rows of kSlots doubles, fixed order: lane group g adds rows g, g+8, ... then the 8 group
+// sums are added in order.  All 256 threads call; threads < 31 return the total of their slot.
+__device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t count, double (*sm)[kSlots]) {
+    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double v[kChunk / 8];
+#pragma unroll
+    for (int u = 0; u < kChunk / 8; ++u) {
+        const uint32_t r = (uint32_t)grp + 8u * u;
+        v[u] = r < count ? ld_agent(rows + (size_t)r * kSlots + j) : 0.0;
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < kChunk / 8; ++u) t += v[u];
+    __syncthreads();
+    sm[grp][j] = t;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < 31) {
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
+    }
+    return tot;
+}
+
+template <int MODE, bool FUSED>
 static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
-                                                       double *__restrict__ partials, uint32_t n_blocks_x, DebugDev dbg) {
-    __shared__ double red[kBlock / 64][kSlots];
+                                                       double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg) {
+    __shared__ double red[8][kSlots];
+    __shared__ int s_role;
     __shared__ RunList runs;
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x);
@@ -585,6 +660,17 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     // ---- query, cell, reach test
     const bool have_q = i < n_src;
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // warm start: the K-th neighbour distance is at most the largest distance to ANY K distinct target points, so
+    // the neighbour set of the previous linearisation (any pose) bounds this search; the result is the same exact
+    // set, found after visiting only the cells that ball touches.  The position loads and the point gathers are
+    // issued here, ahead of the pose transform and the cell-table loads, so their latency overlaps with those.
+    uint32_t pp[5];
+    float4 pv[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) pp[j] = (a.prev && have_q) ? a.prev[(size_t)j * a.prev_stride + i] : kNoIdx;
+    const bool warm = pp[4] != kNoIdx;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) pv[j] = warm ? g.pts[pp[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
     const double px = s4.x, py = s4.y, pz = s4.z;
     float qx, qy, qz;
     body_to_global(P, px, py, pz, qx, qy, qz);
@@ -592,14 +678,26 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     const double lim = (double)a.max_ring + 1.0;
     // a query farther than max_ring cells from the grid has no neighbour inside the radius
     const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
-    const double flx = floor(fx), fly = floor(fy), flz = floor(fz);
-    const int cx = reach ? (int)flx : 0, cy = reach ? (int)fly : 0, cz = reach ? (int)flz : 0;
 
     KnnResult<5> nn;
     nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
     if (MODE == 1) clk[1] = clock64();
     unsigned long long sst[3] = {0, 0, 0};
-    if (reach) knn_exact<5>(g, runs, qx, qy, qz, a.radius_sq_f, a.max_ring, nn, MODE == 1 ? sst : nullptr);
+    float bound = a.radius_sq_f;
+    if (warm) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) m = fmaxf(m, dist2_nofma(qx, qy, qz, pv[j]));
+        // inclusive bound for a strict '<' heap: next float above m (m >= 0, finite)
+        const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
+        bound = fminf(bound, incl);
+    }
+    if (reach) knn_exact<5>(g, runs, qx, qy, qz, bound, a.max_ring, nn, MODE == 1 ? sst : nullptr);
+    if (a.prev && have_q) {
+        const bool keep = reach && nn.full;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a.prev[(size_t)j * a.prev_stride + i] = keep ? nn.pos[j] : kNoIdx;
+    }
     if (MODE == 1) clk[2] = clock64();
 
     uint8_t flag = 0;
@@ -694,13 +792,38 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     }
     if (MODE == 1) clk[4] = clock64();
     __syncthreads();
+    double *my_rows = partials + (size_t)pose_id * n_blocks_x * kSlots;
     if (threadIdx.x < kSlots) {
         double t = 0.0;
         if (threadIdx.x < 31) {
 #pragma unroll
             for (int w = 0; w < kBlock / 64; ++w) t += red[w][threadIdx.x];
         }
-        partials[((size_t)pose_id * n_blocks_x + vb) * kSlots + threadIdx.x] = t;
+        if (FUSED) {
+            st_agent(my_rows + (size_t)vb * kSlots + threadIdx.x, t);
+            wait_stores();                                 // the row is at the coherence point before the ticket is taken
+        } else {
+            my_rows[(size_t)vb * kSlots + threadIdx.x] = t;
+        }
+    }
+    if (FUSED) {
+        const uint32_t chunk = vb / kChunk;
+        const uint32_t csize = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_role = (prev == csize - 1) ? 1 : 0;
+            if (prev == csize - 1) __hip_atomic_store(&fin.tickets[chunk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
+            const double t = block_sum_rows(my_rows + (size_t)chunk * kChunk * kSlots, csize, red);
+            double *orow = fin.out + (size_t)chunk * kSlots;
+            if (threadIdx.x < 31) { st_system(orow + threadIdx.x, t); wait_stores(); }
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store((unsigned long long *)(orow + 31), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (MODE == 1 && dbg.clocks && lane == 0) {
         clk[5] = clock64();
@@ -712,36 +835,23 @@ static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__res
     }
 }
 
-// one block per pose: sums the block partials in index order, writes 32 doubles to the pinned, host-
-// coherent result row, then publishes a sequence number the host spins on (no stream synchronise on
-// the hot path).  out row layout: [0..30] sums, [31] = sequence number as double bits.
-static __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out,
-                                                           unsigned long long seq) {
-    __shared__ double sm[32][kSlots + 1];
+// Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused
+// single-pose path (chunk sums, then chunks in index order), so a batched pose is bitwise equal to the same pose
+// linearised alone.  Writes 31 sums to the pinned, host-coherent result row, then publishes the sequence number the
+// host spins on (no stream synchronise on the hot path).  out row layout: [0..30] sums, [31] = sequence number.
+static __global__ __launch_bounds__(kBlock) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out,
+                                                            unsigned long long seq) {
+    __shared__ double sm[8][kSlots];
     const uint32_t pose_id = blockIdx.x;
-    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 32 groups of 32 lanes
     const double *base = partials + (size_t)pose_id * n_blocks * kSlots;
-    // 8 independent accumulators -> 8 loads in flight per lane (fixed association order, deterministic)
-    double t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t b = grp;
-    for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t8[u] += base[(size_t)(b + u * 32) * kSlots + j];
-    }
-    for (int u = 0; b < n_blocks; b += 32, ++u) t8[u] += base[(size_t)b * kSlots + j];
-    const double t = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
-    sm[grp][j] = t;
-    __syncthreads();
-    if (threadIdx.x < 31) {
-        double s = 0.0;
-#pragma unroll
-        for (int gidx = 0; gidx < 32; ++gidx) s += sm[gidx][threadIdx.x];
-        out[(size_t)pose_id * kSlots + threadIdx.x] = s;
-        __threadfence_system();
-    }
+    double tot = 0.0;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += kChunk)
+        tot += block_sum_rows(base + (size_t)c0 * kSlots, min((uint32_t)kChunk, n_blocks - c0), sm);
+    double *orow = out + (size_t)pose_id * kSlots;
+    if (threadIdx.x < 31) { st_system(orow + threadIdx.x, tot); wait_stores(); }
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_store((unsigned long long *)(out + (size_t)pose_id * kSlots + 31), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long *)(orow + 31), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------- plain k-NN kernel (p2p metrics, tests)
