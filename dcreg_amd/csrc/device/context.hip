@@ -327,7 +327,9 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     const unsigned long long seq = ++c->seq;
     FinArgs fin{c->d_tickets, c->d_out, seq};
     if (fused) c->tickets_dirty = true;    // cleared again once this launch is known to have completed
-    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    // kernel timing: HIP events around every opt_time_kernels-th launch (each timed launch costs ~10 us of host time)
+    const bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
     if (dbg_host)
         hipLaunchKernelGGL((k_linearize<1, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
@@ -335,7 +337,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         hipLaunchKernelGGL((k_linearize<0, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
     else
         hipLaunchKernelGGL((k_linearize<0, false>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
-    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
     if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
     if (dbg_host) {
         if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
@@ -367,7 +369,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     c->tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
     for (void *p2 : tmp_dev) (void)hipFree(p2);
     if (dbg_host) HIP_TRY(c, hipGetLastError());
-    if (c->opt_time_kernels) {
+    if (timed) {
         float ms = 0.f;
         hipError_t te = hipEventElapsedTime(&ms, c->ev0, c->ev1);
         if (te == hipErrorNotReady) { HIP_TRY(c, hipEventSynchronize(c->ev1)); te = hipEventElapsedTime(&ms, c->ev0, c->ev1); }
@@ -485,7 +487,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     const std::string k(key);
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
-    else if (k == "time_kernels") c->opt_time_kernels = v != 0.0;
+    else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)

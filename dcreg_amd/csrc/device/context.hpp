@@ -70,7 +70,8 @@ struct dcreg_ctx {
 
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
-    bool opt_time_kernels = false;
+    int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
+    uint64_t launch_counter = 0;
     bool opt_spin = true;          // wait for results by spinning on pinned memory instead of hipStreamSynchronize
     bool need_set_device = true;
     unsigned long long seq = 0;
