@@ -15,9 +15,6 @@
 
 namespace dcreg {
 
-#ifndef DCREG_TRIP_W
-#define DCREG_TRIP_W 4
-#endif
 constexpr int kBlock = 256;          // 4 waves
 constexpr int kSlots = 32;           // doubles per partial row
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
@@ -59,10 +56,10 @@ struct HeapExact {
         for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
         n_eval = 0; n_shell = 1;
     }
-    __device__ __forceinline__ void push(float d2, uint32_t idx, uint32_t p) {
-        ++n_eval;
+    __device__ __forceinline__ void push(float d2, uint32_t idx, uint32_t p, bool valid = true) {
+        n_eval += valid ? 1u : 0u;
         const uint64_t k = ((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)idx;
-        if (k < key[K - 1]) {
+        if (valid && k < key[K - 1]) {
             key[K - 1] = k; pos[K - 1] = p;
 #pragma unroll
             for (int j = K - 1; j > 0; --j) {
@@ -79,55 +76,91 @@ struct HeapExact {
     __device__ __forceinline__ bool full() const { return pos[K - 1] != kNoIdx; }
 };
 
-// Fast heap: 32-bit keys (d2 only, strict <), half the insertion cost of the exact heap.  It yields the
-// exact neighbour SET unless some candidate outside the final heap has d2 == the K-th best d2; that case
-// is detected exactly (equality at rejection time / last evicted d2) and the caller re-runs the exact heap.
-// Order among equal d2 inside the heap is fixed afterwards (canonical (d2, idx) order).
+// Fast heap: 32-bit keys (d2 only, strict <), branch-light insertion.  It yields the exact neighbour SET unless some
+// point outside the final heap has d2 == the K-th best d2; `outside_min` tracks the smallest d2 that was ever kept out
+// (rejected candidates and evicted entries alike: max(d2, K-th best before the push) is exactly that value), so the
+// tie is detected exactly and the caller re-runs the exact heap.  Order among equal d2 inside the heap is fixed
+// afterwards (canonical (d2, idx) order).
 template <int K_>
 struct HeapFast {
     static constexpr int K = K_;
     float d[K];
     uint32_t pos[K];
-    bool rej_tie;        // some candidate was rejected with d2 == the K-th best of that moment
-    float evict_last;    // d2 of the most recently evicted entry (evictions are non-increasing)
+    float outside_min;   // smallest d2 among all points seen that are not in the heap
     uint32_t n_eval, n_shell;
     __device__ __forceinline__ void init(float bound_f) {
 #pragma unroll
         for (int i = 0; i < K; ++i) { d[i] = bound_f; pos[i] = kNoIdx; }
-        rej_tie = false; evict_last = __builtin_inff();
+        outside_min = __builtin_inff();
         n_eval = 0; n_shell = 1;
     }
-    __device__ __forceinline__ void push(float d2, uint32_t /*idx*/, uint32_t p) {
-        ++n_eval;
-        // a rejected candidate can only tie with the FINAL K-th best if it ties with the current one
-        // (the K-th best never grows), so equality at rejection time is all that must be remembered
-        rej_tie |= (d2 == d[K - 1]);
-        if (d2 < d[K - 1]) {
-            evict_last = d[K - 1];
-            d[K - 1] = d2; pos[K - 1] = p;
+    // valid == false: the slot is padding (d2 must then be +inf).  Branch-free: with 64 queries per wave some lane
+    // accepts almost every candidate, so a divergent "if (d2 < worst)" is taken anyway and only adds exec-mask
+    // juggling and merge copies.  Sorted insertion without a dependency chain: entry i becomes the median of
+    // (d[i-1], d[i], d2); positions follow the same selection through the masks c[i] = d2 < d[i] (ties stay behind).
+    __device__ __forceinline__ void push(float d2, uint32_t /*idx*/, uint32_t p, bool valid = true) {
+        n_eval += valid ? 1u : 0u;
+        if constexpr (K == 5) {
+            // 21 VALU instructions, written out: the compiler's select canonicalisation turns the nine position
+            // selects into 13-20 when it sees several pushes at once.  All compares read the OLD distances and sit
+            // at least five instructions ahead of the v_cndmask that consumes their SGPR mask.
+            unsigned long long m0, m1, m2, m3, m4;
+            float t;
+            asm("v_cmp_lt_f32_e64 %[m0], %[x], %[d0]\n\t"
+                "v_cmp_lt_f32_e64 %[m1], %[x], %[d1]\n\t"
+                "v_cmp_lt_f32_e64 %[m2], %[x], %[d2]\n\t"
+                "v_cmp_lt_f32_e64 %[m3], %[x], %[d3]\n\t"
+                "v_cmp_lt_f32_e64 %[m4], %[x], %[d4]\n\t"
+                "v_max_f32_e32 %[t], %[x], %[d4]\n\t"
+                "v_min_f32_e32 %[om], %[om], %[t]\n\t"
+                "v_med3_f32 %[d4], %[d3], %[d4], %[x]\n\t"
+                "v_med3_f32 %[d3], %[d2], %[d3], %[x]\n\t"
+                "v_med3_f32 %[d2], %[d1], %[d2], %[x]\n\t"
+                "v_med3_f32 %[d1], %[d0], %[d1], %[x]\n\t"
+                "v_min_f32_e32 %[d0], %[d0], %[x]\n\t"
+                "v_cndmask_b32_e64 %[p4], %[p4], %[p], %[m4]\n\t"
+                "v_cndmask_b32_e64 %[p4], %[p4], %[p3], %[m3]\n\t"
+                "v_cndmask_b32_e64 %[p3], %[p3], %[p], %[m3]\n\t"
+                "v_cndmask_b32_e64 %[p3], %[p3], %[p2], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p1], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p0], %[m0]\n\t"
+                "v_cndmask_b32_e64 %[p0], %[p0], %[p], %[m0]"
+                : [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [d4] "+v"(d[4]),
+                  [p0] "+v"(pos[0]), [p1] "+v"(pos[1]), [p2] "+v"(pos[2]), [p3] "+v"(pos[3]), [p4] "+v"(pos[4]),
+                  [om] "+v"(outside_min), [t] "=&v"(t),
+                  [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4)
+                : [x] "v"(d2), [p] "v"(p));
+        } else {
+            outside_min = fminf(outside_min, fmaxf(d2, d[K - 1]));
+            bool c[K];
 #pragma unroll
-            for (int j = K - 1; j > 0; --j) {
-                const bool sw = d[j] < d[j - 1];
-                const float da = d[j - 1], db = d[j];
-                const uint32_t pa = pos[j - 1], pb = pos[j];
-                d[j - 1] = sw ? db : da; d[j] = sw ? da : db;
-                pos[j - 1] = sw ? pb : pa; pos[j] = sw ? pa : pb;
+            for (int i = 0; i < K; ++i) c[i] = d2 < d[i];
+#pragma unroll
+            for (int i = K - 1; i >= 1; --i) {
+                pos[i] = c[i - 1] ? pos[i - 1] : (c[i] ? p : pos[i]);
+                d[i] = __builtin_amdgcn_fmed3f(d[i - 1], d[i], d2);
             }
+            pos[0] = c[0] ? p : pos[0];
+            d[0] = fminf(d[0], d2);
         }
     }
     __device__ __forceinline__ float worst_d2() const { return d[K - 1]; }
     __device__ __forceinline__ float dist(int j) const { return d[j]; }
     __device__ __forceinline__ bool full() const { return pos[K - 1] != kNoIdx; }
     // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
-    __device__ __forceinline__ bool boundary_tie() const { return full() && (rej_tie || evict_last == d[K - 1]); }
+    __device__ __forceinline__ bool boundary_tie() const { return full() && outside_min == d[K - 1]; }
 };
 
 // float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
 __device__ __forceinline__ float dist2_nofma(float qx, float qy, float qz, const float4 &c) {
 #pragma clang fp contract(off)
-    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-    float d2 = dx * dx;
-    d2 = d2 + dy * dy;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 dxy = f2{qx, qy} - f2{c.x, c.y};       // (x,y) is the register pair a dwordx4 load leaves aligned for v_pk_*
+    dxy = dxy * dxy;
+    const float dz = qz - c.z;
+    float d2 = dxy.x + dxy.y;
     d2 = d2 + dz * dz;
     return d2;
 }
@@ -164,8 +197,9 @@ struct RunList {
 };
 
 template <class H>
-__device__ __forceinline__ void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p) {
-    hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p);
+__device__ __forceinline__ void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p, bool valid) {
+    const float d2 = dist2_nofma(qx, qy, qz, c);
+    hp.push(valid ? d2 : __builtin_inff(), __float_as_uint(c.w), p, valid);     // padding slots can never enter
 }
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
@@ -246,29 +280,29 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
         };
         // software-pipelined: the loads of trip t+1 are issued before the insertions of trip t (measured:
         // 33.7 k vs 41.8 k cycles for this phase without the overlap)
+        // software-pipelined, unrolled twice over two register sets (no copies): the loads of trip t+1 are issued
+        // before the insertions of trip t.  Slots past the end of a run are clamped loads that push +inf.
+        constexpr int W = 4;
+        float4 ca[W], cb[W];
         bool have = advance();
-        constexpr int W = DCREG_TRIP_W;
-        float4 cn[W];
-        if (have) {
+        auto load = [&](float4 (&c)[W]) {
             const uint32_t last = e - 1;
 #pragma unroll
-            for (int u = 0; u < W; ++u) cn[u] = g.pts[min(p + u, last)];
-        }
-        while (have) {
+            for (int u = 0; u < W; ++u) c[u] = g.pts[min(p + u, last)];
+        };
+        auto trip = [&](float4 (&cur)[W], float4 (&nxt)[W]) {   // insert `cur` (positions p..), prefetch `nxt`
             const uint32_t cp = p, ce = e;
-            float4 cc[W];
-#pragma unroll
-            for (int u = 0; u < W; ++u) cc[u] = cn[u];
             p += W;
             have = advance();
-            if (have) {
-                const uint32_t last = e - 1;
+            if (have) load(nxt);
 #pragma unroll
-                for (int u = 0; u < W; ++u) cn[u] = g.pts[min(p + u, last)];
-            }
-#pragma unroll
-            for (int u = 0; u < W; ++u)
-                if (cp + u < ce) push_point<H>(hp, qx, qy, qz, cc[u], cp + u);
+            for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, cur[u], cp + u, cp + u < ce);
+        };
+        if (have) load(ca);
+        while (have) {
+            trip(ca, cb);
+            if (!have) break;
+            trip(cb, ca);
         }
     }
     if (stamp) stamp[1] = clock64();

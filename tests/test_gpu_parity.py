@@ -129,6 +129,48 @@ def test_knn_exact_with_ties_and_outside_queries(ctx):
     assert np.all(gi[~inside] == -1)
 
 
+@pytest.mark.parametrize("scene", ["lattice_ties", "cylinder_20k"])
+def test_warm_start_bound_keeps_the_search_exact(ctx, scene):
+    """The search of a linearisation is bounded by the previous call's neighbour sets (any pose).  Whatever the
+    history - small steps, a jump far outside the cloud and back, a new target - every result must be bitwise the
+    result of the unbounded (cold) search, including the (d2, idx) order among exact distance ties."""
+    if scene == "lattice_ties":
+        g = np.arange(0, 14, dtype=np.float32) * 0.25
+        tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        src = (tgt[::3] + np.float32(0.125)).astype(np.float32)
+    else:
+        tgt = h.scene_cylinder(20_000, seed=7, noise=0.01)
+        src = tgt[::2].copy()
+    poses = [h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008), h.pose6d_matrix(0.03, -0.05, 0.02, 0.002, -0.001, 0.005),
+             h.pose6d_matrix(0.0, 0.0, 0.0, 0.0, 0.0, 0.0), h.pose6d_matrix(500.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+             h.pose6d_matrix(0.3, 0.2, -0.1, 0.01, 0.02, -0.03), h.pose6d_matrix(0.0, 0.0, 0.0, 0.0, 0.0, 0.0)]
+    prm = api.default_lin_params(1.0, 1)
+    keys = ("H_upper", "g", "nn_idx", "flag", "r", "s", "normal")
+    try:
+        ctx.set_option("warm_start", 0)
+        ctx.set_target(tgt, 1.0); ctx.set_source(src)
+        cold = [ctx.linearize(T[:3, :3], T[:3, 3], prm, debug=True) for T in poses]
+        ctx.set_option("warm_start", 1)
+        ctx.set_target(tgt, 1.0); ctx.set_source(src)
+        for k, T in enumerate(poses):
+            w = ctx.linearize(T[:3, :3], T[:3, 3], prm, debug=(k % 2 == 0))    # debug and plain launches share the state
+            assert w["n_eff"] == cold[k]["n_eff"] and w["n_pt"] == cold[k]["n_pt"]
+            for key in keys:
+                if key in w:
+                    assert np.array_equal(w[key], cold[k][key]), (k, key)
+            if "nn_d2" in w:
+                assert np.array_equal(w["nn_d2"].view(np.uint32), cold[k]["nn_d2"].view(np.uint32))
+        # a new target invalidates the stored positions (different sort order): results must follow the new cloud
+        tgt2 = np.ascontiguousarray(tgt[::-1][: len(tgt) - 17])
+        ctx.set_target(tgt2, 1.0)
+        w = ctx.linearize(poses[0][:3, :3], poses[0][:3, 3], prm, debug=True)
+        ref = po.linearize(po.KdTree(tgt2), src, poses[0][:3, :3], poses[0][:3, 3], po.default_lin_params(1.0, 1), debug=True)
+        assert_lin_equal(w, ref)
+        assert_debug_equal(w, ref)
+    finally:
+        ctx.set_option("warm_start", 1)
+
+
 def test_empty_and_tiny_inputs(ctx):
     with pytest.raises(api.DcregError):
         ctx.set_target(np.zeros((0, 3), np.float32), 1.0)
