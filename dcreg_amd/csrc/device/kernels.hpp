@@ -268,41 +268,45 @@ __device__ __forceinline__ void knn_search(const GridDev &g, RunList &rl, float 
     {
         int ri = 0;
         uint32_t p = 0, e = 0;
-        auto advance = [&]() {      // position (p,e) on the next candidate; false when the list is exhausted
-            while (p >= e && ri < nrun) {
-                const float g2 = rl.gap2[ri][tid];
-                const uint32_t s_ = rl.s[ri][tid], e_ = rl.e[ri][tid];
-                ++ri;
-                if (g2 > hp.worst_d2()) continue;     // every point of this row is farther than the K-th best
-                p = s_; e = e_;
-            }
-            return p < e;
+        // switch to the next listed row (one per call, no inner loop: a row that the K-th best has meanwhile put out
+        // of reach becomes an empty run and costs one idle trip, which is rare once the search is bounded)
+        auto next_run = [&]() {
+            const float g2 = rl.gap2[ri][tid];
+            const uint32_t s_ = rl.s[ri][tid], e_ = rl.e[ri][tid];
+            ++ri;
+            const bool keep = !(g2 > hp.worst_d2());
+            p = keep ? s_ : 0u; e = keep ? e_ : 0u;
         };
-        // software-pipelined: the loads of trip t+1 are issued before the insertions of trip t (measured:
-        // 33.7 k vs 41.8 k cycles for this phase without the overlap)
-        // software-pipelined, unrolled twice over two register sets (no copies): the loads of trip t+1 are issued
-        // before the insertions of trip t.  Slots past the end of a run are clamped loads that push +inf.
+        // software-pipelined over two register sets, unrolled twice (no copies): the loads of trip t+1 are in flight
+        // while trip t is inserted (a third set, two trips ahead: +2.5 % at 100 k points, -8 % at 1 M where the extra
+        // registers cost a wave of occupancy).  Slots past the end of a run are clamped loads that push +inf.
         constexpr int W = 4;
-        float4 ca[W], cb[W];
-        bool have = advance();
-        auto load = [&](float4 (&c)[W]) {
-            const uint32_t last = e - 1;
+        struct Slot { float4 c[W]; uint32_t cp, ce; bool live; };
+        bool have = nrun > 0;
+        if (have) next_run();
+        auto fetch = [&](Slot &sl) {
+            sl.live = have; sl.cp = p; sl.ce = e;
+            if (have) {
+                const uint32_t last = max(e, 1u) - 1u;
 #pragma unroll
-            for (int u = 0; u < W; ++u) c[u] = g.pts[min(p + u, last)];
+                for (int u = 0; u < W; ++u) sl.c[u] = g.pts[min(p + u, last)];
+                p += W;
+                if (p >= e) {
+                    have = ri < nrun;
+                    if (have) next_run();
+                }
+            }
         };
-        auto trip = [&](float4 (&cur)[W], float4 (&nxt)[W]) {   // insert `cur` (positions p..), prefetch `nxt`
-            const uint32_t cp = p, ce = e;
-            p += W;
-            have = advance();
-            if (have) load(nxt);
+        auto consume = [&](const Slot &sl) {
 #pragma unroll
-            for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, cur[u], cp + u, cp + u < ce);
+            for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, sl.c[u], sl.cp + u, sl.cp + u < sl.ce);
         };
-        if (have) load(ca);
-        while (have) {
-            trip(ca, cb);
-            if (!have) break;
-            trip(cb, ca);
+        Slot A, B;
+        fetch(A);
+        while (A.live) {
+            fetch(B); consume(A);
+            if (!B.live) break;
+            fetch(A); consume(B);
         }
     }
     if (stamp) stamp[1] = clock64();
@@ -672,7 +676,7 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 }
 
 template <int MODE, bool FUSED>
-static __global__ __launch_bounds__(kBlock) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg) {
     __shared__ double red[8][kSlots];
