@@ -37,6 +37,14 @@ if kt:
         ks[k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)}
     out["kernel_trace"] = ks
     md.append("")
+# rocprofv3's own --stats table of the same process
+st = kt.replace("kernel_trace.csv", "kernel_stats.csv") if kt else None
+if st and os.path.exists(st):
+    rows = list(csv.reader(open(st)))
+    with open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, wl)), "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        for r in rows:
+            w.writerow([r[0][:160]] + r[1:])      # rocprim template names run to kilobytes
 def counters(sub):
     f = one(sub + "/**/*counter_collection.csv")
     res = collections.defaultdict(lambda: collections.defaultdict(list))
