@@ -15,6 +15,7 @@
 #include <limits>
 #include <map>
 #include <random>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -404,9 +405,11 @@ private:
                 for (int m : a.degenerate_mask) f << (m ? "1" : "0") << " ";
                 f << "\n  Is Degenerate: " << (a.isDegenerate ? "Yes" : "No") << "\n\n" << std::setprecision(6);
                 if (kv.first.find("PCG") != std::string::npos || kv.first == "Ours") {
-                    // the reference logs P with rows/columns permuted by the alignment indices
+                    // the reference logs P with rows/columns permuted by the alignment indices:
+                    // logged(idx[i], idx[j]) = P(i, j) per block; the 3-cycle of the paper run's last iteration
+                    // (trans_indices = 1 2 0) fixes the direction, the first iteration's swaps cannot
                     int perm[6];
-                    for (int i = 0; i < 3; ++i) { perm[i] = a.rot_indices[i]; perm[3 + i] = 3 + a.trans_indices[i]; }
+                    for (int i = 0; i < 3; ++i) { perm[a.rot_indices[i]] = i; perm[3 + a.trans_indices[i]] = 3 + i; }
                     f << "  Preconditioner Matrix P:\n";
                     for (int i = 0; i < 6; ++i) {
                         f << "    ";
@@ -436,6 +439,105 @@ private:
                 }
             }
             f << "\n\n";
+        }
+        // ---- transform_details.csv, :801-890.  Default ostream formatting.  Bug-compatible: no separator after
+        // Transform_33 nor after Degenerate_Mask_5 (header and rows), the "SVD_Sigma" columns carry the eigenvalues, the
+        // Schur lambda columns are constant 0.0 and the condition columns hold {Schur rot, Schur trans, full SVD, 0.0, 0.0}.
+        {
+            std::ofstream f(config_.output_folder + "transform_details.csv");
+            f << "Method,Run,Converged,Iterations,Time_ms,Trans_Error_m,Rot_Error_deg,Final_RMSE,Final_Fitness,Corr_Number,";
+            for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) f << "Transform_" << i << j << ",";
+            f << "SVD_Sigma_0,SVD_Sigma_1,SVD_Sigma_2,SVD_Sigma_3,SVD_Sigma_4,SVD_Sigma_5,"
+                 "EVD_Lambda_0,EVD_Lambda_1,EVD_Lambda_2,EVD_Lambda_3,EVD_Lambda_4,EVD_Lambda_5,"
+                 "Schur_Rot_Lambda_0,Schur_Rot_Lambda_1,Schur_Rot_Lambda_2,Schur_Trans_Lambda_0,Schur_Trans_Lambda_1,Schur_Trans_Lambda_2,"
+                 "Cond_Full_SVD,Cond_Sub_Rot,Cond_Sub_Trans,Cond_Schur_Rot,Cond_Schur_Trans,"
+                 "Degenerate_Mask_0,Degenerate_Mask_1,Degenerate_Mask_2,Degenerate_Mask_3,Degenerate_Mask_4,Degenerate_Mask_5";
+            f << "SuperLoc_Has_Data,SuperLoc_Uncertainty_X,SuperLoc_Uncertainty_Y,SuperLoc_Uncertainty_Z,"
+                 "SuperLoc_Uncertainty_Roll,SuperLoc_Uncertainty_Pitch,SuperLoc_Uncertainty_Yaw,"
+                 "SuperLoc_Cond_Full,SuperLoc_Cond_Rot,SuperLoc_Cond_Trans,SuperLoc_Is_Degenerate\n";
+            for (const auto &kv : detailed_results_) {
+                int run = 0;
+                for (const auto &r : kv.second) {
+                    f << kv.first << "," << run++ << "," << (r.converged ? 1 : 0) << "," << r.iterations << "," << r.time_ms << "," << r.trans_error_m << ","
+                      << r.rot_error_deg << "," << r.final_rmse << "," << r.final_fitness << "," << r.corr_num << ",";
+                    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { f << r.final_transform[i * 4 + j]; if (i < 3 || j < 3) f << ","; }
+                    const bool have = !r.iteration_data.empty();                         // result.eigenvalues etc. come from the last iteration, :484-497
+                    const dcreg_analysis *a = have ? &r.iteration_data.back().analysis : nullptr;
+                    if (have) { for (int rep = 0; rep < 2; ++rep) for (double v : a->eigenvalues_full) f << v << ","; }
+                    else for (int i = 0; i < 12; ++i) f << "0.0,";
+                    for (int i = 0; i < 6; ++i) f << "0.0,";
+                    if (have) f << a->cond_schur_rot << "," << a->cond_schur_trans << "," << a->cond_full << ",0.0,0.0,";
+                    else for (int i = 0; i < 5; ++i) f << "0.0,";
+                    for (int i = 0; i < 6; ++i) { f << ((have && a->degenerate_mask[i]) ? 1 : 0); if (i < 5) f << ","; }
+                    f << "0,NaN,NaN,NaN,NaN,NaN,NaN,NaN,NaN,NaN,0\n";                    // no SuperLoc data in this build
+                }
+            }
+        }
+        // ---- degeneracy_analysis_last_iter.txt, :1199-1385 (every num_runs; first run of each method)
+        {
+            std::ofstream f(config_.output_folder + "degeneracy_analysis_last_iter.txt");
+            f << std::fixed << std::setprecision(6);
+            f << "Degeneracy Analysis Results\n==========================\n\n";
+            auto eigen_row = [](const double *v, int n) {       // Eigen's default IOFormat of a row vector: common width
+                std::vector<std::string> t;
+                size_t w = 0;
+                for (int i = 0; i < n; ++i) { std::ostringstream o; o << std::fixed << std::setprecision(6) << v[i]; t.push_back(o.str()); w = std::max(w, t.back().size()); }
+                std::string out;
+                for (int i = 0; i < n; ++i) { out += std::string(w - t[i].size(), ' ') + t[i]; if (i + 1 < n) out += " "; }
+                return out;
+            };
+            for (const auto &kv : detailed_results_) {
+                if (kv.second.empty()) continue;
+                const auto &r = kv.second[0];
+                f << "Method: " << kv.first << "\nFinal Transform Matrix:\n";
+                for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) f << std::setw(12) << r.final_transform[i * 4 + j] << " "; f << "\n"; }
+                f << "\n";
+                if (!r.iteration_data.empty()) {
+                    const dcreg_analysis &a = r.iteration_data.back().analysis;
+                    f << "  Condition Numbers:\n    Schur Rot: " << a.cond_schur_rot << "\n    Schur Trans: " << a.cond_schur_trans << "\n    Diag Rot: " << a.cond_diag_rot
+                      << "\n    Diag Trans: " << a.cond_diag_trans << "\n    SVD Diag Rot: " << a.cond_full_sub_rot << "\n    SVD Diag Trans: " << a.cond_full_sub_trans
+                      << "\n    Full SVD: " << a.cond_full << "\n\n";
+                    f << "  EVD Eigenvalues (Full):\n";
+                    for (int i = 0; i < 6; ++i) f << "    \xCE\xBB" << i << ": " << a.eigenvalues_full[i] << "\n";
+                    f << "\n  SVD Singular Values:\n";
+                    for (int i = 0; i < 6; ++i) f << "    \xCF\x83" << i << ": " << a.singular_values[i] << "\n";
+                    f << "\n  Diagonal Block Eigenvalues:\n    Rotation: [" << eigen_row(a.lambda_sub_rot, 3) << "]\n    Translation: [" << eigen_row(a.lambda_sub_trans, 3) << "]\n\n";
+                    f << "  Schur Complement Eigenvalues:\n    Rotation: [" << eigen_row(a.lambda_schur_rot, 3) << "]\n    Translation: [" << eigen_row(a.lambda_schur_trans, 3) << "]\n\n";
+                    f << "  Degenerate Mask (\xCF\x89x\xCF\x89y\xCF\x89z xyz): ";
+                    for (int m : a.degenerate_mask) f << (m ? "1" : "0") << " ";
+                    f << "\n\n";
+                    if (kv.first.find("PCG") != std::string::npos || kv.first == "Ours") {
+                        int perm[6];                                                     // logged(idx[i], idx[j]) = P(i, j), as in the first-iteration file
+                        for (int i = 0; i < 3; ++i) { perm[a.rot_indices[i]] = i; perm[3 + a.trans_indices[i]] = 3 + i; }
+                        f << "  Preconditioner Matrix P:\n";
+                        for (int i = 0; i < 6; ++i) {
+                            f << "    ";
+                            for (int j = 0; j < 6; ++j) f << std::setw(12) << a.P_preconditioner[perm[i] * 6 + perm[j]] << " ";
+                            f << "\n";
+                        }
+                        f << "\n";
+                    }
+                    if ((kv.first == "Ours" || kv.first.find("SCHUR") != std::string::npos) && a.isDegenerate) {
+                        f << "  Alignment Analysis:\n";
+                        for (int blk = 0; blk < 2; ++blk) {
+                            f << (blk ? "    Translation Axes:\n" : "    Rotation Axes:\n");
+                            const int *idx = blk ? a.trans_indices : a.rot_indices;
+                            const double *lam = blk ? a.lambda_schur_trans : a.lambda_schur_rot;
+                            const double *V = blk ? a.aligned_V_trans : a.aligned_V_rot;
+                            const char *names = blk ? "XYZ" : "RPY";
+                            for (int i = 0; i < 3; ++i) {
+                                const double v[3] = {V[0 * 3 + i], V[1 * 3 + i], V[2 * 3 + i]};
+                                const double ang = std::acos(std::min(1.0, std::max(0.0, std::fabs(v[i])))) * 180.0 / M_PI;
+                                const double sabs = std::max(1e-9, std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]));
+                                f << "      [" << i << "]~" << names[i] << " (orig_idx=" << idx[i] << "): \xCE\xBB=" << lam[idx[i]] << ", Angle=" << ang << "\xC2\xB0, "
+                                  << 100 * std::fabs(v[0]) / sabs << "%" << names[0] << "+" << 100 * std::fabs(v[1]) / sabs << "%" << names[1] << "+"
+                                  << 100 * std::fabs(v[2]) / sabs << "%" << names[2] << "\n";
+                            }
+                        }
+                    }
+                }
+                f << "\n" << std::string(60, '-') << "\n\n";
+            }
         }
         // ---- all_results.csv, :996-1028
         {

@@ -83,6 +83,37 @@ def test_runner_outputs_match_committed_files(cfg, family, tmp_path):
         assert len(vo) == len(vg)
         for a, b in zip(vo, vg):
             assert abs(a - b) <= 2e-5 * max(1.0, abs(b)) + 2e-6, (m, a, b)
+    # degeneracy_analysis_last_iter.txt: same layout (incl. Eigen's common-width row vectors), numbers to print precision
+    ours_txt = open(out + "degeneracy_analysis_last_iter.txt").read()
+    gold_txt = open(os.path.join(h.GOLDEN, family, "degeneracy_analysis_last_iter.txt")).read()
+    assert ours_txt.splitlines()[:2] == gold_txt.splitlines()[:2]
+    for m in methods:
+        blk = lambda t: t.split("Method: " + m + "\n")[1].split("Method: ")[0]
+        bo, bg = blk(ours_txt), blk(gold_txt)
+        assert num.sub("#", bo).split() == num.sub("#", bg).split(), m
+        vo, vg = [float(x) for x in num.findall(bo)], [float(x) for x in num.findall(bg)]
+        assert len(vo) == len(vg)
+        for a, b in zip(vo, vg):
+            assert abs(a - b) <= 3e-5 * max(1.0, abs(b)) + 2e-6, (m, a, b)
+    # transform_details.csv: bug-compatible raw layout (merged cells after Transform_33 and Degenerate_Mask_5)
+    tl = lambda path: [ln.split(",") for ln in open(path).read().splitlines()]
+    A, G = tl(out + "transform_details.csv"), tl(os.path.join(h.GOLDEN, family, "transform_details.csv"))
+    assert A[0] == G[0]
+    for m in methods:
+        ra, rg = [r for r in A if r[0] == m][0], [r for r in G if r[0] == m][0]
+        assert len(ra) == len(rg)
+        for k, (x, y) in enumerate(zip(ra, rg)):
+            if k == 4:                                    # Time_ms
+                continue
+            try:
+                fy = float(y)
+            except ValueError:
+                assert x == y, (m, k, x, y)
+                continue
+            if np.isnan(fy):
+                assert x.lower() == y.lower(), (m, k, x, y)
+            else:
+                assert np.isclose(float(x), fy, rtol=5e-5, atol=2e-6), (m, k, x, y)
     txt = open(out + "statistics_summary.txt").read()
     gold = open(os.path.join(h.GOLDEN, family, "statistics_summary.txt")).read()
     assert txt.splitlines()[0] == gold.splitlines()[0] and "Detailed Statistics:" in txt
