@@ -74,4 +74,20 @@ inline bool save_binary(const std::string &path, const float *xyzi, size_t n) {
     return (bool)f;
 }
 
+// pcl::PointXYZRGB as pcl::io::savePCDFileBinary writes it: x y z + packed 0xAARRGGBB (alpha 255) in one uint32 field
+inline bool save_binary_rgb(const std::string &path, const std::vector<float> &xyz, const std::vector<uint32_t> &rgba) {
+    const size_t n = rgba.size();
+    std::ofstream f(path, std::ios::binary);
+    if (!f || xyz.size() != 3 * n) return false;
+    f << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+      << "WIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA binary\n";
+    for (size_t i = 0; i < n; ++i) {
+        f.write(reinterpret_cast<const char *>(&xyz[3 * i]), 3 * sizeof(float));
+        f.write(reinterpret_cast<const char *>(&rgba[i]), sizeof(uint32_t));
+    }
+    return (bool)f;
+}
+
+inline uint32_t pack_rgb(unsigned r, unsigned g, unsigned b) { return 0xFF000000u | (r << 16) | (g << 8) | b; }
+
 }  // namespace pcdio

@@ -206,9 +206,13 @@ private:
             TestResult r = runSingleTest(name, det, hand, run);
             detailed_results_[name].push_back(r);
             updateStatistics(name, r);
-            if (run == 0 && config_.save_pcd) {
+            if (run == 0 && (config_.save_pcd || config_.save_error_pcd)) {          // :352-380
                 std::vector<float> aligned(source_.xyzi);
                 transformCloud(r.final_transform, aligned);
+                if (config_.save_error_pcd) saveErrorPointCloud(aligned, config_.output_folder + name + "_error.pcd");
+                if (!config_.save_pcd) continue;
+                saveAlignedClouds(aligned, config_.output_folder + name + "_aligned_clouds.pcd");
+                std::cout << "Saved aligned clouds for " << name << " to " << config_.output_folder + name + "_aligned_clouds.pcd" << std::endl;
                 pcdio::save_binary(config_.output_folder + name + "_aligned_clouds_sig.pcd", aligned.data(), source_.size());
                 std::vector<float> initial(source_.xyzi);
                 transformCloud(config_.initial_matrix, initial);
@@ -217,6 +221,52 @@ private:
             }
         }
         return true;
+    }
+
+    // saveAlignedClouds, :519-552: aligned source in orange (245,121,0) followed by the target in blue-grey (144,159,207)
+    void saveAlignedClouds(const std::vector<float> &aligned_xyzi, const std::string &filename) {
+        std::vector<float> xyz;
+        std::vector<uint32_t> rgb;
+        xyz.reserve(3 * (source_.size() + target_.size()));
+        for (size_t i = 0; i < source_.size(); ++i) {
+            xyz.insert(xyz.end(), {aligned_xyzi[4 * i], aligned_xyzi[4 * i + 1], aligned_xyzi[4 * i + 2]});
+            rgb.push_back(pcdio::pack_rgb(245, 121, 0));
+        }
+        for (size_t i = 0; i < target_.size(); ++i) {
+            xyz.insert(xyz.end(), {target_.xyzi[4 * i], target_.xyzi[4 * i + 1], target_.xyzi[4 * i + 2]});
+            rgb.push_back(pcdio::pack_rgb(144, 159, 207));
+        }
+        pcdio::save_binary_rgb(filename, xyz, rgb);
+    }
+
+    // saveErrorPointCloud / createErrorPointCloud / getJetColorForError, :555-600 + utils.hpp:591-627: nearest-target
+    // distance of every aligned point (1-NN sweep on the device index), jet colour map clipped at
+    // min(error_threshold, largest distance)
+    void saveErrorPointCloud(const std::vector<float> &aligned_xyzi, const std::string &filename) {
+        const size_t n = source_.size();
+        std::vector<int32_t> idx(n);
+        std::vector<float> d2(n);
+        if (dcreg_knn(ctx_, aligned_xyzi.data(), (int64_t)n, 4, 1, 0.0, idx.data(), d2.data()) != DCREG_OK) {
+            std::cerr << "error cloud: " << dcreg_last_error(ctx_) << std::endl;
+            return;
+        }
+        double mx = 0.0;
+        for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::sqrt((double)d2[i]));
+        const double cmax = std::min(config_.error_threshold, mx);
+        std::vector<float> xyz(3 * n);
+        std::vector<uint32_t> rgb(n);
+        for (size_t i = 0; i < n; ++i) {
+            const double e = std::min(std::sqrt((double)d2[i]) / cmax, 1.0);
+            double r, g, b;
+            if (e < 0.25) { r = 0.0; g = e / 0.25; b = 1.0; }
+            else if (e < 0.5) { r = 0.0; g = 1.0; b = 1.0 - (e - 0.25) / 0.25; }
+            else if (e < 0.75) { r = (e - 0.5) / 0.25; g = 1.0; b = 0.0; }
+            else { r = 1.0; g = 1.0 - (e - 0.75) / 0.25; b = 0.0; }
+            rgb[i] = pcdio::pack_rgb((uint8_t)(255 * r), (uint8_t)(255 * g), (uint8_t)(255 * b));
+            for (int k = 0; k < 3; ++k) xyz[3 * i + k] = aligned_xyzi[4 * i + k];
+        }
+        pcdio::save_binary_rgb(filename, xyz, rgb);
+        std::cout << "Saved error visualization to " << filename << std::endl;
     }
 
     static void transformCloud(const double T[16], std::vector<float> &xyzi) {   // pcl::transformPointCloud<PointT,double>

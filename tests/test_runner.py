@@ -120,3 +120,53 @@ def test_runner_outputs_match_committed_files(cfg, family, tmp_path):
     for line in gold.splitlines():
         if line.strip().startswith("Converged:"):
             assert line in txt
+
+
+def _read_pcd_raw(path):
+    """header lines + the binary payload as a [n, 4] uint32 array (x y z as float bits, 4th field raw)"""
+    with open(path, "rb") as f:
+        header = []
+        while True:
+            line = f.readline().decode("ascii").strip()
+            header.append(line)
+            if line.startswith("DATA"):
+                break
+        n = int([ln for ln in header if ln.startswith("POINTS")][0].split()[1])
+        body = np.frombuffer(f.read(), dtype=np.uint32).reshape(n, 4)
+    return header, body
+
+
+@pytest.mark.gpu
+def test_runner_colour_pcds(tmp_path):
+    """save_pcd / save_error_pcd outputs: the combined two-colour cloud vs the committed file of the release run,
+    the jet error cloud vs an independent evaluation of the same colour map on oracle distances."""
+    from oracle import pyoracle as po
+    out = str(tmp_path) + "/"
+    cfg = open(os.path.join(h.REPO, "configs", "icp.yaml")).read()
+    cfg = cfg.replace("save_pcd: false", "save_pcd: true").replace("save_error_pcd: false", "save_error_pcd: true")
+    ypath = os.path.join(str(tmp_path), "icp_pcd.yaml")
+    open(ypath, "w").write(cfg)
+    p = subprocess.run([RUNNER, ypath, out], cwd=h.REPO, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    hg, bg = _read_pcd_raw(os.path.join(h.GOLDEN, "release", "ME-SR_aligned_clouds.pcd"))
+    ho, bo = _read_pcd_raw(out + "ME-SR_aligned_clouds.pcd")
+    assert ho == hg                                                   # identical PCD header (fields, types, counts)
+    assert np.array_equal(bo[:, 3], bg[:, 3])                          # packed colours incl. alpha
+    # the final transform agrees with the committed one to ~1e-6 (all_results tolerance); at 40 m range that is 1e-4 m
+    assert np.allclose(bo[:, :3].view(np.float32), bg[:, :3].view(np.float32), rtol=0, atol=5e-4)
+    # error cloud
+    he, be = _read_pcd_raw(out + "ME-SR_error.pcd")
+    assert he[:6] == hg[:6] and len(be) == 7562
+    pts = h.cylinder_cloud()
+    aligned = be[:, :3].view(np.float32)
+    assert np.allclose(aligned, bo[:7562, :3].view(np.float32), rtol=0, atol=0)
+    _, d2 = po.KdTree(pts).knn(np.ascontiguousarray(aligned), k=1)
+    err = np.sqrt(d2[:, 0].astype(np.float64))
+    e = np.minimum(err / min(0.2, err.max()), 1.0)                     # error_threshold 0.2 in configs/icp.yaml
+    r = np.where(e < 0.5, 0.0, np.where(e < 0.75, (e - 0.5) / 0.25, 1.0))
+    g = np.where(e < 0.25, e / 0.25, np.where(e < 0.75, 1.0, 1.0 - (e - 0.75) / 0.25))
+    b = np.where(e < 0.25, 1.0, np.where(e < 0.5, 1.0 - (e - 0.25) / 0.25, 0.0))
+    want = 0xFF000000 | ((255 * r).astype(np.uint32) << 16) | ((255 * g).astype(np.uint32) << 8) | (255 * b).astype(np.uint32)
+    assert np.array_equal(be[:, 3], want.astype(np.uint32))
+    for f in ("ME-SR_aligned_clouds_sig.pcd", "initial_clouds.pcd", "target_clouds.pcd", "FCN-SR_error.pcd"):
+        assert os.path.getsize(out + f) > 7562 * 16
