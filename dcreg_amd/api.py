@@ -32,7 +32,8 @@ OK, E_INVALID, E_NOMEM, E_DEVICE, E_STATE = 0, -1, -2, -3, -4
 class LinParams(C.Structure):
     _fields_ = [("search_radius", C.c_double), ("max_plane_thickness_sq", C.c_double),
                 ("min_normal_norm", C.c_double), ("weight_slope", C.c_double), ("weight_min", C.c_double),
-                ("use_weight_derivative", C.c_int), ("k", C.c_int)]
+                ("use_weight_derivative", C.c_int), ("k", C.c_int), ("parameterization", C.c_int), ("reserved_", C.c_int),
+                ("euler_rpy", C.c_double * 3)]
 
 
 class LinOut(C.Structure):
@@ -113,7 +114,7 @@ EXPORTS = [
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_debug", "dcreg_knn",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
-    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
+    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
 ]
 
 _lib = None
@@ -167,6 +168,8 @@ def load():
     L.dcreg_pose_error.argtypes = [dp, dp, dp, dp]
     L.dcreg_icp_run.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
                                 C.POINTER(IcpResult)]
+    L.dcreg_icp_run_euler.argtypes = [vp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
+                                      C.POINTER(IcpResult), dp]
     L.dcreg_icp_run_trials.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(TrialResult)]
     L.dcreg_p2p_error.argtypes = [vp, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int64)]
     L.dcreg_sizeof.restype = C.c_size_t
@@ -203,10 +206,15 @@ def default_config(**kw):
     return cfg
 
 
-def default_lin_params(search_radius=1.0, use_weight_derivative=0):
+def default_lin_params(search_radius=1.0, use_weight_derivative=0, euler_rpy=None):
+    """euler_rpy = (roll, pitch, yaw): the Euler / LOAM row of the second engine (R, t passed to linearize must be the
+    pose6d_matrix of that pose)."""
     p = LinParams()
     load().dcreg_default_lin_params(C.byref(p), float(search_radius))
     p.use_weight_derivative = int(use_weight_derivative)
+    if euler_rpy is not None:
+        p.parameterization = 1
+        p.euler_rpy[:] = [float(v) for v in euler_rpy]
     return p
 
 
@@ -368,6 +376,19 @@ class Context:
         if res.status == 1:
             n = min(res.iterations - 1, cap)
         return res, [logs[i] for i in range(max(n, 0))]
+
+    def icp_run_euler(self, pose6d, method, cfg, log_capacity=None):
+        """Second engine (Pose6D state, LOAM Jacobian); pose6d = (roll, pitch, yaw, x, y, z).
+        Returns (result, [IterLog...], final_pose6d)."""
+        p0 = _f64(pose6d, 6)
+        det, hand = METHODS[method] if isinstance(method, str) else method
+        cap = cfg.max_iterations if log_capacity is None else log_capacity
+        logs = (IterLog * max(cap, 1))()
+        res = IcpResult()
+        pf = np.zeros(6)
+        self._check(self._L.dcreg_icp_run_euler(self._h, _dp(p0), DETECTION[det], HANDLING[hand], C.byref(cfg), logs, cap,
+                                                C.byref(res), _dp(pf)), "dcreg_icp_run_euler")
+        return res, [logs[i] for i in range(max(min(res.iterations, cap), 0))], pf
 
     def icp_run_trials(self, T0s, method, cfg):
         T0s = _f64(T0s).reshape(-1, 4, 4)

@@ -247,6 +247,23 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     }
     a.max_ring = k;
     c->last_max_ring = k;
+    a.euler = p->parameterization == DCREG_PARAM_EULER ? 1 : 0;
+    if (p->parameterization != DCREG_PARAM_SO3 && p->parameterization != DCREG_PARAM_EULER) { c->fail("unknown parameterization"); return DCREG_E_INVALID; }
+    for (double &v : a.dR) v = 0.0;
+    if (a.euler) {   // derivatives of R = Rz(yaw) Ry(pitch) Rx(roll) (Pose6D2Matrix, utils.hpp:452-460)
+        const double cr = std::cos(p->euler_rpy[0]), sr = std::sin(p->euler_rpy[0]);
+        const double cp = std::cos(p->euler_rpy[1]), sp = std::sin(p->euler_rpy[1]);
+        const double cy = std::cos(p->euler_rpy[2]), sy = std::sin(p->euler_rpy[2]);
+        const double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, dRx[9] = {0, 0, 0, 0, -sr, -cr, 0, cr, -sr};
+        const double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, dRy[9] = {-sp, 0, cp, 0, 0, 0, -cp, 0, -sp};
+        const double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1}, dRz[9] = {-sy, -cy, 0, cy, -sy, 0, 0, 0, 0};
+        auto mul3 = [](const double *A, const double *B, const double *C3, double *out) {
+            double T[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j]; T[i * 3 + j] = s; }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * C3[k * 3 + j]; out[i * 3 + j] = s; }
+        };
+        mul3(Rz, Ry, dRx, a.dR); mul3(Rz, dRy, Rx, a.dR + 9); mul3(dRz, Ry, Rx, a.dR + 18);
+    }
     return DCREG_OK;
 }
 
@@ -502,6 +519,7 @@ int dcreg_set_source_device(dcreg_ctx *c, const float *xyz, int64_t n, int64_t s
 
 int dcreg_default_lin_params(dcreg_lin_params *p, double radius) {
     if (!p) return DCREG_E_INVALID;
+    std::memset(p, 0, sizeof(*p));            // parameterization = DCREG_PARAM_SO3
     p->search_radius = radius; p->max_plane_thickness_sq = 0.2 * 0.2; p->min_normal_norm = 1e-6;
     p->weight_slope = 0.9; p->weight_min = 0.1; p->use_weight_derivative = 0; p->k = 5;
     return DCREG_OK;

@@ -38,6 +38,8 @@ struct LinArgs {
     int max_ring;                 // rings needed to cover the radius
     uint32_t *prev;               // [5][prev_stride] sorted-target positions of each query's last neighbour set, or null
     uint32_t prev_stride;
+    int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
+    double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
 };
 
 // ---------------------------------------------------------------- k-NN heaps (sorted, K entries)
@@ -790,14 +792,27 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
                         const float cif = (float)(s * r);                                                    // :1790
                         const double inv_s = 1.0 / s;
                         const double nx = (double)cxf * inv_s, ny = (double)cyf * inv_s, nz = (double)czf * inv_s;   // :1889
-                        // J_r = [ (p x m)^T , m^T ],  m = R^T n   (math_utils.hpp:102-121)
-                        const double m0 = P.R[0] * nx + P.R[3] * ny + P.R[6] * nz;
-                        const double m1 = P.R[1] * nx + P.R[4] * ny + P.R[7] * nz;
-                        const double m2 = P.R[2] * nx + P.R[5] * ny + P.R[8] * nz;
-                        const double w = s + r * ds;                                                         // :1898
                         double A[6];
-                        A[0] = w * (py * m2 - pz * m1); A[1] = w * (pz * m0 - px * m2); A[2] = w * (px * m1 - py * m0);
-                        A[3] = w * m0; A[4] = w * m1; A[5] = w * m2;
+                        if (!a.euler) {
+                            // J_r = [ (p x m)^T , m^T ],  m = R^T n   (math_utils.hpp:102-121)
+                            const double m0 = P.R[0] * nx + P.R[3] * ny + P.R[6] * nz;
+                            const double m1 = P.R[1] * nx + P.R[4] * ny + P.R[7] * nz;
+                            const double m2 = P.R[2] * nx + P.R[5] * ny + P.R[8] * nz;
+                            const double w = s + r * ds;                                                     // :1898
+                            A[0] = w * (py * m2 - pz * m1); A[1] = w * (pz * m0 - px * m2); A[2] = w * (px * m1 - py * m0);
+                            A[3] = w * m0; A[4] = w * m1; A[5] = w * m2;
+                        } else {
+                            // second engine (:2296-2347): row = [ c^T dR/droll p, c^T dR/dpitch p, c^T dR/dyaw p, c^T ] with
+                            // c = the float-stored weighted normal s*n; no weight derivative, no division by s
+                            const double c0 = (double)cxf, c1 = (double)cyf, c2 = (double)czf;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const double *D = a.dR + 9 * k;
+                                A[k] = c0 * (D[0] * px + D[1] * py + D[2] * pz) + c1 * (D[3] * px + D[4] * py + D[5] * pz) +
+                                       c2 * (D[6] * px + D[7] * py + D[8] * pz);
+                            }
+                            A[3] = c0; A[4] = c1; A[5] = c2;
+                        }
                         const double b = -(double)cif;                                                       // :1906
                         int idx = 0;
 #pragma unroll

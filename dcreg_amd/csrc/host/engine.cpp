@@ -8,9 +8,11 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../../include/dcreg.h"
+#include "linalg.hpp"
 #include "se3.hpp"
 
 namespace dcreg {
@@ -168,6 +170,118 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
         dcreg::poseError(cfg->gt_matrix, tr.final_transform, &tr.trans_error_m, &tr.rot_error_deg);   // :501-503
         tr.time_ms = total_ms / (double)n_trials;   // amortised: trials advance together
     }
+    return DCREG_OK;
+}
+
+// Second engine: TestRunner::Point2PlaneICP (icp_test_runner.cpp:2064-2830), Pose6D state, LOAM Jacobian.
+int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, int handling, const dcreg_config *cfg,
+                        dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res, double final_pose6d[6]) {
+    if (!ctx || !pose6d || !cfg || !res) return DCREG_E_INVALID;
+    std::memset(res, 0, sizeof(*res));
+    const auto t_total = Clock::now();
+    double pose[6];                                    // roll pitch yaw x y z  (:2086)
+    std::memcpy(pose, pose6d, sizeof(pose));
+    double Hlast[36];
+    for (int i = 0; i < 36; ++i) Hlast[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    dcreg_lin_params prm = lin_params_of(*cfg);
+    prm.parameterization = DCREG_PARAM_EULER;
+    prm.use_weight_derivative = 0;                     // this engine has no weight-derivative term (:2296-2347)
+    dcreg_index_info info;
+    dcreg_index_info_get(ctx, &info);
+    double T[16], R[9], t[3];
+    auto pose_matrix = [&]() {
+        dcreg::pose6dToMatrix(pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], T);   // Pose6D2Matrix, :2164
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j]; t[i] = T[i * 4 + 3]; }
+    };
+    pose_matrix();
+    if (info.n_source <= 0 || info.n_target <= 0) {    // :2089-2100
+        res->status = 3;
+        std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
+        covariance_of(false, Hlast, res->icp_cov);
+        if (final_pose6d) std::memcpy(final_pose6d, pose, sizeof(pose));
+        return DCREG_OK;
+    }
+    double prev_rmse = std::numeric_limits<double>::max(), prev_fitness = 0.0;   // :2115-2116
+    for (int it = 0; it < cfg->max_iterations; ++it) {
+        const auto t_iter = Clock::now();
+        pose_matrix();
+        prm.euler_rpy[0] = pose[0]; prm.euler_rpy[1] = pose[1]; prm.euler_rpy[2] = pose[2];
+        dcreg_lin_out lo;
+        const int rc = dcreg_linearize(ctx, R, t, &prm, &lo);
+        if (rc != DCREG_OK) return rc;
+        if (lo.n_eff < 10) { res->iterations = it; res->converged = 0; res->status = 1; break; }   // :2272-2286 (final_iterations_ = iterCount)
+        const double fitness = (double)lo.n_pt / (double)info.n_source;          // :2289
+        const double rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);            // :2291
+        StepOut so;
+        dcreg_unpack_hessian(lo.H_upper, so.H);
+        dcreg_analyze_degeneracy(so.H, detection, handling, cfg, &so.an);
+        dcreg_solve_degenerate_system(so.H, lo.g, handling, cfg, &so.an, so.dx);
+        bool finite = true;
+        for (double v : so.dx) finite = finite && std::isfinite(v);
+        if (!finite) { res->iterations = it; res->converged = 0; res->status = 2; break; }         // :2605-2617
+        for (int i = 0; i < 6; ++i) pose[i] += so.dx[i];                         // :2633-2638
+        const double d_rmse = rmse - prev_rmse, d_fit = fitness - prev_fitness;  // :2645-2648
+        prev_rmse = rmse; prev_fitness = fitness;
+        std::memcpy(Hlast, so.H, sizeof(Hlast));                                 // :2649
+        if (log && it < log_capacity) {
+            dcreg_iter_log &L = log[it];
+            std::memset(&L, 0, sizeof(L));
+            L.iter_count = it;
+            L.effective_points = lo.n_eff; L.corr_pt_count = lo.n_pt;
+            L.fitness = fitness; L.rmse = rmse;
+            L.objective_value = 0.5 * lo.sum_b2;                                 // :2357
+            for (int i = 0; i < 6; ++i) { L.gradient[i] = -lo.g[i]; L.update_dx[i] = so.dx[i]; }   // :2356, :2630
+            pose_matrix();
+            std::memcpy(L.transform_matrix, T, sizeof(T));                       // :2675
+            dcreg::poseError(cfg->gt_matrix, L.transform_matrix, &L.trans_error_vs_gt, &L.rot_error_vs_gt);
+            std::memcpy(L.H_upper, lo.H_upper, sizeof(L.H_upper));
+            L.analysis = so.an;
+            L.iter_time_ms = ms_since(t_iter);
+        }
+        res->iterations = it + 1;
+        if (std::fabs(d_rmse) < 1e-4 && std::fabs(d_fit) < 1e-4) { res->converged = 1; break; }   // :2679-2687
+    }
+    pose_matrix();
+    std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
+    if (final_pose6d) std::memcpy(final_pose6d, pose, sizeof(pose));
+    // covariance (:2695-2738): H_last^-1, PSD-clamped, mapped through blockdiag(J_euler->lie, I), clamped again
+    covariance_of(false, Hlast, res->icp_cov);                                   // 1e6 * I
+    double inv[36];
+    if (res->converged && dcreg::invertSpd6(Hlast, inv)) {
+        using dcreg::Mat6; using dcreg::Vec;
+        auto clamp_psd = [](Mat6 &M, bool always) {
+            Mat6 Ms;                                                             // symmetrise (SelfAdjointEigenSolver reads one triangle)
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ms.v[i * 6 + j] = 0.5 * (M.v[i * 6 + j] + M.v[j * 6 + i]);
+            Vec<6> w; Mat6 V;
+            const bool ok = dcreg::symEig<6>(Ms, w, V);
+            double mn = w[0]; for (double x : w) mn = std::min(mn, x);
+            if (!always && ok && mn > 1e-12) return;
+            for (double &x : w) x = std::max(x, 1e-9);
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+                double s2 = 0.0;
+                for (int k = 0; k < 6; ++k) s2 += V.v[i * 6 + k] * w[k] * V.v[j * 6 + k];
+                M.v[i * 6 + j] = s2;
+            }
+        };
+        Mat6 C; std::memcpy(C.v, inv, sizeof(inv));
+        clamp_psd(C, false);
+        // computeEulerToLieJacobian, math_utils.hpp:125-136
+        const double cr = std::cos(pose[0]), sr = std::sin(pose[0]), cp = std::cos(pose[1]), sp = std::sin(pose[1]);
+        dcreg::Mat3 Jl; for (double &x : Jl.v) x = 0.0;
+        Jl.v[0] = Jl.v[4] = Jl.v[8] = 1.0;
+        if (std::fabs(cp) >= 1e-6) {
+            dcreg::Mat3 E; const double e[9] = {1.0, 0.0, sp, 0.0, cr, -sr * cp, 0.0, sr, cr * cp};
+            std::memcpy(E.v, e, sizeof(e));
+            dcreg::Mat3 Ei;
+            if (dcreg::fullPivLuInverse3(E, Ei)) Jl = Ei;
+        }
+        Mat6 J; for (double &x : J.v) x = 0.0;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) J.v[i * 6 + j] = Jl.v[i * 3 + j]; J.v[(i + 3) * 6 + i + 3] = 1.0; }
+        Mat6 Cl = dcreg::mul(dcreg::mul(J, C), dcreg::transpose(J));
+        clamp_psd(Cl, true);
+        std::memcpy(res->icp_cov, Cl.v, sizeof(Cl.v));
+    }
+    res->time_ms = ms_since(t_total);
     return DCREG_OK;
 }
 

@@ -3,7 +3,8 @@
 // DCReg/src/icp_test_runner.cpp:20-516, 604-1030, 1386-1500) on top of the C-ABI of include/dcreg.h.
 // YAML keys, method-name dispatch, std::map method order, enum strings and the on-disk formats are kept, so
 // DCReg/config/icp.yaml, icp_iter.yaml and icp_pk01.yaml run unmodified apart from paths.
-// Additive keys (all optional): icp.use_weight_derivative, icp.always_compute_schur, device, test.seed,
+// Additive keys (all optional): icp.use_weight_derivative, icp.always_compute_schur, icp.use_so3_parameterization (the
+// reference's Config field, utils.hpp:170, which its loader never reads; false selects the Euler / LOAM engine), device, test.seed,
 // test.perturb_trans_m, test.perturb_rot_deg (seeded per-run perturbation of initial_noise; the reference has no RNG).
 #include <chrono>
 #include <cmath>
@@ -44,6 +45,7 @@ struct RunnerConfig {                 // ICPRunner::Config, utils.hpp:132-171
     int device = 0;
     uint64_t seed = 0;
     double perturb_trans = 0.0, perturb_rot_deg = 0.0;
+    bool use_so3_parameterization = true;   // utils.hpp:170 (false -> the Euler / LOAM engine, :449-458)
 };
 
 struct TestResult {                   // utils.hpp:253-303
@@ -114,6 +116,7 @@ bool loadConfig(const std::string &filename, RunnerConfig &c) {     // :20-153
             c.core.CONVERGENCE_THRESH_ROT = i["CONVERGENCE_THRESH_ROT"].as_double();
             if (i.has("use_weight_derivative")) c.core.use_weight_derivative = i["use_weight_derivative"].as_bool();
             if (i.has("always_compute_schur")) c.core.always_compute_schur = i["always_compute_schur"].as_bool();
+            if (i.has("use_so3_parameterization")) c.use_so3_parameterization = i["use_so3_parameterization"].as_bool();
             std::cout << "CONVERGENCE_THRESH_TRANS: " << c.core.CONVERGENCE_THRESH_TRANS << std::endl;
             std::cout << "CONVERGENCE_THRESH_ROT: " << c.core.CONVERGENCE_THRESH_ROT << std::endl;
         }
@@ -150,6 +153,7 @@ bool loadConfig(const std::string &filename, RunnerConfig &c) {     // :20-153
     std::cout << "DEGENERACY_THRES_COND: " << c.core.DEGENERACY_THRES_COND << std::endl;
     std::cout << "DEGENERACY_THRES_EIG: " << c.core.DEGENERACY_THRES_EIG << std::endl;
     std::cout << "USE_WEIGHT_DERIVATIVE: " << c.core.use_weight_derivative << std::endl;
+    std::cout << "USE_SO3 ICP: " << c.use_so3_parameterization << std::endl;                   // :145
     std::cout << "==========================\n" << std::endl;
     return true;
 }
@@ -283,10 +287,10 @@ private:
         r.method_name = name;
         double T0[16];
         for (int i = 0; i < 16; ++i) T0[i] = config_.initial_matrix[i];
+        Pose6D p = config_.initial_noise;
         if (run > 0 && (config_.perturb_trans > 0.0 || config_.perturb_rot_deg > 0.0)) {   // additive: seeded perturbation
             std::mt19937_64 rng(config_.seed + (uint64_t)run);
             std::uniform_real_distribution<double> u(-1.0, 1.0);
-            Pose6D p = config_.initial_noise;
             p.x += u(rng) * config_.perturb_trans; p.y += u(rng) * config_.perturb_trans; p.z += u(rng) * config_.perturb_trans;
             p.roll += deg2rad(u(rng) * config_.perturb_rot_deg); p.pitch += deg2rad(u(rng) * config_.perturb_rot_deg); p.yaw += deg2rad(u(rng) * config_.perturb_rot_deg);
             dcreg_pose6d_to_matrix(p.roll, p.pitch, p.yaw, p.x, p.y, p.z, T0);
@@ -302,7 +306,10 @@ private:
         std::vector<dcreg_iter_log> log((size_t)std::max(config_.core.max_iterations, 1));
         dcreg_icp_result res;
         const auto start = std::chrono::high_resolution_clock::now();                      // :442
-        const int rc = dcreg_icp_run(ctx_, R0, t0, det, hand, &config_.core, log.data(), (int)log.size(), &res);
+        const double pose6d[6] = {p.roll, p.pitch, p.yaw, p.x, p.y, p.z};
+        const int rc = config_.use_so3_parameterization                                      // :443-458
+                           ? dcreg_icp_run(ctx_, R0, t0, det, hand, &config_.core, log.data(), (int)log.size(), &res)
+                           : dcreg_icp_run_euler(ctx_, pose6d, det, hand, &config_.core, log.data(), (int)log.size(), &res, nullptr);
         const auto end = std::chrono::high_resolution_clock::now();                        // :459
         if (rc != DCREG_OK) { std::cerr << "[ICP Error] " << dcreg_last_error(ctx_) << std::endl; return r; }
         if (res.status == 1) std::cerr << "[ICP Warn] Not enough effective points. Aborting." << std::endl;
@@ -311,7 +318,7 @@ private:
         r.time_ms = std::chrono::duration<double, std::milli>(end - start).count();
         r.iterations = res.iterations;
         int n_logged = res.iterations;
-        if (res.status == 1) n_logged = res.iterations - 1;
+        if (res.status == 1 && config_.use_so3_parameterization) n_logged = res.iterations - 1;   // the Euler engine reports iterCount
         n_logged = std::max(0, std::min(n_logged, (int)log.size()));
         r.iteration_data.assign(log.begin(), log.begin() + n_logged);
         for (int i = 0; i < 16; ++i) r.final_transform[i] = (i % 5 == 0) ? 1.0 : 0.0;

@@ -14,6 +14,8 @@
  *   engine seam
  *       TestRunner::Point2PlaneICP_SO3_OpenMP  icp_test_runner.h:92-102, icp_test_runner.cpp:1611-2060
  *                                                                                 -> dcreg_icp_run
+ *       TestRunner::Point2PlaneICP (Euler / LOAM parameterisation)  icp_test_runner.h:72-82, icp_test_runner.cpp:2064-2830
+ *                                                                                 -> dcreg_icp_run_euler
  *       TestRunner::runMethod num_runs loop  icp_test_runner.cpp:331-390         -> dcreg_icp_run_trials
  *       calculatePointToPointError           utils.hpp:538-589                   -> dcreg_p2p_error
  *
@@ -67,7 +69,14 @@ typedef struct dcreg_lin_params {
     double weight_min;             /* 0.1,     :1785 */
     int use_weight_derivative;     /* USE_WEIGHT_DERIVATIVE, :1691 (0 = released source, 1 = paper) */
     int k;                         /* 5 (only value supported) */
+    int parameterization;          /* DCREG_PARAM_SO3 (right perturbation, math_utils.hpp:102-121) or DCREG_PARAM_EULER
+                                      (LOAM roll/pitch/yaw Jacobian of the second engine, icp_test_runner.cpp:2296-2347) */
+    int reserved_;
+    double euler_rpy[3];           /* DCREG_PARAM_EULER: roll, pitch, yaw of the pose the R passed alongside was built from
+                                      (Pose6D2Matrix: R = Rz(yaw) Ry(pitch) Rx(roll), utils.hpp:452-460) */
 } dcreg_lin_params;
+
+enum dcreg_parameterization { DCREG_PARAM_SO3 = 0, DCREG_PARAM_EULER = 1 };
 
 typedef struct dcreg_lin_out {
     double H_upper[21]; /* A^T A, row-major upper triangle, order [wx wy wz x y z] (hessian_computer.h:89-94) */
@@ -205,6 +214,16 @@ typedef struct dcreg_icp_result {
 
 int dcreg_icp_run(dcreg_ctx *, const double R0[9], const double t0[3], int detection, int handling,
                   const dcreg_config *, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *);
+
+/* The second engine of the reference (selected by Config::use_so3_parameterization == false, icp_test_runner.cpp:443-458):
+ * state = Pose6D {roll, pitch, yaw, x, y, z}, LOAM Jacobian with the float-stored weighted normal and no weight
+ * derivative (:2296-2347), additive update (:2633-2638), convergence on |d rmse| < 1e-4 && |d fitness| < 1e-4
+ * (:2679-2687), covariance mapped through the Euler->Lie Jacobian (:2695-2738).  pose6d = {roll, pitch, yaw, x, y, z};
+ * final_pose6d receives the optimised pose (may be NULL).  The 6x6 analysis / handling step goes through the solver
+ * seam above (the reference inlines a copy of it in this engine).  No committed trace of the reference exercises this
+ * engine: parity is pinned on the shared correspondence steps only. */
+int dcreg_icp_run_euler(dcreg_ctx *, const double pose6d[6], int detection, int handling, const dcreg_config *,
+                        dcreg_iter_log *log, int log_capacity, dcreg_icp_result *, double final_pose6d[6]);
 
 /* TestResult subset per trial (utils.hpp:253-303) */
 typedef struct dcreg_trial_result {

@@ -403,6 +403,37 @@ int orc_plane_fit(const double Q[15], double n_out[3], double *d_out, double *ps
 
 typedef struct { double a[6]; double b; double r; uint8_t flag; uint8_t has_pt; } orc_row;
 
+static void mat3_mul3(const double *A, const double *B, const double *C3, double *out) {
+    double T[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0.0; for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j]; T[i * 3 + j] = s; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0.0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * C3[k * 3 + j]; out[i * 3 + j] = s; }
+}
+
+void orc_euler_dR(double roll, double pitch, double yaw, double dR[27]) {
+    const double cr = cos(roll), sr = sin(roll), cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw);
+    const double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, dRx[9] = {0, 0, 0, 0, -sr, -cr, 0, cr, -sr};
+    const double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, dRy[9] = {-sp, 0, cp, 0, 0, 0, -cp, 0, -sp};
+    const double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1}, dRz[9] = {-sy, -cy, 0, cy, -sy, 0, 0, 0, 0};
+    mat3_mul3(Rz, Ry, dRx, dR); mat3_mul3(Rz, dRy, Rx, dR + 9); mat3_mul3(dRz, Ry, Rx, dR + 18);
+}
+
+/* second engine, :2296-2347: LOAM's arz/arx/ary are the derivatives of (Rz(yaw) Ry(pitch) Rx(roll) p) . c with respect to
+ * roll / pitch / yaw (its x<-y, y<-z, z<-x axis relabelling undone), c = the float-stored weighted normal; translation
+ * columns = c; no weight derivative, no division by s.  Kept out of line so that the pinned SO(3) row compiles exactly as
+ * before (inlining it changed that path's rounding in the 16th digit, which ME-TReg's trace amplifies). */
+static __attribute__((noinline)) void orc_euler_row(const orc_lin_params *prm, double px, double py, double pz,
+                                                    float cx, float cy, float cz, double a[6]) {
+    double dR[27];
+    orc_euler_dR(prm->euler_rpy[0], prm->euler_rpy[1], prm->euler_rpy[2], dR);
+    const double c[3] = {(double)cx, (double)cy, (double)cz};
+    for (int k = 0; k < 3; ++k) {
+        const double *D = dR + 9 * k;
+        a[k] = c[0] * (D[0] * px + D[1] * py + D[2] * pz) + c[1] * (D[3] * px + D[4] * py + D[5] * pz) +
+               c[2] * (D[6] * px + D[7] * py + D[8] * pz);
+        a[3 + k] = c[k];
+    }
+}
+
 static void orc_point_row(const orc_kdtree *tree, const float *P, const double R[9], const double t[3],
                           const orc_lin_params *prm, orc_row *row, orc_lin_debug *dbg, int64_t i) {
     row->flag = 0; row->has_pt = 0; row->b = 0.0; row->r = 0.0;
@@ -460,6 +491,7 @@ static void orc_point_row(const orc_kdtree *tree, const float *P, const double R
     double w = s + r * ds;                                       /* :1898 */
     row->a[0] = w * c0; row->a[1] = w * c1; row->a[2] = w * c2;
     row->a[3] = w * m0; row->a[4] = w * m1; row->a[5] = w * m2;
+    if (prm->parameterization == 1) orc_euler_row(prm, px, py, pz, cx, cy, cz, row->a);
     row->b = -(double)ci;                                        /* :1906 */
     row->r = r;
     row->flag = 1;
@@ -806,7 +838,7 @@ int orc_icp_run(const orc_kdtree *tree, const float *src, int64_t n_src, int64_t
     memcpy(R, R0, sizeof(R)); memcpy(t, t0, sizeof(t));
     for (int i = 0; i < 36; ++i) Hlast[i] = (i % 7 == 0) ? 1.0 : 0.0;
     memset(res, 0, sizeof(*res));
-    orc_lin_params prm = {cfg->search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, cfg->use_weight_derivative, cfg->num_threads};
+    orc_lin_params prm = {cfg->search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, cfg->use_weight_derivative, cfg->num_threads, 0, 0, {0.0, 0.0, 0.0}};
     if (!tree || orc_kdtree_size(tree) == 0 || n_src <= 0) { res->status = 3; return 0; } /* :1635-1646 */
     for (int it = 0; it < cfg->max_iterations; ++it) {
         orc_lin_out lo;
@@ -864,6 +896,56 @@ cov:
         if (ok) memcpy(res->cov, inv, sizeof(inv));
     }
     return res->converged;
+}
+
+/* second engine (icp_test_runner.cpp:2064-2830) */
+int orc_icp_run_euler(const orc_kdtree *tree, const float *src, int64_t n_src, int64_t stride,
+                      const double pose6d[6], int detection, int handling, const orc_config *cfg,
+                      orc_iter_log *log, int log_cap, orc_icp_result *res, double final_pose6d[6]) {
+    double pose[6], T[16], R[9], t[3];
+    memcpy(pose, pose6d, sizeof(pose));
+    memset(res, 0, sizeof(*res));
+    for (int i = 0; i < 36; ++i) res->cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
+    orc_lin_params prm = {cfg->search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, 0, cfg->num_threads, 1, 0, {0.0, 0.0, 0.0}};
+    if (!tree || orc_kdtree_size(tree) == 0 || n_src <= 0) { res->status = 3; return 0; }
+    double prev_rmse = DBL_MAX, prev_fit = 0.0;                 /* :2115-2116 */
+    for (int it = 0; it < cfg->max_iterations; ++it) {
+        orc_pose6d_to_matrix(pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], T);   /* :2164 */
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j]; t[i] = T[i * 4 + 3]; }
+        prm.euler_rpy[0] = pose[0]; prm.euler_rpy[1] = pose[1]; prm.euler_rpy[2] = pose[2];
+        orc_lin_out lo;
+        orc_linearize(tree, src, n_src, stride, R, t, &prm, &lo, NULL);
+        if (lo.n_eff < 10) { res->iterations = it; res->status = 1; break; }             /* :2272-2286 */
+        const double fitness = (double)lo.n_pt / (double)n_src, rmse = sqrt(lo.sum_r2 / (double)lo.n_eff);   /* :2289-2291 */
+        double H[36], x[6];
+        orc_unpack_H(lo.H_upper, H);
+        orc_analysis an;
+        orc_analyze(H, detection, handling, cfg, &an);
+        orc_solve(H, lo.g, handling, cfg, &an, x);
+        int finite = 1;
+        for (int i = 0; i < 6; ++i) if (!isfinite(x[i])) finite = 0;
+        if (!finite) { res->iterations = it; res->status = 2; break; }                   /* :2605-2617 */
+        for (int i = 0; i < 6; ++i) pose[i] += x[i];                                     /* :2633-2638 */
+        const double d_rmse = rmse - prev_rmse, d_fit = fitness - prev_fit;              /* :2645-2648 */
+        prev_rmse = rmse; prev_fit = fitness;
+        if (log && it < log_cap) {
+            orc_iter_log *L = &log[it];
+            memset(L, 0, sizeof(*L));
+            L->iter = it; L->n_eff = lo.n_eff; L->n_pt = lo.n_pt; L->fitness = fitness; L->rmse = rmse;
+            L->objective = 0.5 * lo.sum_b2;
+            for (int i = 0; i < 6; ++i) { L->gradient[i] = -lo.g[i]; L->dx[i] = x[i]; }
+            orc_pose6d_to_matrix(pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], L->T);   /* :2675 */
+            orc_pose_error(cfg->gt, L->T, &L->trans_err, &L->rot_err_deg);
+            memcpy(L->H_upper, lo.H_upper, sizeof(lo.H_upper));
+            L->an = an;
+        }
+        res->iterations = it + 1;
+        if (fabs(d_rmse) < 1e-4 && fabs(d_fit) < 1e-4) { res->converged = 1; break; }    /* :2679-2687 */
+    }
+    orc_pose6d_to_matrix(pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], T);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) res->R[i * 3 + j] = T[i * 4 + j]; res->t[i] = T[i * 4 + 3]; }
+    if (final_pose6d) memcpy(final_pose6d, pose, sizeof(pose));
+    return res->converged;      /* covariance (:2695-2738) is not restated here: host-only post-processing */
 }
 
 /* ============================================================================================

@@ -61,6 +61,10 @@ typedef struct orc_lin_params {
     double weight_min;             /* 0.1  */
     int use_weight_derivative;     /* 0 = released source, 1 = paper traces */
     int num_threads;               /* 0 = OpenMP default; reference hard-codes 8 */
+    int parameterization;          /* 0 = SO(3) right perturbation (math_utils.hpp:102-121), 1 = Euler / LOAM row of the
+                                      second engine (icp_test_runner.cpp:2296-2347) */
+    int reserved_;
+    double euler_rpy[3];           /* parameterization 1: roll, pitch, yaw the R was built from (utils.hpp:452-460) */
 } orc_lin_params;
 
 typedef struct orc_lin_out {
@@ -182,6 +186,15 @@ int orc_icp_run(const orc_kdtree *, const float *src_xyz, int64_t n_src, int64_t
                 const orc_config *, orc_iter_log *log, int log_capacity, orc_icp_result *);
 
 /* calculatePointToPointError (utils.hpp:538-589) */
+/* second engine, TestRunner::Point2PlaneICP (icp_test_runner.cpp:2064-2830): Pose6D state {roll,pitch,yaw,x,y,z}, LOAM
+ * Jacobian, additive update, convergence on |d rmse|,|d fitness| < 1e-4.  The analysis / handling step is orc_analyze /
+ * orc_solve (the reference inlines a copy).  NOT pinned by any committed trace of the reference. */
+int orc_icp_run_euler(const orc_kdtree *, const float *src_xyz, int64_t n_src, int64_t stride_floats,
+                      const double pose6d[6], int detection, int handling, const orc_config *,
+                      orc_iter_log *log, int log_capacity, orc_icp_result *, double final_pose6d[6]);
+/* dR/droll, dR/dpitch, dR/dyaw (row-major 3x3 each) of R = Rz(yaw) Ry(pitch) Rx(roll) */
+void orc_euler_dR(double roll, double pitch, double yaw, double dR[27]);
+
 void orc_p2p_error(const float *aligned_xyz, int64_t n_a, const orc_kdtree *target_tree,
                    const float *target_xyz, int64_t n_t, double error_threshold,
                    double *rmse, double *fitness, double *chamfer, int64_t *valid);

@@ -31,7 +31,8 @@ class LinParams(C.Structure):
     _fields_ = [("search_radius", C.c_double), ("max_plane_thickness_sq", C.c_double),
                 ("min_normal_norm", C.c_double), ("weight_slope", C.c_double),
                 ("weight_min", C.c_double), ("use_weight_derivative", C.c_int),
-                ("num_threads", C.c_int)]
+                ("num_threads", C.c_int), ("parameterization", C.c_int), ("reserved_", C.c_int),
+                ("euler_rpy", C.c_double * 3)]
 
 
 class LinOut(C.Structure):
@@ -130,6 +131,10 @@ def lib():
     L.orc_icp_run.restype = C.c_int
     L.orc_icp_run.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, dp, dp, C.c_int, C.c_int,
                               C.POINTER(Config), C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult)]
+    L.orc_icp_run_euler.restype = C.c_int
+    L.orc_icp_run_euler.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, dp, C.c_int, C.c_int, C.POINTER(Config),
+                                    C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult), dp]
+    L.orc_euler_dR.argtypes = [C.c_double, C.c_double, C.c_double, dp]
     L.orc_p2p_error.argtypes = [fp, C.c_int64, C.c_void_p, fp, C.c_int64, C.c_double, dp, dp, dp,
                                 C.POINTER(C.c_int64)]
     L.orc_sizeof_iter_log.restype = C.c_size_t
@@ -159,8 +164,14 @@ def default_config(**kw):
     return cfg
 
 
-def default_lin_params(search_radius=1.0, use_weight_derivative=0, num_threads=0):
-    return LinParams(search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, use_weight_derivative, num_threads)
+def default_lin_params(search_radius=1.0, use_weight_derivative=0, num_threads=0, euler_rpy=None):
+    """euler_rpy = (roll, pitch, yaw) selects the Euler / LOAM row of the second engine (the R, t passed to
+    linearize must be the Pose6D2Matrix of that pose)."""
+    p = LinParams(search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, use_weight_derivative, num_threads)
+    if euler_rpy is not None:
+        p.parameterization = 1
+        p.euler_rpy[:] = [float(v) for v in euler_rpy]
+    return p
 
 
 class KdTree:
@@ -263,6 +274,27 @@ def icp_run(tree, src, T0, method, cfg, log_capacity=None):
     if res.status == 1:
         n = min(res.iterations - 1, cap)
     return res, [logs[i] for i in range(max(n, 0))]
+
+
+def icp_run_euler(tree, src, pose6d, method, cfg, log_capacity=None):
+    """Second engine (Pose6D state, LOAM Jacobian); pose6d = (roll, pitch, yaw, x, y, z).
+    Returns (result, [IterLog...], final_pose6d)."""
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 3)
+    p0 = np.ascontiguousarray(pose6d, np.float64).reshape(6)
+    det, hand = METHODS[method] if isinstance(method, str) else method
+    cap = log_capacity if log_capacity is not None else cfg.max_iterations
+    logs = (IterLog * max(cap, 1))()
+    res = IcpResult()
+    pf = np.zeros(6)
+    lib().orc_icp_run_euler(tree.ptr, _fp(src), src.shape[0], 3, _dp(p0), DET[det], HAND[hand], C.byref(cfg), logs, cap,
+                            C.byref(res), _dp(pf))
+    return res, [logs[i] for i in range(max(min(res.iterations, cap), 0))], pf
+
+
+def euler_dR(roll, pitch, yaw):
+    d = np.zeros(27)
+    lib().orc_euler_dR(float(roll), float(pitch), float(yaw), _dp(d))
+    return d.reshape(3, 3, 3)
 
 
 def p2p_error(aligned, tree, error_threshold):
