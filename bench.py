@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--method", default="Ours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sharding", default="pairs", choices=["pairs", "points"],
+                    help="pairs (default): one independent scan pair per GPU, no data-path collective, weak scaling; "
+                         "points: ONE pair, source points split over the GPUs, one 256 B all_gather per iteration "
+                         "(dcreg_amd/pointshard.py), strong scaling")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="backend option (dcreg_backend_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
     args = ap.parse_args()
@@ -84,7 +88,14 @@ def main():
     from dcreg_amd import api
 
     scene, n_pts, radius, run_len = WORKLOADS[args.workload]
-    tgt, src = make_pair(scene, n_pts, seed=100 + rank)        # every rank: its own scan pair
+    by_points = args.sharding == "points"
+    tgt, src = make_pair(scene, n_pts, seed=100 + (0 if by_points else rank))   # pairs: every rank its own scan pair
+    n_src_total = len(src)
+    if by_points:                                                # points: the same pair everywhere, this rank's slice
+        from dcreg_amd import pointshard
+        lo, hi = pointshard.slice_of(len(src), rank, world)
+        src = np.ascontiguousarray(src[lo:hi])
+        reducer = pointshard.make_reducer(dist, "cuda")
     ctx = dcreg_amd.Context(local_rank)
     for kv in args.opt:
         k, v = kv.split("=", 1)
@@ -130,9 +141,25 @@ def main():
             state["mc_iters"] += sum(trial_res[i].iterations for i in range(MC_BATCH))   # trials that abort stop counting
             left -= n
 
+    def run_steps_points(k):
+        """k lock-step iterations of ONE scan pair whose source points are split over the ranks: per iteration one
+        linearisation of the local slice, one all_gather of 32 doubles, the host step on every rank."""
+        left = k
+        while left > 0:
+            n = min(run_len, left)
+            cfg.max_iterations = n
+            out, _ = ctx.icp_run_sharded(T_init, args.method, cfg, n_src_total, reducer, log_capacity=0)
+            if out.iterations != n or out.status != 0:
+                raise RuntimeError("point-sharded run stopped early: iterations=%d status=%d" % (out.iterations, out.status))
+            res.R[:] = out.R[:]; res.t[:] = out.t[:]
+            left -= n
+        state["done"] += k
+
     def run_steps(k):
         if mc:
             return run_steps_mc(k)
+        if by_points:
+            return run_steps_points(k)
         return run_steps_single(k)
 
     def run_steps_single(k):
@@ -188,20 +215,21 @@ def main():
 
     if rank == 0:
         per_step = (state["mc_iters"] - mc_before) / args.steps if mc else 1
-        iters_per_s = n_gpus * args.steps * per_step / elapsed
+        iters_per_s = (1 if by_points else n_gpus) * args.steps * per_step / elapsed
         kern_us = float(np.mean(recs[:, 3])) * 1e3
-        algo_bytes = BYTES_PER_QUERY * n_pts * per_step
+        algo_bytes = BYTES_PER_QUERY * len(src) * per_step          # per launch of THIS kernel (a rank's slice when sharded by points)
         traffic = measured_traffic(args.workload)
         achieved = algo_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         result = {
             "metric": "ICP iterations/sec", "value": iters_per_s, "unit": "iterations/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if by_points else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d-pt source x %d-pt target, radius %.2f, runs of %d ICP iterations, method %s "
-                                   "(Schur detection + PCG), one scan pair per GPU" % (args.workload, len(src), len(tgt), radius, run_len, args.method),
-                       "n_src": int(len(src)), "n_tgt": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells)},
-            "correspondence_queries_per_s": iters_per_s * len(src), "icp_iterations_per_step": per_step,
+                                   "(Schur detection + PCG), %s" % (args.workload, n_src_total, len(tgt), radius, run_len, args.method,
+                                                                    "ONE scan pair, source points split over the GPUs" if by_points else "one scan pair per GPU"),
+                       "n_src": int(n_src_total), "n_tgt": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells)},
+            "correspondence_queries_per_s": iters_per_s * n_src_total, "icp_iterations_per_step": per_step,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_linearize (fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r reduction)",

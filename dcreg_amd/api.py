@@ -108,13 +108,15 @@ _STRUCTS = {"dcreg_lin_params": LinParams, "dcreg_lin_out": LinOut, "dcreg_lin_d
             "dcreg_iter_log": IterLog, "dcreg_icp_result": IcpResult, "dcreg_trial_result": TrialResult}
 
 # every symbol include/dcreg.h declares
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_void_p)      # dcreg_reduce_fn
+
 EXPORTS = [
     "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_debug", "dcreg_knn",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
-    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
+    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
 ]
 
 _lib = None
@@ -168,6 +170,8 @@ def load():
     L.dcreg_pose_error.argtypes = [dp, dp, dp, dp]
     L.dcreg_icp_run.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
                                 C.POINTER(IcpResult)]
+    L.dcreg_icp_run_sharded.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.c_int64, REDUCE_FN, vp,
+                                        C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult)]
     L.dcreg_icp_run_euler.argtypes = [vp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
                                       C.POINTER(IcpResult), dp]
     L.dcreg_icp_run_trials.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(TrialResult)]
@@ -372,6 +376,35 @@ class Context:
         res = IcpResult()
         self._check(self._L.dcreg_icp_run(self._h, _dp(R0), _dp(t0), DETECTION[det], HANDLING[hand], C.byref(cfg), logs, cap,
                                           C.byref(res)), "dcreg_icp_run")
+        n = min(res.iterations, cap)
+        if res.status == 1:
+            n = min(res.iterations - 1, cap)
+        return res, [logs[i] for i in range(max(n, 0))]
+
+    def icp_run_sharded(self, T0, method, cfg, n_source_total, reduce_rows, log_capacity=None):
+        """dcreg_icp_run_sharded: reduce_rows(numpy float64[32] view) must overwrite the row IN PLACE with the sum over
+        all ranks in rank order (see dcreg_amd/pointshard.py)."""
+        T0 = _f64(T0).reshape(4, 4)
+        R0, t0 = np.ascontiguousarray(T0[:3, :3]).reshape(9), np.ascontiguousarray(T0[:3, 3])
+        det, hand = METHODS[method] if isinstance(method, str) else method
+        cap = cfg.max_iterations if log_capacity is None else log_capacity
+        logs = (IterLog * max(cap, 1))()
+        res = IcpResult()
+        err = []
+
+        def _cb(row_ptr, _user):
+            try:
+                reduce_rows(np.ctypeslib.as_array(row_ptr, shape=(32,)))
+                return 0
+            except Exception as e:          # never let an exception cross the C boundary
+                err.append(e)
+                return 1
+        cb = REDUCE_FN(_cb)
+        rc = self._L.dcreg_icp_run_sharded(self._h, _dp(R0), _dp(t0), DETECTION[det], HANDLING[hand], C.byref(cfg),
+                                           int(n_source_total), cb, None, logs, cap, C.byref(res))
+        if err:
+            raise err[0]
+        self._check(rc, "dcreg_icp_run_sharded")
         n = min(res.iterations, cap)
         if res.status == 1:
             n = min(res.iterations - 1, cap)

@@ -55,8 +55,9 @@ inline void covariance_of(bool converged, const double Hlast[36], double cov[36]
 
 extern "C" {
 
-int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
-                  const dcreg_config *cfg, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
+int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
+                          const dcreg_config *cfg, int64_t n_source_total, dcreg_reduce_fn reduce, void *reduce_user,
+                          dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
     if (!ctx || !R0 || !t0 || !cfg || !res) return DCREG_E_INVALID;
     std::memset(res, 0, sizeof(*res));
     const auto t_total = Clock::now();
@@ -66,6 +67,7 @@ int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int de
     const dcreg_lin_params prm = lin_params_of(*cfg);
     dcreg_index_info info;
     dcreg_index_info_get(ctx, &info);
+    const double n_src_all = reduce ? (double)n_source_total : (double)info.n_source;
     if (info.n_source <= 0 || info.n_target <= 0) {   // :1635-1646
         res->status = 3;
         std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
@@ -77,6 +79,14 @@ int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int de
         dcreg_lin_out lo;
         const int rc = dcreg_linearize(ctx, R, t, &prm, &lo);
         if (rc != DCREG_OK) return rc;
+        if (reduce) {   // point sharding: this rank linearised its slice; the sums of all slices, added in rank order
+            double row[32];
+            std::memcpy(row, lo.H_upper, 21 * sizeof(double)); std::memcpy(row + 21, lo.g, 6 * sizeof(double));
+            row[27] = lo.sum_r2; row[28] = lo.sum_b2; row[29] = (double)lo.n_eff; row[30] = (double)lo.n_pt; row[31] = 0.0;
+            if (reduce(row, reduce_user) != 0) return DCREG_E_DEVICE;
+            std::memcpy(lo.H_upper, row, 21 * sizeof(double)); std::memcpy(lo.g, row + 21, 6 * sizeof(double));
+            lo.sum_r2 = row[27]; lo.sum_b2 = row[28]; lo.n_eff = (int64_t)std::llround(row[29]); lo.n_pt = (int64_t)std::llround(row[30]);
+        }
         if (lo.n_eff < 10) {                            // :1847-1854
             res->iterations = it + 1; res->converged = 0; res->status = 1;
             break;
@@ -90,7 +100,7 @@ int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int de
             std::memset(&L, 0, sizeof(L));
             L.iter_count = it;
             L.effective_points = lo.n_eff; L.corr_pt_count = lo.n_pt;
-            L.fitness = (double)lo.n_pt / (double)info.n_source;          // :1856
+            L.fitness = (double)lo.n_pt / n_src_all;                      // :1856
             L.rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);             // :1858
             L.objective_value = 0.5 * lo.sum_b2;                          // :1919
             for (int i = 0; i < 6; ++i) { L.gradient[i] = -lo.g[i]; L.update_dx[i] = so.dx[i]; }   // :1918
@@ -107,6 +117,11 @@ int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int de
     covariance_of(res->converged != 0, Hlast, res->icp_cov);
     res->time_ms = ms_since(t_total);
     return DCREG_OK;
+}
+
+int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
+                  const dcreg_config *cfg, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
+    return dcreg_icp_run_sharded(ctx, R0, t0, detection, handling, cfg, 0, nullptr, nullptr, log, log_capacity, res);
 }
 
 int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const double *t0, int detection, int handling,

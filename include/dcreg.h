@@ -215,6 +215,16 @@ typedef struct dcreg_icp_result {
 int dcreg_icp_run(dcreg_ctx *, const double R0[9], const double t0[3], int detection, int handling,
                   const dcreg_config *, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *);
 
+/* Point sharding of ONE scan pair over several devices: the ctx holds the whole target and THIS rank's slice
+ * of the source; after every linearisation `reduce` must replace row[32] (21 H, 6 g, sum r^2, sum b^2, n_eff, n_pt, pad) by
+ * the sum over all ranks, added in rank order so that every rank obtains bitwise the same totals (e.g. an all_gather over
+ * RCCL + ordered sum; return 0 on success).  Every rank then takes the identical host step: no broadcast is needed.
+ * n_source_total = points of the whole source cloud (fitness, :1856).  reduce == NULL: plain dcreg_icp_run. */
+typedef int (*dcreg_reduce_fn)(double row[32], void *user);
+int dcreg_icp_run_sharded(dcreg_ctx *, const double R0[9], const double t0[3], int detection, int handling,
+                          const dcreg_config *, int64_t n_source_total, dcreg_reduce_fn reduce, void *reduce_user,
+                          dcreg_iter_log *log, int log_capacity, dcreg_icp_result *);
+
 /* The second engine of the reference (selected by Config::use_so3_parameterization == false, icp_test_runner.cpp:443-458):
  * state = Pose6D {roll, pitch, yaw, x, y, z}, LOAM Jacobian with the float-stored weighted normal and no weight
  * derivative (:2296-2347), additive update (:2633-2638), convergence on |d rmse| < 1e-4 && |d fitness| < 1e-4

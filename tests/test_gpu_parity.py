@@ -338,3 +338,32 @@ def test_montecarlo_driver_on_gpu(ctx, cyl):
         assert np.allclose(T[:3, :3].reshape(9), ores.R[:], atol=1e-9) and np.allclose(T[:3, 3], ores.t[:], atol=1e-9)
         if ologs:
             assert recs[k, mc.R_CORR] == ologs[-1].n_eff
+
+
+def test_sharded_engine_plumbing(ctx, cyl):
+    """dcreg_icp_run_sharded: with an identity reducer it IS dcreg_icp_run; with a reducer that adds a second, identical
+    rank (row doubled, twice the source points) the unregularised update (2H)^-1 (2g) and the fitness are unchanged."""
+    pts, _ = cyl
+    ctx.set_target(pts, 1.0); ctx.set_source(pts)
+    T0 = h.pose6d_matrix(**h.RELEASE_INIT)
+    cfg = _cfg(False)
+    ref, rlogs = ctx.icp_run(T0, "ME-SR", cfg)
+    same, slogs = ctx.icp_run_sharded(T0, "ME-SR", cfg, len(pts), lambda row: None)
+    assert same.iterations == ref.iterations and same.R[:] == ref.R[:] and same.t[:] == ref.t[:]
+    assert all(a.update_dx[:] == b.update_dx[:] for a, b in zip(slogs, rlogs))
+    calls = []
+
+    def twice(row):
+        calls.append(row[29])
+        row *= 2.0
+    one, ologs = ctx.icp_run(T0, "NONE", cfg)
+    two, tlogs = ctx.icp_run_sharded(T0, "NONE", cfg, 2 * len(pts), twice)
+    assert two.iterations == one.iterations == len(calls) and calls[0] == 871
+    for a, b in zip(tlogs, ologs):
+        assert a.effective_points == 2 * b.effective_points and a.fitness == b.fitness
+        assert np.allclose(a.update_dx[:], b.update_dx[:], rtol=1e-9, atol=1e-15)
+
+    def boom(row):
+        raise ValueError("exchange failed")
+    with pytest.raises(ValueError):
+        ctx.icp_run_sharded(T0, "ME-SR", cfg, len(pts), boom)
