@@ -113,7 +113,8 @@ REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_void_p)      # dcreg
 EXPORTS = [
     "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
-    "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_debug", "dcreg_knn",
+    "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
+    "dcreg_linearize_batch_end", "dcreg_linearize_debug", "dcreg_knn",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",

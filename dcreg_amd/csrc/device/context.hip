@@ -267,10 +267,17 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     return DCREG_OK;
 }
 
-int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
-                     dcreg_lin_out *outs, dcreg_lin_debug *dbg_host) {
+// One linearisation = begin (argument checks, buffers, launches: returns as soon as the work is queued) + end (wait for
+// the pinned result rows, unpack).  Two slots with their own pose / partial / result buffers let a caller keep one batch
+// on the device while the host works on the other (dcreg_linearize_batch_begin / _end); the blocking entry points use
+// slot 0.  Debug dumps are synchronous and only exist on slot 0.
+static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
+                           dcreg_lin_debug *dbg_host) {
     if (!c) return DCREG_E_INVALID;
-    if (!R9 || !t3 || !outs || n_poses < 1) { c->fail("null argument"); return DCREG_E_INVALID; }
+    if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
+    LinSlot &S = c->slots[slot];
+    if (S.pending) { c->fail("slot %d still has a linearisation in flight", slot); return DCREG_E_STATE; }
+    if (!R9 || !t3 || n_poses < 1) { c->fail("null argument"); return DCREG_E_INVALID; }
     if (c->n_tgt <= 0) { c->fail("KdTree/target index is not set up in context"); return DCREG_E_STATE; }   // :1639
     if (c->n_src <= 0) { c->fail("measure cloud is not set"); return DCREG_E_STATE; }
     LinArgs a;
@@ -278,41 +285,40 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
     if (rc) return rc;
     if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
     const uint32_t nbx = blocks_for(c->n_src, kBlock);
-    if (ensure(c, c->d_partials, c->partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
+    if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     // one pose: the kernel finishes the reduction itself (chunk rows -> pinned memory); many poses: k_finalize
     const bool fused = (n_poses == 1);
     const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
     const size_t n_rows = fused ? (size_t)n_chunks : (size_t)n_poses;      // result rows the host waits for
     if (fused) {   // tickets: zero when (re)allocated, afterwards every completed launch leaves them zero
-        const size_t had = c->tickets_cap;
-        if (ensure(c, c->d_tickets, c->tickets_cap, (size_t)n_chunks)) return DCREG_E_NOMEM;
-        if (c->tickets_cap != had || c->tickets_dirty) {
-            HIP_TRY(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * c->tickets_cap, c->stream));
-            c->tickets_dirty = false;
+        const size_t had = S.tickets_cap;
+        if (ensure(c, S.d_tickets, S.tickets_cap, (size_t)n_chunks)) return DCREG_E_NOMEM;
+        if (S.tickets_cap != had || S.tickets_dirty) {
+            HIP_TRY(c, hipMemsetAsync(S.d_tickets, 0, sizeof(unsigned int) * S.tickets_cap, c->stream));
+            S.tickets_dirty = false;
         }
     }
-    if (n_rows > c->out_cap) {
-        if (c->h_out) (void)hipHostFree(c->h_out);
-        c->h_out = nullptr; c->out_cap = 0;
+    if (n_rows > S.out_cap) {
+        if (S.h_out) (void)hipHostFree(S.h_out);
+        S.h_out = nullptr; S.out_cap = 0;
         const size_t cap = std::max<size_t>(n_rows, 64);
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_out, cap * kSlots * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(c->h_out, 0, cap * kSlots * sizeof(double));
-        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_out, c->h_out, 0));
-        c->out_cap = cap;
+        HIP_TRY(c, hipHostMalloc((void **)&S.h_out, cap * kSlots * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(S.h_out, 0, cap * kSlots * sizeof(double));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&S.d_out, S.h_out, 0));
+        S.out_cap = cap;
     }
     PoseArg one{};
     const PoseArg *d_poses = nullptr;
     if (n_poses == 1) {
         std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
     } else {
-        if (ensure(c, c->d_poses, c->poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
-        c->h_poses.resize((size_t)n_poses);
-        for (int i = 0; i < n_poses; ++i) { std::memcpy(c->h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(c->h_poses[i].t, t3 + 3 * i, sizeof(one.t)); }
-        HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
-        d_poses = c->d_poses;
+        if (ensure(c, S.d_poses, S.poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
+        S.h_poses.resize((size_t)n_poses);      // stays alive until end(): source of the asynchronous copy
+        for (int i = 0; i < n_poses; ++i) { std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t)); }
+        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
+        d_poses = S.d_poses;
     }
     DebugDev dd{};
-    std::vector<void *> tmp_dev;
     const int64_t n = c->n_src;
     a.prev = nullptr; a.prev_stride = 0;
     if (c->opt_warm && n_poses == 1) {
@@ -324,12 +330,13 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         }
         a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
     }
+    S.tmp_dev.clear();
     if (dbg_host) {
         auto alloc = [&](size_t bytes, int fill) -> void * {
             void *p2 = nullptr;
             if (hipMalloc(&p2, bytes) != hipSuccess) return nullptr;
             (void)hipMemsetAsync(p2, fill, bytes, c->stream);
-            tmp_dev.push_back(p2);
+            S.tmp_dev.push_back(p2);
             return p2;
         };
         if (dbg_host->nn_idx) dd.nn_idx = (int32_t *)alloc(sizeof(int32_t) * 5 * n, 0xFF);
@@ -342,20 +349,20 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 8 * ((n + 63) / 64 + 4), 0);
     }
     const unsigned long long seq = ++c->seq;
-    FinArgs fin{c->d_tickets, c->d_out, seq};
-    if (fused) c->tickets_dirty = true;    // cleared again once this launch is known to have completed
+    FinArgs fin{S.d_tickets, S.d_out, seq};
+    if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
     // kernel timing: HIP events around every opt_time_kernels-th launch (each timed launch costs ~10 us of host time)
-    const bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
+    const bool timed = slot == 0 && c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
     if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
     if (dbg_host)
-        hipLaunchKernelGGL((k_linearize<1, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
+        hipLaunchKernelGGL((k_linearize<1, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd);
     else if (fused)
-        hipLaunchKernelGGL((k_linearize<0, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
+        hipLaunchKernelGGL((k_linearize<0, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd);
     else
-        hipLaunchKernelGGL((k_linearize<0, false>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_partials, nbx, fin, dd);
+        hipLaunchKernelGGL((k_linearize<0, false>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd);
     if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
-    if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, c->d_partials, nbx, c->d_out, seq);
+    if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
     if (dbg_host) {
         if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.nn_d2) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_d2, dd.nn_d2, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, c->stream));
@@ -366,27 +373,40 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         if (dd.stats) HIP_TRY(c, hipMemcpyAsync(dbg_host->stats, dd.stats, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
         if (dd.clocks) HIP_TRY(c, hipMemcpyAsync(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 8 * ((n + 63) / 64), hipMemcpyDeviceToHost, c->stream));
     }
-    if (dbg_host || !c->opt_spin) {
+    S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
+    S.seq = seq; S.sync = dbg_host != nullptr;
+    return DCREG_OK;
+}
+
+static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
+    if (!c) return DCREG_E_INVALID;
+    if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
+    LinSlot &S = c->slots[slot];
+    if (!S.pending) { c->fail("slot %d has no linearisation in flight", slot); return DCREG_E_STATE; }
+    if (!outs) { c->fail("null argument"); return DCREG_E_INVALID; }
+    S.pending = false;
+    if (S.sync || !c->opt_spin) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else {
         // hot path: spin on the sequence numbers the kernels publish into pinned host memory
-        for (size_t i = 0; i < n_rows; ++i) {
-            volatile unsigned long long *flag = (volatile unsigned long long *)(c->h_out + (size_t)i * kSlots + 31);
+        for (size_t i = 0; i < S.n_rows; ++i) {
+            volatile unsigned long long *flag = (volatile unsigned long long *)(S.h_out + i * kSlots + 31);
             uint64_t spins = 0;
-            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) {
                 __builtin_ia32_pause();
                 if (++spins > (1ull << 26)) {   // ~seconds: surface a device fault instead of hanging
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
                     break;
                 }
             }
         }
     }
-    c->tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
-    for (void *p2 : tmp_dev) (void)hipFree(p2);
-    if (dbg_host) HIP_TRY(c, hipGetLastError());
-    if (timed) {
+    S.tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
+    for (void *p2 : S.tmp_dev) (void)hipFree(p2);
+    S.tmp_dev.clear();
+    if (S.sync) HIP_TRY(c, hipGetLastError());
+    if (S.timed) {
         float ms = 0.f;
         hipError_t te = hipEventElapsedTime(&ms, c->ev0, c->ev1);
         if (te == hipErrorNotReady) { HIP_TRY(c, hipEventSynchronize(c->ev1)); te = hipEventElapsedTime(&ms, c->ev0, c->ev1); }
@@ -394,21 +414,31 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
         c->kernel_ms_total += ms; c->kernel_launches += 1;
     }
     double total[kSlots];
-    if (fused) {   // add the chunk rows in index order (fixed order: deterministic)
+    if (S.fused) {   // add the chunk rows in index order (fixed order: deterministic)
         for (int k = 0; k < 31; ++k) total[k] = 0.0;
-        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-            const double *row = c->h_out + (size_t)ch * kSlots;
+        for (uint32_t ch = 0; ch < S.n_chunks; ++ch) {
+            const double *row = S.h_out + (size_t)ch * kSlots;
             for (int k = 0; k < 31; ++k) total[k] += row[k];
         }
     }
-    for (int i = 0; i < n_poses; ++i) {
-        const double *o = fused ? total : c->h_out + (size_t)i * kSlots;
+    for (int i = 0; i < S.n_poses; ++i) {
+        const double *o = S.fused ? total : S.h_out + (size_t)i * kSlots;
         std::memcpy(outs[i].H_upper, o, 21 * sizeof(double));
         std::memcpy(outs[i].g, o + 21, 6 * sizeof(double));
         outs[i].sum_r2 = o[27]; outs[i].sum_b2 = o[28];
         outs[i].n_eff = (int64_t)std::llround(o[29]); outs[i].n_pt = (int64_t)std::llround(o[30]);
     }
     return DCREG_OK;
+}
+
+int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
+                     dcreg_lin_out *outs, dcreg_lin_debug *dbg_host) {
+    if (c && !outs) { c->fail("null argument"); return DCREG_E_INVALID; }
+    int rc = linearize_begin(c, 0, n_poses, R9, t3, p, dbg_host);
+    if (rc) return rc;
+    rc = linearize_end(c, 0, outs);
+    if (rc && c) c->slots[0].pending = false;
+    return rc;
 }
 
 // k-NN of arbitrary queries (host pointer) or of the transformed source cloud (q == nullptr)
@@ -481,10 +511,14 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
-                    c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_partials, c->d_poses, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_tickets};
+                    c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev};
     for (void *b : bufs) if (b) (void)hipFree(b);
-    if (c->h_out) (void)hipHostFree(c->h_out);
+    for (LinSlot &S : c->slots) {
+        for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
+        for (void *b : S.tmp_dev) (void)hipFree(b);
+        if (S.h_out) (void)hipHostFree(S.h_out);
+    }
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -531,6 +565,10 @@ int dcreg_linearize(dcreg_ctx *c, const double R[9], const double t[3], const dc
 int dcreg_linearize_batch(dcreg_ctx *c, int n, const double *R9, const double *t3, const dcreg_lin_params *p, dcreg_lin_out *outs) {
     return launch_linearize(c, n, R9, t3, p, outs, nullptr);
 }
+int dcreg_linearize_batch_begin(dcreg_ctx *c, int slot, int n, const double *R9, const double *t3, const dcreg_lin_params *p) {
+    return linearize_begin(c, slot, n, R9, t3, p, nullptr);
+}
+int dcreg_linearize_batch_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) { return linearize_end(c, slot, outs); }
 int dcreg_linearize_debug(dcreg_ctx *c, const double R[9], const double t[3], const dcreg_lin_params *p, dcreg_lin_out *out, dcreg_lin_debug *dbg) {
     return launch_linearize(c, 1, R, t, p, out, dbg);
 }

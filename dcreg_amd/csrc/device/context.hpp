@@ -13,6 +13,22 @@ struct dcreg_lin_params;
 struct dcreg_lin_out;
 struct dcreg_lin_debug;
 
+// buffers and in-flight state of one linearisation slot
+struct LinSlot {
+    double *d_partials = nullptr; size_t partials_cap = 0;
+    dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
+    std::vector<dcreg::PoseArg> h_poses;
+    double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped result rows
+    unsigned int *d_tickets = nullptr; size_t tickets_cap = 0;
+    bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
+    std::vector<void *> tmp_dev;   // debug dump buffers of the launch in flight
+    bool pending = false, fused = false, timed = false, sync = false;
+    int n_poses = 0;
+    uint32_t n_chunks = 0;
+    size_t n_rows = 0;
+    unsigned long long seq = 0;
+};
+
 struct dcreg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -54,13 +70,9 @@ struct dcreg_ctx {
     uint32_t *d_scratch = nullptr;
     char *sort_tmp = nullptr; size_t sort_tmp_cap = 0;
 
-    // linearisation
-    double *d_partials = nullptr; size_t partials_cap = 0;
-    unsigned int *d_tickets = nullptr; size_t tickets_cap = 0;
-    bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
-    dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
-    std::vector<dcreg::PoseArg> h_poses;
-    double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped
+    // linearisation: per-slot buffers (see linearize_begin / linearize_end)
+    static constexpr int kLinSlots = 2;
+    LinSlot slots[kLinSlots];
 
     // k-NN / p2p
     float4 *d_aligned = nullptr; size_t aligned_cap = 0;

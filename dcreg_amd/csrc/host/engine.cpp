@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -135,31 +137,51 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
     std::vector<double> R((size_t)n_trials * 9), t((size_t)n_trials * 3);
     std::memcpy(R.data(), R0, sizeof(double) * 9 * (size_t)n_trials);
     std::memcpy(t.data(), t0, sizeof(double) * 3 * (size_t)n_trials);
-    std::vector<int> live((size_t)n_trials);
-    for (int i = 0; i < n_trials; ++i) { live[(size_t)i] = i; std::memset(&results[i], 0, sizeof(results[i])); }
+    for (int i = 0; i < n_trials; ++i) std::memset(&results[i], 0, sizeof(results[i]));
     if (info.n_source <= 0 || info.n_target <= 0) {
         for (int i = 0; i < n_trials; ++i) results[i].status = 3;
         return DCREG_OK;
     }
-    std::vector<double> Rb, tb;
-    std::vector<dcreg_lin_out> outs;
-    for (int it = 0; it < cfg->max_iterations && !live.empty(); ++it) {
-        const int nl = (int)live.size();
-        Rb.resize((size_t)nl * 9); tb.resize((size_t)nl * 3); outs.resize((size_t)nl);
+    // The trials advance in lock-step, one batched launch per iteration and group.  With enough trials they are split into
+    // two groups that alternate on the device: while the kernels of one group run, the host takes steps 6-9 of the other
+    // (software pipeline over the two linearisation slots of the ctx), so the 6x6 solves cost no wall time.
+    struct Group { std::vector<int> live; std::vector<double> Rb, tb; std::vector<dcreg_lin_out> outs; int it = 0; bool in_flight = false; };
+    Group grp[2];
+    const int n_groups = n_trials >= 64 ? 2 : 1;
+    for (int i = 0; i < n_trials; ++i) grp[n_groups == 2 ? (i & 1) : 0].live.push_back(i);
+    double t_lin_ms = 0.0, t_host_ms = 0.0;
+    int n_steps = 0;
+    auto begin = [&](int gi) -> int {
+        Group &G = grp[gi];
+        if (G.live.empty() || G.it >= cfg->max_iterations) return DCREG_OK;
+        const int nl = (int)G.live.size();
+        G.Rb.resize((size_t)nl * 9); G.tb.resize((size_t)nl * 3); G.outs.resize((size_t)nl);
         for (int j = 0; j < nl; ++j) {
-            std::memcpy(&Rb[(size_t)j * 9], &R[(size_t)live[(size_t)j] * 9], sizeof(double) * 9);
-            std::memcpy(&tb[(size_t)j * 3], &t[(size_t)live[(size_t)j] * 3], sizeof(double) * 3);
+            std::memcpy(&G.Rb[(size_t)j * 9], &R[(size_t)G.live[(size_t)j] * 9], sizeof(double) * 9);
+            std::memcpy(&G.tb[(size_t)j * 3], &t[(size_t)G.live[(size_t)j] * 3], sizeof(double) * 3);
         }
-        const int rc = dcreg_linearize_batch(ctx, nl, Rb.data(), tb.data(), &prm, outs.data());
+        const int rc = dcreg_linearize_batch_begin(ctx, gi, nl, G.Rb.data(), G.tb.data(), &prm);
+        G.in_flight = rc == DCREG_OK;
+        return rc;
+    };
+    auto finish = [&](int gi) -> int {          // wait for the group's results, take the host steps, compact the live set
+        Group &G = grp[gi];
+        if (!G.in_flight) return DCREG_OK;
+        const auto t_a = Clock::now();
+        const int rc = dcreg_linearize_batch_end(ctx, gi, G.outs.data());
+        G.in_flight = false;
         if (rc != DCREG_OK) return rc;
+        t_lin_ms += ms_since(t_a);
+        const auto t_b = Clock::now();
+        const int nl = (int)G.live.size(), it = G.it;
         // host steps 6-9 of every live trial are independent: spread them over host threads
         std::vector<int> keep((size_t)nl, 0);
         const int nthreads = std::max(1, std::min({omp_get_max_threads(), 32, nl / 8}));
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int j = 0; j < nl; ++j) {
-            const int id = live[(size_t)j];
+            const int id = G.live[(size_t)j];
             dcreg_trial_result &tr = results[id];
-            const dcreg_lin_out &lo = outs[(size_t)j];
+            const dcreg_lin_out &lo = G.outs[(size_t)j];
             if (lo.n_eff < 10) { tr.iterations = it + 1; tr.status = 1; continue; }
             StepOut so;
             const int st = host_step(lo, detection, handling, *cfg, &R[(size_t)id * 9], &t[(size_t)id * 3], so);
@@ -175,10 +197,30 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
         }
         std::vector<int> next;
         next.reserve((size_t)nl);
-        for (int j = 0; j < nl; ++j) if (keep[(size_t)j]) next.push_back(live[(size_t)j]);
-        live.swap(next);
+        for (int j = 0; j < nl; ++j) if (keep[(size_t)j]) next.push_back(G.live[(size_t)j]);
+        G.live.swap(next);
+        ++G.it;
+        t_host_ms += ms_since(t_b);
+        ++n_steps;
+        return DCREG_OK;
+    };
+    auto has_work = [&](int gi) { return grp[gi].in_flight || (!grp[gi].live.empty() && grp[gi].it < cfg->max_iterations); };
+    int rc = begin(0);
+    while (rc == DCREG_OK && (has_work(0) || has_work(1))) {
+        if (!grp[1].in_flight && (rc = begin(1)) != DCREG_OK) break;   // queued behind group 0 (no-op for a single group)
+        if ((rc = finish(0)) != DCREG_OK) break;                       // host steps of group 0 overlap group 1's kernels
+        if (!grp[0].in_flight && (rc = begin(0)) != DCREG_OK) break;   // queued behind group 1
+        if ((rc = finish(1)) != DCREG_OK) break;                       // host steps of group 1 overlap group 0's kernels
+    }
+    if (rc != DCREG_OK) {                                            // drain whatever is still queued
+        for (int gi = 0; gi < 2; ++gi) if (grp[gi].in_flight) { grp[gi].outs.resize(grp[gi].live.size()); (void)dcreg_linearize_batch_end(ctx, gi, grp[gi].outs.data()); }
+        return rc;
     }
     const double total_ms = ms_since(t_total);
+    if (std::getenv("DCREG_TRIALS_TIMING"))
+        std::fprintf(stderr, "[dcreg_icp_run_trials] %d group steps: wait for results %.1f us/step, host %.1f us/step, wall %.1f us per lock-step iteration\n",
+                     n_steps, 1e3 * t_lin_ms / std::max(n_steps, 1), 1e3 * t_host_ms / std::max(n_steps, 1),
+                     1e3 * total_ms / std::max(std::max(grp[0].it, grp[1].it), 1));
     for (int i = 0; i < n_trials; ++i) {
         dcreg_trial_result &tr = results[i];
         dcreg::stateToMatrix(&R[(size_t)i * 9], &t[(size_t)i * 3], tr.final_transform);

@@ -134,6 +134,11 @@ int dcreg_linearize(dcreg_ctx *, const double R[9], const double t[3], const dcr
 /* the same for n_poses independent poses of the same cloud pair in ONE launch (Monte-Carlo trials) */
 int dcreg_linearize_batch(dcreg_ctx *, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *,
                           dcreg_lin_out *outs);
+/* asynchronous pair of the above: _begin queues the copy + kernels on the ctx's stream and returns, _end waits for the
+ * results of that slot (pinned-memory sequence numbers) and unpacks them.  Two slots (0, 1) with their own buffers: keep
+ * one batch on the device while the host solves the other (dcreg_icp_run_trials does).  R9 / t3 are copied by _begin. */
+int dcreg_linearize_batch_begin(dcreg_ctx *, int slot, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *);
+int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
 int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], const dcreg_lin_params *,
                           dcreg_lin_out *, dcreg_lin_debug *);
 /* exact k-NN (k = 1 or 5) of host queries against the target index; float sq. distances, (d2, idx) order */
