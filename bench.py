@@ -256,6 +256,9 @@ def main():
             t_conc = float(tm.item())
         conc = {"pairs_per_gpu": P, "value": n_gpus * P * args.steps / t_conc, "unit": "iterations/s",
                 "us_per_iteration_per_pair": 1e6 * t_conc / args.steps,
+                # device-level: algorithmic bytes of all P pairs' launches over the WALL time of the region (host steps included)
+                "achieved_GBps_wall": P * BYTES_PER_QUERY * n_pts * args.steps / t_conc / 1e9,
+                "frac_of_hbm_peak_wall": P * BYTES_PER_QUERY * n_pts * args.steps / t_conc / 1e9 / HBM_PEAK_GBS,
                 "note": "P independent %d-pt pairs in flight per GPU, one context + stream + host thread each; aggregate over all GPUs" % n_pts}
         for cq in ctxs[1:]:
             cq.close()
