@@ -117,7 +117,7 @@ EXPORTS = [
     "dcreg_linearize_batch_end", "dcreg_linearize_debug", "dcreg_knn",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
-    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
+    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
 ]
 
 _lib = None
@@ -173,6 +173,7 @@ def load():
                                 C.POINTER(IcpResult)]
     L.dcreg_icp_run_sharded.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.c_int64, REDUCE_FN, vp,
                                         C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult)]
+    L.dcreg_icp_run_many.argtypes = [C.c_int, C.POINTER(vp), dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IcpResult)]
     L.dcreg_icp_run_euler.argtypes = [vp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
                                       C.POINTER(IcpResult), dp]
     L.dcreg_icp_run_trials.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(TrialResult)]
@@ -261,6 +262,21 @@ def pose_error(gt, T):
     a, b = C.c_double(), C.c_double()
     load().dcreg_pose_error(_dp(_f64(gt, 16)), _dp(_f64(T, 16)), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def icp_run_many(contexts, T0s, method, cfg):
+    """dcreg_icp_run_many: independent scan pairs (one Context each) at once, one host thread per pair."""
+    n = len(contexts)
+    T0s = _f64(T0s).reshape(n, 4, 4)
+    R0 = np.ascontiguousarray(T0s[:, :3, :3]).reshape(n, 9)
+    t0 = np.ascontiguousarray(T0s[:, :3, 3]).reshape(n, 3)
+    det, hand = METHODS[method] if isinstance(method, str) else method
+    handles = (C.c_void_p * max(n, 1))(*[c._h for c in contexts])
+    res = (IcpResult * max(n, 1))()
+    rc = load().dcreg_icp_run_many(n, handles, _dp(R0), _dp(t0), DETECTION[det], HANDLING[hand], C.byref(cfg), res)
+    if rc:
+        raise DcregError("dcreg_icp_run_many rc=%d" % rc)
+    return [res[i] for i in range(n)]
 
 
 class Context:

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../../include/dcreg.h"
@@ -124,6 +125,22 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
 int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
                   const dcreg_config *cfg, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
     return dcreg_icp_run_sharded(ctx, R0, t0, detection, handling, cfg, 0, nullptr, nullptr, log, log_capacity, res);
+}
+
+int dcreg_icp_run_many(int n, dcreg_ctx *const *ctxs, const double *R0, const double *t0, int detection, int handling,
+                       const dcreg_config *cfg, dcreg_icp_result *results) {
+    if (n < 0 || (n > 0 && (!ctxs || !R0 || !t0 || !cfg || !results))) return DCREG_E_INVALID;
+    for (int i = 0; i < n; ++i) if (!ctxs[i]) return DCREG_E_INVALID;
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (ctxs[i] == ctxs[j]) return DCREG_E_INVALID;   // a ctx is single-threaded
+    std::vector<int> rc((size_t)std::max(n, 0), DCREG_OK);
+    std::vector<std::thread> th;
+    th.reserve((size_t)std::max(n - 1, 0));
+    auto body = [&](int i) { rc[(size_t)i] = dcreg_icp_run(ctxs[i], R0 + 9 * (size_t)i, t0 + 3 * (size_t)i, detection, handling, cfg, nullptr, 0, &results[i]); };
+    for (int i = 1; i < n; ++i) th.emplace_back(body, i);
+    if (n > 0) body(0);
+    for (auto &t_ : th) t_.join();
+    for (int i = 0; i < n; ++i) if (rc[(size_t)i] != DCREG_OK) return rc[(size_t)i];
+    return DCREG_OK;
 }
 
 int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const double *t0, int detection, int handling,

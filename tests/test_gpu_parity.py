@@ -367,3 +367,29 @@ def test_sharded_engine_plumbing(ctx, cyl):
         raise ValueError("exchange failed")
     with pytest.raises(ValueError):
         ctx.icp_run_sharded(T0, "ME-SR", cfg, len(pts), boom)
+
+
+def test_run_many_equals_individual_runs(cyl):
+    """dcreg_icp_run_many: independent pairs on their own contexts / streams / host threads give exactly the results of
+    running each pair alone."""
+    pts, _ = cyl
+    rng = np.random.default_rng(3)
+    ctxs, T0s = [], []
+    try:
+        for q in range(3):
+            c = api.Context(0)
+            src = (pts + rng.normal(0, 0.002, pts.shape)).astype(np.float32)
+            c.set_target(pts, 1.0); c.set_source(src)
+            ctxs.append(c)
+            T0s.append(h.pose6d_matrix(0.01 * (q + 1), 0.01, 0.01, 0.0, 0.0, 0.001 * q))
+        cfg = _cfg(True)
+        alone = [c.icp_run(T, "Ours", cfg)[0] for c, T in zip(ctxs, T0s)]
+        many = api.icp_run_many(ctxs, np.stack(T0s), "Ours", cfg)
+        for a, b in zip(alone, many):
+            assert (a.converged, a.iterations, a.status) == (b.converged, b.iterations, b.status)
+            assert a.R[:] == b.R[:] and a.t[:] == b.t[:]
+        with pytest.raises(api.DcregError):
+            api.icp_run_many([ctxs[0], ctxs[0]], np.stack(T0s[:2]), "Ours", cfg)     # a ctx is single-threaded
+    finally:
+        for c in ctxs:
+            c.close()
