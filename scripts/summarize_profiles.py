@@ -13,7 +13,7 @@ def short(name):
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
-      "Command: `python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload %s` under", 
+      "Command: `python bench.py --steps 200 --warmup 20 --no-cpu-baseline --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
       "`rocprofv3 --kernel-trace --stats` and separate `--pmc` passes (scripts/collect_profiles.sh).", ""]
 md[2] = md[2] % wl
 bp = os.path.join(src, "bench_plain.json")
