@@ -234,9 +234,11 @@ def main():
                 rc = L.dcreg_icp_run(cq._h, R0.ctypes.data_as(dp), t0.ctypes.data_as(dp), api.DETECTION[det], api.HANDLING[hand],
                                      C.byref(cfg_q), None, 0, C.byref(res_q))
                 if rc != 0 or res_q.iterations != n:
-                    raise RuntimeError("concurrent pair failed: rc=%d" % rc)
+                    pair_errors.append("concurrent pair failed: rc=%d iterations=%d %s" % (rc, res_q.iterations, L.dcreg_last_error(cq._h)))
+                    return
                 left -= n
 
+        pair_errors = []
         t_conc = None
         for k in (args.warmup, args.steps):
             barrier = threading.Barrier(P + 1)
@@ -250,6 +252,8 @@ def main():
                 t_.join()
             fence()
             t_conc = time.perf_counter() - ta
+        if pair_errors:
+            raise RuntimeError("; ".join(pair_errors))
         if dist is not None:
             tm = torch.tensor([t_conc], dtype=torch.float64, device="cuda")
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
