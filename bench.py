@@ -78,13 +78,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (control-flow check of the multi-rank path on a single-GPU box): several ranks on one device over gloo
+    backend = os.environ.get("DCREG_BENCH_BACKEND", "nccl")
+    if "DCREG_BENCH_LOCAL_RANK" in os.environ:
+        local_rank = int(os.environ["DCREG_BENCH_LOCAL_RANK"])
+    cdev = "cuda" if backend == "nccl" else "cpu"        # device of the (tiny) collective payloads
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
 
     import helpers as h
@@ -99,7 +107,7 @@ def main():
         from dcreg_amd import pointshard
         lo, hi = pointshard.slice_of(len(src), rank, world)
         src = np.ascontiguousarray(src[lo:hi])
-        reducer = pointshard.make_reducer(dist, "cuda")
+        reducer = pointshard.make_reducer(dist, cdev)
     ctx = dcreg_amd.Context(local_rank)
     for kv in args.opt:
         k, v = kv.split("=", 1)
@@ -201,7 +209,7 @@ def main():
     kern_ms, kern_n = ctx.kernel_time(reset=True)
     ctx.set_option("time_kernels", 0)
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -255,7 +263,7 @@ def main():
         if pair_errors:
             raise RuntimeError("; ".join(pair_errors))
         if dist is not None:
-            tm = torch.tensor([t_conc], dtype=torch.float64, device="cuda")
+            tm = torch.tensor([t_conc], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             t_conc = float(tm.item())
         conc = {"pairs_per_gpu": P, "value": n_gpus * P * args.steps / t_conc, "unit": "iterations/s",
@@ -271,7 +279,7 @@ def main():
     T_fin = np.eye(4); T_fin[:3, :3] = np.array(res.R[:]).reshape(3, 3); T_fin[:3, 3] = res.t[:]
     te, re_ = api.pose_error(np.eye(4), T_fin)
     last = ctx.linearize(T_fin[:3, :3], T_fin[:3, 3], prm)
-    rec = torch.tensor([te, re_, float(last["n_eff"]), kern_ms / max(kern_n, 1)], dtype=torch.float64, device="cuda")
+    rec = torch.tensor([te, re_, float(last["n_eff"]), kern_ms / max(kern_n, 1)], dtype=torch.float64, device=cdev)
     if dist is not None:
         allrec = [torch.zeros_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
