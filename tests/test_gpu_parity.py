@@ -393,3 +393,34 @@ def test_run_many_equals_individual_runs(cyl):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_duplicate_points_and_rank_deficient_neighbourhoods(ctx):
+    """Targets with exact duplicates: zero distances, distance ties resolved by index, and neighbour sets whose 5x3 system
+    is rank deficient - cold and warm searches, all bit-exact against the oracle in indices, distances and gate flags."""
+    base = h.scene_cylinder(24_000, seed=9, noise=0.0)
+    tgt = np.concatenate([base, base[::7], base[::13], base[:200], base[:200], base[:200], base[:200]]).astype(np.float32)
+    rng = np.random.default_rng(4)
+    tgt = np.ascontiguousarray(tgt[rng.permutation(len(tgt))])
+    src = np.concatenate([base[::4], base[:300] + np.float32(0.01)]).astype(np.float32)
+    tree = po.KdTree(tgt)
+    ctx.set_target(tgt, 1.0); ctx.set_source(src)
+    for T in (h.pose6d_matrix(0.0, 0.0, 0.0, 0.0, 0.0, 0.0), h.pose6d_matrix(0.02, -0.01, 0.01, 0.001, 0.0, 0.002),
+              h.pose6d_matrix(0.0, 0.0, 0.0, 0.0, 0.0, 0.0)):
+        gpu = ctx.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(1.0, 1), debug=True)
+        ref = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(1.0, 1), debug=True)
+        assert np.array_equal(gpu["flag"], ref["flag"])
+        ok = ref["flag"] != 0
+        assert np.array_equal(gpu["nn_idx"][ok], ref["nn_idx"][ok])
+        assert np.array_equal(gpu["nn_d2"][ok].view(np.uint32), ref["nn_d2"][ok].view(np.uint32))
+        assert gpu["n_eff"] == ref["n_eff"] and gpu["n_pt"] == ref["n_pt"]
+        # plane fits: wherever the five neighbours are five distinct points the fits agree to rounding; neighbourhoods with
+        # repeated points make the 5x3 system rank deficient, where the truncated-QR solution is decided by rounding noise in
+        # the trailing pivots (in the reference's Eigen build as much as here), so only the gates are compared there
+        passed = (ref["flag"] == 1) | (ref["flag"] == 4)
+        nbr = tgt[np.clip(ref["nn_idx"], 0, None)]
+        distinct = np.array([len({tuple(p) for p in row}) for row in nbr]) == 5
+        sel = passed & distinct
+        assert sel.sum() > 100 and (passed & ~distinct).sum() > 5
+        assert np.allclose(gpu["normal"][sel], ref["normal"][sel], rtol=0, atol=1e-7)
+        assert np.allclose(gpu["r"][sel], ref["r"][sel], rtol=0, atol=1e-7)
