@@ -4,7 +4,7 @@
 // Layout in HBM
 //   target : float4 {x,y,z,bits(orig_idx)} sorted by linear grid cell (x fastest) + cell_start[n_cells+1]
 //            -> the three x-adjacent cells of one (y,z) row are ONE contiguous run of points
-//   source : float4 {x,y,z,bits(orig_idx)} sorted by Morton code of the body-frame position, so the 64
+//   source : float4 {x,y,z,bits(orig_idx)} sorted by the Hilbert-curve key of the body-frame position, so the 64
 //            lanes of a wave walk neighbouring cells (a rigid pose keeps neighbours neighbours)
 //   partial: double[pose][block][32]  (21 H + 6 g + sum r^2 + sum b^2 + n_eff + n_pt + pad)
 // Arithmetic: k-NN distances float32, non-fused, summed x,y,z in that order (what FLANN's L2 functor does
@@ -609,7 +609,7 @@ __device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32], int l
 }
 
 // XCD-aware block remap: hardware places block b on XCD b%8; give each XCD a contiguous run of query
-// blocks so spatially adjacent (Morton-ordered) queries share that XCD's L2.  Bijective for any n.
+// blocks so spatially adjacent (Hilbert-ordered) queries share that XCD's L2.  Bijective for any n.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     const uint32_t nx = 8u;
     const uint32_t q = n / nx, r = n % nx, xcd = b % nx, k = b / nx;
@@ -982,7 +982,7 @@ __device__ __forceinline__ uint64_t spread21(uint64_t v) {
     return v;
 }
 // Hilbert-curve key (Skilling's transpose algorithm, 21 bits per axis).  Consecutive keys are always
-// spatial neighbours (no Z-order seams), which keeps the per-wave tile boxes tight.
+// spatial neighbours (no Z-order seams), which keeps the cells a wave touches close together.
 static __global__ void k_curve_keys(const float4 *__restrict__ p, int64_t n, double ox, double oy, double oz, double inv_q,
                                     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -97,7 +97,7 @@ typedef struct dcreg_lin_debug {
     double *r;       /* [n] */
     double *s;       /* [n] */
     uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 */
-    uint64_t *clocks; /* [8 * ceil(n/64)] per-wave shader-clock stamps: start, tile built, search done, rows done,
+    uint64_t *clocks; /* [8 * ceil(n/64)] per-wave shader-clock stamps: start, query ready, search done, rows done,
                          wave reduced, end, packed search sub-phases, hw block id */
 } dcreg_lin_debug;
 
