@@ -157,6 +157,25 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
     return DCREG_OK;
 }
 
+// empty-space distance field of the target grid (queries far from any point skip the rings they know are empty)
+static int build_gap_field(dcreg_ctx *c, double radius_hint) {
+    GridDev &g = c->grid;
+    g.gap = nullptr; g.gap_cap = 0;
+    if (!c->opt_gap_field) return DCREG_OK;
+    const int64_t n_cells = c->n_cells;
+    int rings = 1;                                            // rings that a search up to the radius can need
+    while (rings < 12 && (double)rings * g.h < (radius_hint > 0.0 ? radius_hint : 4.0 * g.h)) ++rings;
+    if (rings < 2) return DCREG_OK;                           // one ring covers the radius: nothing to skip
+    if (ensure(c, c->d_gap, c->gap_cap, (size_t)n_cells)) return DCREG_E_NOMEM;
+    hipLaunchKernelGGL(k_gap_init, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_cell_start, n_cells, c->d_gap);
+    for (int r = 1; r <= rings; ++r)
+        hipLaunchKernelGGL(k_gap_dilate, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_gap, g.nx, g.ny, g.nz, r);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    g.gap = c->d_gap; g.gap_cap = rings;
+    return DCREG_OK;
+}
+
 static GridDst target_dst(dcreg_ctx *c) {
     return GridDst{c->d_tgt_raw, c->n_tgt, &c->d_tgt, &c->tgt_cap, &c->d_cell_start, &c->cell_cap, &c->grid, &c->n_cells};
 }
@@ -196,6 +215,8 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     c->n_tgt = n;
     c->radius_hint = radius_hint;
     rc = build_index(c, target_dst(c), radius_hint, &c->occupied_cells);
+    if (rc) { c->n_tgt = 0; return rc; }
+    rc = build_gap_field(c, radius_hint);
     if (rc) { c->n_tgt = 0; return rc; }
     c->prev_valid = false;   // positions refer to the old sort order
     return DCREG_OK;
@@ -512,7 +533,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_gap};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -540,6 +561,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
     else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }

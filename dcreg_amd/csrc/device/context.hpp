@@ -88,6 +88,8 @@ struct dcreg_ctx {
     bool need_set_device = true;
     unsigned long long seq = 0;
     int opt_lds_pad = 0;
+    bool opt_gap_field = true;     // build the empty-space distance field of the target grid
+    uint8_t *d_gap = nullptr; size_t gap_cap = 0;
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;

@@ -26,6 +26,8 @@ struct GridDev {
     uint32_t n_pts;
     const uint32_t *cell_start;   // [nx*ny*nz + 1]
     const float4 *pts;            // sorted target
+    const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
+    int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
 };
 
 struct PoseArg { double R[9]; double t[3]; };
@@ -324,7 +326,13 @@ __device__ __forceinline__ void knn_shells(const GridDev &g, float qx, float qy,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
-    for (int k = 1; k < max_ring; ++k) {
+    // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
+    int k0 = 1;
+    if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
+        const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
+        k0 = max(1, f - 1);
+    }
+    for (int k = k0; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
         const double safe2 = safe * safe * (1.0 - 1e-6);
@@ -1023,6 +1031,35 @@ static __global__ void k_cell_start(const uint32_t *__restrict__ keys, int64_t n
     const int64_t hi = (i == n) ? n_cells : (int64_t)keys[i];
     for (int64_t c = lo; c <= hi; ++c) cell_start[c] = (uint32_t)i;
     if (i < n && (i == 0 || keys[i] != keys[i - 1])) atomicAdd(n_occupied, 1u);
+}
+
+// empty-space distance field of the target grid: gap[c] = 0 on occupied cells, then one dilation pass per ring.
+// In place: a pass only turns 255 into `ring`, and only looks for neighbours equal to ring - 1.
+static __global__ void k_gap_init(const uint32_t *__restrict__ cell_start, int64_t n_cells, uint8_t *__restrict__ gap) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cells) gap[c] = cell_start[c + 1] > cell_start[c] ? 0 : 255;
+}
+static __global__ void k_gap_dilate(uint8_t *gap, int nx, int ny, int nz, int ring) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_cells = (int64_t)nx * ny * nz;
+    if (c >= n_cells || gap[c] != 255) return;
+    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((int64_t)nx * ny));
+    const uint8_t want = (uint8_t)(ring - 1);
+    bool hit = false;
+    for (int dz = -1; dz <= 1 && !hit; ++dz) {
+        const int zz = z + dz;
+        if (zz < 0 || zz >= nz) continue;
+        for (int dy = -1; dy <= 1 && !hit; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= ny) continue;
+            const int64_t row = ((int64_t)zz * ny + yy) * nx;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx >= 0 && xx < nx && gap[row + xx] == want) { hit = true; break; }
+            }
+        }
+    }
+    if (hit) gap[c] = (uint8_t)ring;
 }
 
 // reductions for dcreg_p2p_error: sum sqrt(d2), sum d2 [dist<thr], count  (deterministic two-stage)

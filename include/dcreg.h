@@ -120,7 +120,8 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
 /* options: "cell" (force grid cell edge, 0 = auto), "cell_factor" (auto = factor * est. 5th-NN distance),
  * "time_kernels" (N > 0 = bracket every N-th linearisation with HIP events, 0 = off), "spin" (1 = wait on the pinned
  * result flag instead of hipStreamSynchronize, default), "warm_start" (1 = bound each search by the previous neighbour
- * set, default; results are identical either way), "lds_pad" (extra dynamic LDS bytes per block, occupancy experiments) */
+ * set, default; results are identical either way), "gap_field" (1 = build the empty-space distance field at the next
+ * dcreg_set_target, default; results are identical either way), "lds_pad" (extra dynamic LDS bytes per block, occupancy experiments) */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
  * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */

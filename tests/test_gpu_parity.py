@@ -424,3 +424,29 @@ def test_duplicate_points_and_rank_deficient_neighbourhoods(ctx):
         assert sel.sum() > 100 and (passed & ~distinct).sum() > 5
         assert np.allclose(gpu["normal"][sel], ref["normal"][sel], rtol=0, atol=1e-7)
         assert np.allclose(gpu["r"][sel], ref["r"][sel], rtol=0, atol=1e-7)
+
+
+def test_empty_space_skip_is_exact(ctx):
+    """Queries in the empty space between two clusters: the distance field lets them skip the rings it knows are empty;
+    results must equal the plain ring walk and the oracle (bounded and unbounded searches)."""
+    rng = np.random.default_rng(8)
+    a = rng.uniform(0, 2, (4000, 3)); b = rng.uniform(0, 2, (4000, 3)) + np.array([9.0, 0.5, 0.0])
+    tgt = np.concatenate([a, b]).astype(np.float32)
+    q = np.concatenate([rng.uniform(2, 9, (1500, 3)) * np.array([1, 0.3, 0.3]), rng.uniform(-4, 14, (500, 3)), tgt[:100] + 0.01]).astype(np.float32)
+    tree = po.KdTree(tgt)
+    oi, od = tree.knn(q, k=5)
+    got = {}
+    try:
+        for opt in (1, 0):
+            ctx.set_option("gap_field", opt)
+            ctx.set_target(tgt, 3.0)                      # radius 3 m: up to a dozen rings of ~0.25 m cells
+            got[opt] = (ctx.knn(q, k=5, max_radius=0.0), ctx.knn(q, k=5, max_radius=3.0), ctx.index_info().cell)
+    finally:
+        ctx.set_option("gap_field", 1)
+    for opt in (1, 0):
+        (gi, gd), (bi, bd), cell = got[opt]
+        assert cell < 1.0
+        assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+        inside = od < np.float32(9.0)
+        assert np.array_equal(bi[inside], oi[inside])
+    assert np.array_equal(got[0][1][0], got[1][1][0])
