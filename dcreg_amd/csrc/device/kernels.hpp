@@ -177,13 +177,10 @@ __device__ __forceinline__ void body_to_global(const PoseArg &P, double px, doub
     qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
 }
 
+// one run of the ring walk: four candidates per trip, their loads issued together (slots past the end are clamped
+// loads that push +inf)
 template <class H>
-__device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
-    for (uint32_t p = s; p < e; ++p) {
-        const float4 c = g.pts[p];
-        hp.push(dist2_nofma(qx, qy, qz, c), __float_as_uint(c.w), p);
-    }
-}
+__device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp);
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -204,6 +201,18 @@ template <class H>
 __device__ __forceinline__ void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p, bool valid) {
     const float d2 = dist2_nofma(qx, qy, qz, c);
     hp.push(valid ? d2 : __builtin_inff(), __float_as_uint(c.w), p, valid);     // padding slots can never enter
+}
+
+template <class H>
+__device__ __forceinline__ void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
+    for (uint32_t p = s; p < e; p += 4) {
+        const uint32_t last = e - 1;
+        float4 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = g.pts[min(p + u, last)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) push_point<H>(hp, qx, qy, qz, c[u], p + u, p + u < e);
+    }
 }
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
