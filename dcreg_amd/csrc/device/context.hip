@@ -238,10 +238,14 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
         ensure(c, c->d_src, c->src_cap, (size_t)n))
         return DCREG_E_NOMEM;
-    hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
-    rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
+    if (c->opt_keep_source_order) {      // experiments: the caller supplies the processing order
+        HIP_TRY(c, hipMemcpyAsync(c->d_src, c->d_src_raw, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
+        rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
@@ -561,6 +565,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
     else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)

@@ -90,6 +90,7 @@ struct dcreg_ctx {
     int opt_lds_pad = 0;
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
+    bool opt_keep_source_order = false;   // experiments only
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
