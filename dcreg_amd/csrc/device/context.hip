@@ -60,7 +60,7 @@ static int sort_pairs_u64(dcreg_ctx *c, uint64_t *keys_in, uint64_t *keys_out, u
 static int device_bounds(dcreg_ctx *c, const float4 *pts, int64_t n, double mn[3], double mx[3]) {
     uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     HIP_TRY(c, hipMemcpyAsync(c->d_scratch, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    const unsigned nb = std::min<unsigned>(blocks_for(n, 256), 2048);
+    const unsigned nb = std::min<unsigned>(blocks_for(n, 256), 256);      // grid-stride: one block per CU is plenty
     hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, c->stream, pts, n, c->d_scratch);
     uint32_t out[6];
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, sizeof(out), hipMemcpyDeviceToHost, c->stream));

@@ -972,9 +972,19 @@ static __global__ void k_bounds(const float4 *__restrict__ p, int64_t n, uint32_
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
     }
+    // block level first: 6 atomics per block instead of per wave (the 6 target words serialise them)
+    __shared__ float smn[4][3], smx[4][3];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&bounds[a], f2ord(mn[a])); atomicMax(&bounds[3 + a], f2ord(mx[a])); }
+        for (int a = 0; a < 3; ++a) { smn[wave][a] = mn[a]; smx[wave][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = smn[0][a], hi = smx[0][a];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, smn[w][a]); hi = fmaxf(hi, smx[w][a]); }
+        atomicMin(&bounds[a], f2ord(lo)); atomicMax(&bounds[3 + a], f2ord(hi));
     }
 }
 
