@@ -218,7 +218,7 @@ def main():
     # host step, so independent pairs interleave almost for free
     conc = None
     P = args.concurrent_pairs
-    if P > 1 and not mc and not by_points:
+    if P > 1 and not mc and not by_points and n_gpus == 1:     # (single-GPU runs only, like the CPU baseline: it needs P host threads)
         import threading
         ctxs = [ctx]
         for q in range(1, P):
