@@ -450,3 +450,24 @@ def test_empty_space_skip_is_exact(ctx):
         inside = od < np.float32(9.0)
         assert np.array_equal(bi[inside], oi[inside])
     assert np.array_equal(got[0][1][0], got[1][1][0])
+
+
+@pytest.mark.parametrize("method,n_iter", [("Ours", 1500), ("ME-SR", 300), ("ME-TSVD", 300), ("ME-TReg", 300), ("FCN-SR", 300)])
+def test_fig8_long_trace_through_the_hip_path(ctx, cyl, method, n_iter):
+    """icp_iter.yaml (max_iterations 5000, vanishing thresholds): the committed per-iteration history of the reference,
+    reproduced through dcreg_icp_run - correspondence count exact on every one of the 1500 / 300 iterations (each is a
+    warm-started search whose bound comes from the iteration before), errors and rmse to the printed precision."""
+    import os
+    pts, _ = cyl
+    ctx.set_target(pts, 1.0); ctx.set_source(pts)
+    cfg = _cfg(True, max_iterations=n_iter, CONVERGENCE_THRESH_TRANS=1e-12, CONVERGENCE_THRESH_ROT=1e-14)
+    res, logs = ctx.icp_run(h.pose6d_matrix(**h.PAPER_INIT), method, cfg)
+    rows = [r for r in h.read_csv_rows(os.path.join(h.GOLDEN, "fig8", "iteration_history.csv.gz")) if r["Method"] == method][:n_iter]
+    assert len(logs) == n_iter == len(rows)
+    mism = 0
+    for L, r in zip(logs, rows):
+        mism += int(L.effective_points != int(r["CorrNum"]))
+        assert abs(L.trans_error_vs_gt - float(r["TransError"])) < 2e-6
+        assert abs(L.rot_error_vs_gt - float(r["RotError"])) < 2e-5
+        assert abs(L.rmse - float(r["RMSE"])) < 2e-6
+    assert mism == 0
