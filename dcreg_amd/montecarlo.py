@@ -113,3 +113,92 @@ def run_montecarlo(run_trials, base_pose, n_trials, seed, trans_amp, rot_amp_rad
     local = np.stack(recs) if recs else np.zeros((0, REC))
     allr = gather_records(local, n_trials, dist, device)
     return allr, method_statistics(allr)
+
+
+def main(argv=None):
+    """The Monte-Carlo experiment end to end (BASELINE config 5): `python -m dcreg_amd.montecarlo --trials 5000` on one GPU, or
+    `python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m dcreg_amd.montecarlo --trials 5000`
+    (one rank per GPU, trials k = rank mod world, one RCCL all_gather of the trial records at the end)."""
+    import argparse, json, os, time
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--cloud", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cylinder_7562.pcd"),
+                    help="PCD (binary or ascii, float32 x y z ...) used as source AND target, like the reference's simulated experiment")
+    ap.add_argument("--trials", type=int, default=5000)
+    ap.add_argument("--methods", default="Ours,ME-SR,ME-TSVD,ME-TReg,FCN-SR")
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--trans-amp", type=float, default=0.5, help="uniform perturbation amplitude per translation DoF [m]")
+    ap.add_argument("--rot-amp-deg", type=float, default=2.0)
+    ap.add_argument("--base", default="0.2,0.8,0.5,0.1,0.1,2.0", help="base initial pose x,y,z [m], roll,pitch,yaw [deg] (paper run)")
+    ap.add_argument("--radius", type=float, default=1.0)
+    ap.add_argument("--max-iterations", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--out", default=None, help="write {method: statistics} as JSON (rank 0)")
+    a = ap.parse_args(argv)
+
+    import torch
+    from . import api, Context
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pts = _read_pcd_xyz(a.cloud)
+    ctx = Context(local)
+    ctx.set_target(pts, a.radius); ctx.set_source(pts)
+    b = [float(v) for v in a.base.split(",")]
+    base = (b[0], b[1], b[2], np.deg2rad(b[3]), np.deg2rad(b[4]), np.deg2rad(b[5]))
+    cfg = api.default_config(search_radius=a.radius, max_iterations=a.max_iterations, CONVERGENCE_THRESH_TRANS=1e-3, CONVERGENCE_THRESH_ROT=1e-5,
+                             KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, DEGENERACY_THRES_COND=10.0, DEGENERACY_THRES_EIG=120.0,
+                             use_weight_derivative=1, always_compute_schur=1)
+    out = {}
+    for method in a.methods.split(","):
+        t0 = time.perf_counter()
+        recs, stats = run_montecarlo(lambda T0s: ctx.icp_run_trials(T0s, method, cfg), base, a.trials, a.seed, a.trans_amp,
+                                     np.deg2rad(a.rot_amp_deg), rank=rank, world=world, dist=dist, device="cuda" if world > 1 else "cpu",
+                                     batch=a.batch)
+        el = time.perf_counter() - t0
+        stats["wall_s"] = el
+        stats["icp_iterations_per_s"] = float(recs[:, R_ITERS].sum()) / el
+        out[method] = stats
+        if rank == 0:
+            print("%-8s %d trials on %d GPU(s): success %.1f %%, trans %.4f +- %.4f m, rot %.4f +- %.4f deg, %.1f iterations/trial, %.2f s (%.0f ICP iterations/s)" % (
+                method, a.trials, world, 100 * stats["success_rate"], stats["mean_trans_error"], stats["std_trans_error"], stats["mean_rot_error"],
+                stats["std_rot_error"], stats["mean_iterations"], el, stats["icp_iterations_per_s"]), flush=True)
+    if rank == 0 and a.out:
+        with open(a.out, "w") as f:
+            json.dump(out, f, indent=1)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def _read_pcd_xyz(path):
+    """Minimal PCD v0.7 reader (binary / ascii, 4-byte fields) -> float32 [n, 3]."""
+    with open(path, "rb") as f:
+        fields, sizes, counts, n, kind = [], [], [], 0, None
+        while True:
+            line = f.readline().decode("ascii", "replace").strip()
+            if line.startswith("FIELDS"): fields = line.split()[1:]
+            elif line.startswith("SIZE"): sizes = [int(v) for v in line.split()[1:]]
+            elif line.startswith("COUNT"): counts = [int(v) for v in line.split()[1:]]
+            elif line.startswith("POINTS"): n = int(line.split()[1])
+            elif line.startswith("DATA"):
+                kind = line.split()[1]
+                break
+        counts = counts or [1] * len(fields)
+        if kind == "ascii":
+            arr = np.loadtxt(f, dtype=np.float64).reshape(n, -1)
+            return np.ascontiguousarray(arr[:, [fields.index(c) for c in "xyz"]], dtype=np.float32)
+        if kind != "binary" or any(s != 4 for s in sizes):
+            raise ValueError("unsupported PCD layout in %s" % path)
+        width = sum(counts)
+        raw = np.frombuffer(f.read(n * width * 4), dtype=np.float32).reshape(n, width)
+        off = np.cumsum([0] + counts)
+        return np.ascontiguousarray(raw[:, [off[fields.index(c)] for c in "xyz"]])
+
+
+if __name__ == "__main__":
+    main()
