@@ -471,3 +471,12 @@ def test_fig8_long_trace_through_the_hip_path(ctx, cyl, method, n_iter):
         assert abs(L.rot_error_vs_gt - float(r["RotError"])) < 2e-5
         assert abs(L.rmse - float(r["RMSE"])) < 2e-6
     assert mism == 0
+
+
+def test_montecarlo_cli_runs_and_is_seeded():
+    from dcreg_amd import montecarlo as mc
+    a = mc.main(["--trials", "48", "--methods", "Ours,ME-SR", "--batch", "32"])
+    b = mc.main(["--trials", "48", "--methods", "Ours", "--batch", "17"])       # batching must not change a trial
+    assert a["Ours"]["total_runs"] == 48 and 0.0 <= a["ME-SR"]["success_rate"] <= 1.0
+    for k in ("success_rate", "mean_trans_error", "mean_rot_error", "mean_iterations"):
+        assert a["Ours"][k] == b["Ours"][k]
