@@ -121,7 +121,8 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  * "time_kernels" (N > 0 = bracket every N-th linearisation with HIP events, 0 = off), "spin" (1 = wait on the pinned
  * result flag instead of hipStreamSynchronize, default), "warm_start" (1 = bound each search by the previous neighbour
  * set, default; results are identical either way), "gap_field" (1 = build the empty-space distance field at the next
- * dcreg_set_target, default; results are identical either way), "lds_pad" (extra dynamic LDS bytes per block, occupancy experiments) */
+ * dcreg_set_target, default; results are identical either way); experiment knobs: "lds_pad" (extra dynamic LDS bytes per
+ * block), "keep_source_order" (1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert sort) */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
  * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */
