@@ -47,11 +47,32 @@ inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const
     return (dr < cfg.CONVERGENCE_THRESH_ROT && dt < cfg.CONVERGENCE_THRESH_TRANS) ? 1 : 0;   // :1998
 }
 
+// eigenvalue clamp of a symmetric 6x6 (:2020-2029): only when the smallest eigenvalue is <= 1e-12 (or `always`), to 1e-9
+inline void clamp_psd6(dcreg::Mat6 &M, bool always) {
+    dcreg::Mat6 Ms;                                                             // SelfAdjointEigenSolver reads one triangle
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ms.v[i * 6 + j] = 0.5 * (M.v[i * 6 + j] + M.v[j * 6 + i]);
+    dcreg::Vec<6> w; dcreg::Mat6 V;
+    const bool ok = dcreg::symEig<6>(Ms, w, V);
+    double mn = w[0];
+    for (double x : w) mn = std::min(mn, x);
+    if (!always && ok && mn > 1e-12) return;
+    for (double &x : w) x = std::max(x, 1e-9);
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+        double s2 = 0.0;
+        for (int k = 0; k < 6; ++k) s2 += V.v[i * 6 + k] * w[k] * V.v[j * 6 + k];
+        M.v[i * 6 + j] = s2;
+    }
+}
+
 inline void covariance_of(bool converged, const double Hlast[36], double cov[36]) {   // :2014-2037
     for (int i = 0; i < 36; ++i) cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
     if (!converged) return;
     double inv[36];
-    if (dcreg::invertSpd6(Hlast, inv)) std::memcpy(cov, inv, sizeof(inv));
+    if (!dcreg::invertSpd6(Hlast, inv)) return;
+    dcreg::Mat6 C;
+    std::memcpy(C.v, inv, sizeof(inv));
+    clamp_psd6(C, false);
+    std::memcpy(cov, C.v, sizeof(C.v));
 }
 
 }  // namespace
@@ -323,22 +344,8 @@ int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, i
     double inv[36];
     if (res->converged && dcreg::invertSpd6(Hlast, inv)) {
         using dcreg::Mat6; using dcreg::Vec;
-        auto clamp_psd = [](Mat6 &M, bool always) {
-            Mat6 Ms;                                                             // symmetrise (SelfAdjointEigenSolver reads one triangle)
-            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ms.v[i * 6 + j] = 0.5 * (M.v[i * 6 + j] + M.v[j * 6 + i]);
-            Vec<6> w; Mat6 V;
-            const bool ok = dcreg::symEig<6>(Ms, w, V);
-            double mn = w[0]; for (double x : w) mn = std::min(mn, x);
-            if (!always && ok && mn > 1e-12) return;
-            for (double &x : w) x = std::max(x, 1e-9);
-            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
-                double s2 = 0.0;
-                for (int k = 0; k < 6; ++k) s2 += V.v[i * 6 + k] * w[k] * V.v[j * 6 + k];
-                M.v[i * 6 + j] = s2;
-            }
-        };
         Mat6 C; std::memcpy(C.v, inv, sizeof(inv));
-        clamp_psd(C, false);
+        clamp_psd6(C, false);
         // computeEulerToLieJacobian, math_utils.hpp:125-136
         const double cr = std::cos(pose[0]), sr = std::sin(pose[0]), cp = std::cos(pose[1]), sp = std::sin(pose[1]);
         dcreg::Mat3 Jl; for (double &x : Jl.v) x = 0.0;
@@ -352,7 +359,7 @@ int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, i
         Mat6 J; for (double &x : J.v) x = 0.0;
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) J.v[i * 6 + j] = Jl.v[i * 3 + j]; J.v[(i + 3) * 6 + i + 3] = 1.0; }
         Mat6 Cl = dcreg::mul(dcreg::mul(J, C), dcreg::transpose(J));
-        clamp_psd(Cl, true);
+        clamp_psd6(Cl, true);
         std::memcpy(res->icp_cov, Cl.v, sizeof(Cl.v));
     }
     res->time_ms = ms_since(t_total);
