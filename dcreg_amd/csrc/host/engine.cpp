@@ -50,7 +50,7 @@ inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const
 // eigenvalue clamp of a symmetric 6x6 (:2020-2029): only when the smallest eigenvalue is <= 1e-12 (or `always`), to 1e-9
 inline void clamp_psd6(dcreg::Mat6 &M, bool always) {
     dcreg::Mat6 Ms;                                                             // SelfAdjointEigenSolver reads one triangle
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ms.v[i * 6 + j] = 0.5 * (M.v[i * 6 + j] + M.v[j * 6 + i]);
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ms.v[i * 6 + j] = M.v[(i > j ? i : j) * 6 + (i > j ? j : i)];   // lower triangle
     dcreg::Vec<6> w; dcreg::Mat6 V;
     const bool ok = dcreg::symEig<6>(Ms, w, V);
     double mn = w[0];

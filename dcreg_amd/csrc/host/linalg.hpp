@@ -256,39 +256,42 @@ inline int colPivHouseholderQrSolve(const Mat<M, N> &A, const Vec<M> &b, Vec<N> 
     return nonzeroPivots;
 }
 
-// ---- Eigen::FullPivLU<Matrix3d>: isInvertible() + inverse()
-inline bool fullPivLuInverse3(const Mat3 &A, Mat3 &inv) {
-    Mat3 lu = A;
-    int rowOf[3] = {0, 1, 2}, colOf[3] = {0, 1, 2};
-    double pivots[3] = {0, 0, 0}, maxPivot = 0.0;
-    for (int k = 0; k < 3; ++k) {
+// ---- Eigen::FullPivLU<MatrixNd>: isInvertible() + inverse()  (3x3 Schur blocks :2422-2445, 6x6 covariance :2016-2018)
+template <int N>
+inline bool fullPivLuInverse(const Mat<N, N> &A, Mat<N, N> &inv) {
+    Mat<N, N> lu = A;
+    int rowOf[N], colOf[N];
+    double pivots[N], maxPivot = 0.0;
+    for (int i = 0; i < N; ++i) { rowOf[i] = colOf[i] = i; pivots[i] = 0.0; }
+    for (int k = 0; k < N; ++k) {
         int pr = k, pc = k; double best = -1.0;
-        for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j)
+        for (int i = k; i < N; ++i) for (int j = k; j < N; ++j)
             if (std::fabs(lu(i, j)) > best) { best = std::fabs(lu(i, j)); pr = i; pc = j; }
         if (best == 0.0) return false;
         maxPivot = std::max(maxPivot, best);
-        if (pr != k) { for (int j = 0; j < 3; ++j) std::swap(lu(k, j), lu(pr, j)); std::swap(rowOf[k], rowOf[pr]); }
-        if (pc != k) { for (int i = 0; i < 3; ++i) std::swap(lu(i, k), lu(i, pc)); std::swap(colOf[k], colOf[pc]); }
+        if (pr != k) { for (int j = 0; j < N; ++j) std::swap(lu(k, j), lu(pr, j)); std::swap(rowOf[k], rowOf[pr]); }
+        if (pc != k) { for (int i = 0; i < N; ++i) std::swap(lu(i, k), lu(i, pc)); std::swap(colOf[k], colOf[pc]); }
         pivots[k] = lu(k, k);
-        for (int i = k + 1; i < 3; ++i) {
+        for (int i = k + 1; i < N; ++i) {
             lu(i, k) /= lu(k, k);
-            for (int j = k + 1; j < 3; ++j) lu(i, j) -= lu(i, k) * lu(k, j);
+            for (int j = k + 1; j < N; ++j) lu(i, j) -= lu(i, k) * lu(k, j);
         }
     }
-    const double thr = DBL_EPSILON * 3.0 * maxPivot;   // FullPivLU::threshold() * |maxpivot|
+    const double thr = DBL_EPSILON * double(N) * maxPivot;   // FullPivLU::threshold() * |maxpivot|
     for (double p : pivots) if (!(std::fabs(p) > thr)) return false;
-    for (int col = 0; col < 3; ++col) {
-        double y[3], z[3];
-        for (int i = 0; i < 3; ++i) y[i] = rowOf[i] == col ? 1.0 : 0.0;
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) y[i] -= lu(i, j) * y[j];
-        for (int i = 2; i >= 0; --i) {
+    for (int col = 0; col < N; ++col) {
+        double y[N], z[N];
+        for (int i = 0; i < N; ++i) y[i] = rowOf[i] == col ? 1.0 : 0.0;
+        for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) y[i] -= lu(i, j) * y[j];
+        for (int i = N - 1; i >= 0; --i) {
             double s = y[i];
-            for (int j = i + 1; j < 3; ++j) s -= lu(i, j) * z[j];
+            for (int j = i + 1; j < N; ++j) s -= lu(i, j) * z[j];
             z[i] = s / lu(i, i);
         }
-        for (int i = 0; i < 3; ++i) inv(colOf[i], col) = z[i];
+        for (int i = 0; i < N; ++i) inv(colOf[i], col) = z[i];
     }
     return true;
 }
+inline bool fullPivLuInverse3(const Mat3 &A, Mat3 &inv) { return fullPivLuInverse<3>(A, inv); }
 
 }  // namespace dcreg

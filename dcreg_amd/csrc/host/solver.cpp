@@ -271,14 +271,11 @@ void solveDegenerateSystem(const double H[36], const double g[6], int handling, 
     const Vec<6> xv = solve(toMat6(H), gv, handling, cfg, an);
     std::memcpy(x, xv.data(), sizeof(double) * 6);
 }
-bool invertSpd6(const double H[36], double inv[36]) {   // covariance, icp_test_runner.cpp:2014-2019
+bool invertSpd6(const double H[36], double inv[36]) {   // covariance: FullPivLU::isInvertible() + inverse(), icp_test_runner.cpp:2016-2018
     const Mat6 A = toMat6(H);
-    for (int c = 0; c < 6; ++c) {
-        Vec<6> e{}; e.fill(0.0); e[c] = 1.0;
-        Vec<6> col;
-        if (colPivHouseholderQrSolve<6, 6>(A, e, col) < 6) return false;
-        for (int r = 0; r < 6; ++r) inv[r * 6 + c] = col[r];
-    }
+    Mat6 I;
+    if (!fullPivLuInverse<6>(A, I)) return false;
+    std::memcpy(inv, I.v, sizeof(I.v));
     return true;
 }
 

@@ -345,45 +345,47 @@ void orc_sym_eig(int n, const double *Ain, double *w, double *Vout) {
     }
 }
 
-/* Eigen::FullPivLU<Matrix3d>::isInvertible()/inverse() (icp_test_runner.cpp:2422-2445).
- * rank counts pivots with |p| > eps*3*|maxpivot| (FullPivLU::threshold()). */
-int orc_inv3_fullpiv(const double *Ain, double *Ainv) {
-    double lu[3][3];
-    int rp[3] = {0, 1, 2}, cp[3] = {0, 1, 2};
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lu[i][j] = Ain[i * 3 + j];
-    double maxpivot = 0.0, piv[3] = {0, 0, 0};
-    int nonzero = 3;
-    for (int k = 0; k < 3; ++k) {
+/* Eigen::FullPivLU<MatrixNd>::isInvertible()/inverse() (icp_test_runner.cpp:2422-2445 for the 3x3 Schur blocks,
+ * :2016-2018 for the 6x6 covariance).  rank counts pivots with |p| > eps*n*|maxpivot| (FullPivLU::threshold()). */
+int orc_inv_fullpiv(int n, const double *Ain, double *Ainv) {
+    double lu[6][6];
+    int rp[6] = {0, 1, 2, 3, 4, 5}, cp[6] = {0, 1, 2, 3, 4, 5};
+    if (n < 1 || n > 6) return 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) lu[i][j] = Ain[i * n + j];
+    double maxpivot = 0.0, piv[6] = {0, 0, 0, 0, 0, 0};
+    int nonzero = n;
+    for (int k = 0; k < n; ++k) {
         int bi = k, bj = k; double best = -1.0;
-        for (int i = k; i < 3; ++i) for (int j = k; j < 3; ++j)
+        for (int i = k; i < n; ++i) for (int j = k; j < n; ++j)
             if (fabs(lu[i][j]) > best) { best = fabs(lu[i][j]); bi = i; bj = j; }
         if (best == 0.0) { nonzero = k; break; }
         if (best > maxpivot) maxpivot = best;
-        if (bi != k) { for (int j = 0; j < 3; ++j) { double t = lu[k][j]; lu[k][j] = lu[bi][j]; lu[bi][j] = t; } int t = rp[k]; rp[k] = rp[bi]; rp[bi] = t; }
-        if (bj != k) { for (int i = 0; i < 3; ++i) { double t = lu[i][k]; lu[i][k] = lu[i][bj]; lu[i][bj] = t; } int t = cp[k]; cp[k] = cp[bj]; cp[bj] = t; }
+        if (bi != k) { for (int j = 0; j < n; ++j) { double t = lu[k][j]; lu[k][j] = lu[bi][j]; lu[bi][j] = t; } int t = rp[k]; rp[k] = rp[bi]; rp[bi] = t; }
+        if (bj != k) { for (int i = 0; i < n; ++i) { double t = lu[i][k]; lu[i][k] = lu[i][bj]; lu[i][bj] = t; } int t = cp[k]; cp[k] = cp[bj]; cp[bj] = t; }
         piv[k] = lu[k][k];
-        for (int i = k + 1; i < 3; ++i) {
+        for (int i = k + 1; i < n; ++i) {
             lu[i][k] /= lu[k][k];
-            for (int j = k + 1; j < 3; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+            for (int j = k + 1; j < n; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
         }
     }
-    if (nonzero < 3) return 0;
-    double thr = DBL_EPSILON * 3.0 * maxpivot;
-    for (int k = 0; k < 3; ++k) if (!(fabs(piv[k]) > thr)) return 0;
+    if (nonzero < n) return 0;
+    double thr = DBL_EPSILON * (double)n * maxpivot;
+    for (int k = 0; k < n; ++k) if (!(fabs(piv[k]) > thr)) return 0;
     /* solve A X = I :  P A Q = L U  =>  A^-1 = Q U^-1 L^-1 P */
-    for (int col = 0; col < 3; ++col) {
-        double y[3], z[3];
-        for (int i = 0; i < 3; ++i) y[i] = (rp[i] == col) ? 1.0 : 0.0;
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) y[i] -= lu[i][j] * y[j];
-        for (int i = 2; i >= 0; --i) {
+    for (int col = 0; col < n; ++col) {
+        double y[6], z[6];
+        for (int i = 0; i < n; ++i) y[i] = (rp[i] == col) ? 1.0 : 0.0;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= lu[i][j] * y[j];
+        for (int i = n - 1; i >= 0; --i) {
             double s = y[i];
-            for (int j = i + 1; j < 3; ++j) s -= lu[i][j] * z[j];
+            for (int j = i + 1; j < n; ++j) s -= lu[i][j] * z[j];
             z[i] = s / lu[i][i];
         }
-        for (int i = 0; i < 3; ++i) Ainv[cp[i] * 3 + col] = z[i];
+        for (int i = 0; i < n; ++i) Ainv[cp[i] * n + col] = z[i];
     }
     return 1;
 }
+int orc_inv3_fullpiv(const double *Ain, double *Ainv) { return orc_inv_fullpiv(3, Ain, Ainv); }
 
 /* ============================================================================================
  * Hot path: one linearisation (icp_test_runner.cpp:1704-1919), SURVEY Appendix A steps 1-8.
@@ -883,17 +885,27 @@ int orc_icp_run(const orc_kdtree *tree, const float *src, int64_t n_src, int64_t
     }
     memcpy(res->R, R, sizeof(R)); memcpy(res->t, t, sizeof(t));
 cov:
-    /* :2014-2037 covariance = H_last^-1 if converged, else 1e6 I (PSD clamp omitted: SPD inverse is SPD) */
+    /* :2014-2037 covariance = FullPivLU(H_last).inverse() if converged and invertible, eigenvalue-clamped to 1e-9 when the
+     * smallest eigenvalue of the inverse is <= 1e-12 (:2020-2029); otherwise 1e6 I */
     for (int i = 0; i < 36; ++i) res->cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
     if (res->converged) {
-        double inv[36]; int ok = 1;
-        for (int c = 0; c < 6 && ok; ++c) {
-            double e[6] = {0, 0, 0, 0, 0, 0}, col[6];
-            e[c] = 1.0;
-            if (orc_colpiv_qr_solve(6, 6, Hlast, e, col) < 6) ok = 0;
-            for (int r2 = 0; r2 < 6; ++r2) inv[r2 * 6 + c] = col[r2];
+        double inv[36];
+        if (orc_inv_fullpiv(6, Hlast, inv)) {
+            double sym[36], w[6], V[36];
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) sym[i * 6 + j] = inv[(i > j ? i : j) * 6 + (i > j ? j : i)];   /* lower triangle */
+            orc_sym_eig(6, sym, w, V);
+            double mn = w[0];
+            for (int i = 1; i < 6; ++i) if (w[i] < mn) mn = w[i];
+            if (mn <= 1e-12) {
+                for (int i = 0; i < 6; ++i) if (w[i] < 1e-9) w[i] = 1e-9;
+                for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+                    double s2 = 0.0;
+                    for (int k = 0; k < 6; ++k) s2 += V[i * 6 + k] * w[k] * V[j * 6 + k];
+                    inv[i * 6 + j] = s2;
+                }
+            }
+            memcpy(res->cov, inv, sizeof(inv));
         }
-        if (ok) memcpy(res->cov, inv, sizeof(inv));
     }
     return res->converged;
 }

@@ -158,6 +158,8 @@ int orc_colpiv_qr_solve(int m, int n, const double *A, const double *b, double *
 void orc_sym_eig(int n, const double *A, double *w, double *V);
 /* 3x3 inverse by full-pivot LU with Eigen's isInvertible() rule; returns 1 if invertible */
 int orc_inv3_fullpiv(const double *A, double *Ainv);
+/* the same for n x n, n <= 6 (6x6: covariance, icp_test_runner.cpp:2016-2018) */
+int orc_inv_fullpiv(int n, const double *A, double *Ainv);
 
 /* ---- hot path ---- */
 int orc_plane_fit(const double Q[15], double n_out[3], double *d_out, double *ps_out);
