@@ -117,7 +117,7 @@ EXPORTS = [
     "dcreg_linearize_batch_end", "dcreg_linearize_debug", "dcreg_knn",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
-    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version",
+    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
 ]
 
 _lib = None
@@ -178,6 +178,7 @@ def load():
                                       C.POINTER(IcpResult), dp]
     L.dcreg_icp_run_trials.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(TrialResult)]
     L.dcreg_p2p_error.argtypes = [vp, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int64)]
+    L.dcreg_trial_pose.argtypes = [dp, C.c_uint64, C.c_int64, C.c_double, C.c_double, dp, dp]
     L.dcreg_sizeof.restype = C.c_size_t
     L.dcreg_sizeof.argtypes = [C.c_char_p]
     L.dcreg_version.restype = C.c_char_p
@@ -262,6 +263,15 @@ def pose_error(gt, T):
     a, b = C.c_double(), C.c_double()
     load().dcreg_pose_error(_dp(_f64(gt, 16)), _dp(_f64(T, 16)), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def trial_pose(base_xyzrpy, seed, k, trans_amp, rot_amp_rad):
+    """dcreg_trial_pose: initial pose of Monte-Carlo trial k (k == 0: the base pose), 4x4."""
+    T = np.empty(16)
+    rc = load().dcreg_trial_pose(_dp(_f64(base_xyzrpy, 6)), int(seed), int(k), float(trans_amp), float(rot_amp_rad), _dp(T), None)
+    if rc:
+        raise DcregError("dcreg_trial_pose rc=%d" % rc)
+    return T.reshape(4, 4)
 
 
 def icp_run_many(contexts, T0s, method, cfg):

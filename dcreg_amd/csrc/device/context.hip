@@ -303,6 +303,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     LinSlot &S = c->slots[slot];
     if (S.pending) { c->fail("slot %d still has a linearisation in flight", slot); return DCREG_E_STATE; }
     if (!R9 || !t3 || n_poses < 1) { c->fail("null argument"); return DCREG_E_INVALID; }
+    if (n_poses > 65535) { c->fail("at most 65535 poses per batched launch (grid.y limit), got %d", n_poses); return DCREG_E_INVALID; }
     if (c->n_tgt <= 0) { c->fail("KdTree/target index is not set up in context"); return DCREG_E_STATE; }   // :1639
     if (c->n_src <= 0) { c->fail("measure cloud is not set"); return DCREG_E_STATE; }
     LinArgs a;

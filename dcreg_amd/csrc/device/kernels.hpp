@@ -1082,7 +1082,7 @@ static __global__ void k_gap_dilate(uint8_t *gap, int nx, int ny, int nz, int ri
 }
 
 // reductions for dcreg_p2p_error: sum sqrt(d2), sum d2 [dist<thr], count  (deterministic two-stage)
-static __global__ __launch_bounds__(kBlock) void k_p2p_partial(const float *__restrict__ d2, int64_t n, float thr, double *__restrict__ part) {
+static __global__ __launch_bounds__(kBlock) void k_p2p_partial(const float *__restrict__ d2, int64_t n, double thr, double *__restrict__ part) {
     __shared__ double tile[kBlock / 64][4];
     double s_d = 0.0, s_sq = 0.0, cnt = 0.0;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1091,7 +1091,7 @@ static __global__ __launch_bounds__(kBlock) void k_p2p_partial(const float *__re
         if (v < __builtin_inff()) {
             const float dist = sqrtf(v);            // std::sqrt(float), utils.hpp:557
             s_d = (double)dist;
-            if ((double)dist < (double)thr) { s_sq = (double)v; cnt = 1.0; }
+            if ((double)dist < thr) { s_sq = (double)v; cnt = 1.0; }   // the reference compares against the double threshold (utils.hpp:560)
         }
     }
     s_d = wave_sum_to_lane63(s_d); s_sq = wave_sum_to_lane63(s_sq); cnt = wave_sum_to_lane63(cnt);

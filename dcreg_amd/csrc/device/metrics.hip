@@ -31,7 +31,7 @@ int build_aux_index(dcreg_ctx *c);   // context.hip
         }                                                                                        \
     } while (0)
 
-static int reduce_p2p(dcreg_ctx *c, const float *d_d2, int64_t n, float thr, double out[3]) {
+static int reduce_p2p(dcreg_ctx *c, const float *d_d2, int64_t n, double thr, double out[3]) {
     const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
     if (c->p2p_part_cap < (size_t)nb * 4) {
         if (c->d_p2p_part) (void)hipFree(c->d_p2p_part);
@@ -40,6 +40,7 @@ static int reduce_p2p(dcreg_ctx *c, const float *d_d2, int64_t n, float thr, dou
         c->p2p_part_cap = (size_t)nb * 4;
     }
     hipLaunchKernelGGL(k_p2p_partial, dim3(nb), dim3(kBlock), 0, c->stream, d_d2, n, thr, c->d_p2p_part);
+    HIP_TRY2(c, hipGetLastError());
     std::vector<double> h((size_t)nb * 4);
     HIP_TRY2(c, hipMemcpyAsync(h.data(), c->d_p2p_part, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY2(c, hipStreamSynchronize(c->stream));
@@ -64,7 +65,7 @@ extern "C" int dcreg_p2p_error(dcreg_ctx *c, const double T[16], double error_th
     int rc = launch_knn(c, c->grid, c->d_src_raw, ns, 1, 0.0, &P, c->d_nn_idx, c->d_nn_d2);
     if (rc) return rc;
     double fwd[3];
-    rc = reduce_p2p(c, c->d_nn_d2, ns, (float)error_threshold, fwd);
+    rc = reduce_p2p(c, c->d_nn_d2, ns, error_threshold, fwd);
     if (rc) return rc;
     // backward: target -> aligned  ==  T^-1 target -> source (body frame)
     rc = build_aux_index(c);

@@ -84,6 +84,8 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
                           dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
     if (!ctx || !R0 || !t0 || !cfg || !res) return DCREG_E_INVALID;
     std::memset(res, 0, sizeof(*res));
+    // every rank passes the same total, so a bad value makes all of them return here together (no collective is pending)
+    if (reduce && n_source_total <= 0) return DCREG_E_INVALID;
     const auto t_total = Clock::now();
     double R[9], t[3], Hlast[36];
     std::memcpy(R, R0, sizeof(R)); std::memcpy(t, t0, sizeof(t));
@@ -92,22 +94,35 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
     dcreg_index_info info;
     dcreg_index_info_get(ctx, &info);
     const double n_src_all = reduce ? (double)n_source_total : (double)info.n_source;
-    if (info.n_source <= 0 || info.n_target <= 0) {   // :1635-1646
+    // Sharded runs: a rank whose slice is empty, or whose target is missing, still takes part in EVERY exchange (it
+    // contributes a zero row, or a poisoned one) - leaving the loop alone would block the other ranks in the collective.
+    const bool local_empty = info.n_source <= 0;
+    const bool local_bad = info.n_target <= 0;
+    if (!reduce && (local_empty || local_bad)) {   // :1635-1646
         res->status = 3;
         std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
         covariance_of(false, Hlast, res->icp_cov);
         return DCREG_OK;
     }
+    int rc_all = DCREG_OK;
     for (int it = 0; it < cfg->max_iterations; ++it) {
         const auto t_iter = Clock::now();
         dcreg_lin_out lo;
-        const int rc = dcreg_linearize(ctx, R, t, &prm, &lo);
-        if (rc != DCREG_OK) return rc;
+        std::memset(&lo, 0, sizeof(lo));
+        int rc = DCREG_OK;
+        if (!local_bad && !local_empty) rc = dcreg_linearize(ctx, R, t, &prm, &lo);
+        if (!reduce && rc != DCREG_OK) return rc;
         if (reduce) {   // point sharding: this rank linearised its slice; the sums of all slices, added in rank order
             double row[32];
             std::memcpy(row, lo.H_upper, 21 * sizeof(double)); std::memcpy(row + 21, lo.g, 6 * sizeof(double));
-            row[27] = lo.sum_r2; row[28] = lo.sum_b2; row[29] = (double)lo.n_eff; row[30] = (double)lo.n_pt; row[31] = 0.0;
-            if (reduce(row, reduce_user) != 0) return DCREG_E_DEVICE;
+            row[27] = lo.sum_r2; row[28] = lo.sum_b2; row[29] = (double)lo.n_eff; row[30] = (double)lo.n_pt;
+            row[31] = (rc != DCREG_OK || local_bad) ? 1.0 : 0.0;          // poison flag: summed like the rest
+            if (rc != DCREG_OK || local_bad) for (int k = 0; k < 31; ++k) row[k] = 0.0;
+            if (reduce(row, reduce_user) != 0) return DCREG_E_DEVICE;   // the exchange itself failed: nothing left to wait for
+            if (row[31] != 0.0) {                                        // some rank failed: every rank stops here, together
+                rc_all = rc != DCREG_OK ? rc : (local_bad ? DCREG_E_STATE : DCREG_E_DEVICE);
+                break;
+            }
             std::memcpy(lo.H_upper, row, 21 * sizeof(double)); std::memcpy(lo.g, row + 21, 6 * sizeof(double));
             lo.sum_r2 = row[27]; lo.sum_b2 = row[28]; lo.n_eff = (int64_t)std::llround(row[29]); lo.n_pt = (int64_t)std::llround(row[30]);
         }
@@ -140,7 +155,7 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
     std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
     covariance_of(res->converged != 0, Hlast, res->icp_cov);
     res->time_ms = ms_since(t_total);
-    return DCREG_OK;
+    return rc_all;
 }
 
 int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
@@ -363,6 +378,45 @@ int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, i
         std::memcpy(res->icp_cov, Cl.v, sizeof(Cl.v));
     }
     res->time_ms = ms_since(t_total);
+    return DCREG_OK;
+}
+
+// Initial pose of Monte-Carlo trial k - the ONE definition both drivers use (the reference has no RNG):
+//   k == 0 : the base pose itself (the reference's deterministic run);
+//   k >= 1 : base + U(-a, a) per degree of freedom, u_j = 2 * genrand_res53() - 1 drawn in the order x y z roll pitch yaw
+//            from MT19937 (32-bit, init_genrand) seeded with the low 32 bits of seed + k;
+//            genrand_res53 = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 of two successive outputs a, b.
+// The same numbers as numpy.random.RandomState((seed + k) & 0xFFFFFFFF).random_sample(6) (tested).
+int dcreg_trial_pose(const double base_xyzrpy[6], uint64_t seed, int64_t k, double trans_amp, double rot_amp_rad, double T[16],
+                     double pose_xyzrpy[6]) {
+    if (!base_xyzrpy || !T || k < 0) return DCREG_E_INVALID;
+    double p[6];
+    std::memcpy(p, base_xyzrpy, sizeof(p));
+    if (k > 0) {
+        uint32_t mt[624];
+        mt[0] = (uint32_t)((seed + (uint64_t)k) & 0xFFFFFFFFull);
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        int idx = 624;
+        auto next = [&]() -> uint32_t {
+            if (idx >= 624) {
+                for (int i = 0; i < 624; ++i) {
+                    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7FFFFFFFu);
+                    mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+                }
+                idx = 0;
+            }
+            uint32_t y = mt[idx++];
+            y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+            return y;
+        };
+        for (int j = 0; j < 6; ++j) {
+            const uint32_t a = next() >> 5, b = next() >> 6;
+            const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+            p[j] += (2.0 * u - 1.0) * (j < 3 ? trans_amp : rot_amp_rad);
+        }
+    }
+    dcreg::pose6dToMatrix(p[3], p[4], p[5], p[0], p[1], p[2], T);
+    if (pose_xyzrpy) std::memcpy(pose_xyzrpy, p, sizeof(p));
     return DCREG_OK;
 }
 

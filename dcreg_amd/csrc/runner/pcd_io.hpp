@@ -46,6 +46,27 @@ inline bool load(const std::string &path, Cloud &out, std::string *err = nullptr
         rec += (size_t)sizes[i] * counts[i]; c += counts[i];
     }
     if (off[0] < 0 || off[1] < 0 || off[2] < 0) { if (err) *err = "PCD has no x y z fields: " + path; return false; }
+    if (data_kind == "binary") {
+        // the 4-byte copies below are only meaningful for float32 fields (pcl::PointXYZI): check TYPE F / SIZE 4 / COUNT 1
+        for (size_t i = 0; i < fields.size(); ++i) {
+            const bool used = fields[i] == "x" || fields[i] == "y" || fields[i] == "z" || fields[i] == "intensity";
+            if (!used) continue;
+            const bool is_float = types.size() != fields.size() || types[i] == "F";
+            if (sizes[i] != 4 || counts[i] != 1 || !is_float) {
+                if (err) *err = "PCD field '" + fields[i] + "' is not a float32 scalar (TYPE F, SIZE 4, COUNT 1): " + path;
+                return false;
+            }
+        }
+        // the header's POINTS must fit the file: no allocation from an unchecked count
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streamoff remaining = f.tellg() - here;
+        f.seekg(here);
+        if (rec == 0 || remaining < 0 || (unsigned long long)npts > (unsigned long long)remaining / rec) {
+            if (err) *err = "truncated PCD " + path + " (POINTS exceeds the file size)";
+            return false;
+        }
+    } else if (npts > ((size_t)1 << 31)) { if (err) *err = "PCD POINTS out of range in " + path; return false; }
     out.xyzi.assign(npts * 4, 0.f);
     if (data_kind == "binary") {
         std::vector<char> buf(rec * npts);

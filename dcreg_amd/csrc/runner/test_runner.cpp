@@ -289,11 +289,11 @@ private:
         for (int i = 0; i < 16; ++i) T0[i] = config_.initial_matrix[i];
         Pose6D p = config_.initial_noise;
         if (run > 0 && (config_.perturb_trans > 0.0 || config_.perturb_rot_deg > 0.0)) {   // additive: seeded perturbation
-            std::mt19937_64 rng(config_.seed + (uint64_t)run);
-            std::uniform_real_distribution<double> u(-1.0, 1.0);
-            p.x += u(rng) * config_.perturb_trans; p.y += u(rng) * config_.perturb_trans; p.z += u(rng) * config_.perturb_trans;
-            p.roll += deg2rad(u(rng) * config_.perturb_rot_deg); p.pitch += deg2rad(u(rng) * config_.perturb_rot_deg); p.yaw += deg2rad(u(rng) * config_.perturb_rot_deg);
-            dcreg_pose6d_to_matrix(p.roll, p.pitch, p.yaw, p.x, p.y, p.z, T0);
+            // the shared generator of the C-ABI (run 0 = the unperturbed reference run); same trial -> same pose in every driver
+            const double base[6] = {p.x, p.y, p.z, p.roll, p.pitch, p.yaw};
+            double q[6];
+            dcreg_trial_pose(base, (uint64_t)config_.seed, (int64_t)run, config_.perturb_trans, deg2rad(config_.perturb_rot_deg), T0, q);
+            p.x = q[0]; p.y = q[1]; p.z = q[2]; p.roll = q[3]; p.pitch = q[4]; p.yaw = q[5];   // the Euler engine starts from the Pose6D
         }
         // context per run: index build + source upload, outside the timed region like :408-409
         if (dcreg_set_target(ctx_, target_.xyzi.data(), (int64_t)target_.size(), 4, config_.core.search_radius) != DCREG_OK ||

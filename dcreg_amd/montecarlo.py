@@ -4,7 +4,10 @@ The reference's skeleton is TestRunner::runMethod (DCReg/src/icp_test_runner.cpp
 plus updateStatistics / finalizeStatistics (:604-664).  The reference has no RNG (every run is identical);
 the seeded perturbation of the initial pose is this build's own definition:
 
-    trial k :  initial_noise = base + U(-a, a) per DoF,  drawn from MT19937(seed + k)
+    trial 0 :  the base pose (the reference's deterministic run)
+    trial k :  initial_noise = base + U(-a, a) per DoF,  drawn from MT19937(seed + k)      (k >= 1)
+
+ONE generator for every driver: dcreg_trial_pose of the C-ABI (include/dcreg.h), which the C++ runner calls too.
 
 Trials are embarrassingly parallel: rank r runs trials k = r, r + world, ... on its own GPU (its own copy of
 the clouds and index); the only exchange is ONE all_gather of fixed-size per-trial records at the end
@@ -34,10 +37,8 @@ def pose6d_matrix(x, y, z, roll, pitch, yaw):
 
 def trial_pose(base, k, seed, trans_amp, rot_amp_rad):
     """Initial pose of trial k.  base = (x, y, z, roll, pitch, yaw) [m, rad]."""
-    rng = np.random.Generator(np.random.MT19937(int(seed) + int(k)))
-    u = rng.uniform(-1.0, 1.0, 6)
-    p = np.asarray(base, np.float64) + np.concatenate([u[:3] * trans_amp, u[3:] * rot_amp_rad])
-    return pose6d_matrix(*p)
+    from . import api
+    return api.trial_pose(base, seed, k, trans_amp, rot_amp_rad)
 
 
 def shard_indices(n_trials, rank, world):

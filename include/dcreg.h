@@ -267,6 +267,14 @@ typedef struct dcreg_trial_result {
 int dcreg_icp_run_trials(dcreg_ctx *, int n_trials, const double *R0_9, const double *t0_3, int detection,
                          int handling, const dcreg_config *, dcreg_trial_result *results);
 
+/* Initial pose of Monte-Carlo trial k (the reference has no RNG: its num_runs loop, icp_test_runner.cpp:339-349, repeats one
+ * deterministic run; the seeded perturbation is this build's definition, shared by the runner and dcreg_amd/montecarlo.py):
+ * k == 0 -> the base pose; k >= 1 -> base + U(-amp, amp) per degree of freedom from MT19937(low 32 bits of seed + k),
+ * 53-bit doubles, drawn in the order x y z roll pitch yaw.  base = {x, y, z [m], roll, pitch, yaw [rad]}; T row-major 4x4
+ * = Pose6D2Matrix (utils.hpp:452-460); pose_xyzrpy (may be NULL) receives the perturbed six numbers. */
+int dcreg_trial_pose(const double base_xyzrpy[6], uint64_t seed, int64_t k, double trans_amp, double rot_amp_rad, double T[16],
+                     double pose_xyzrpy[6]);
+
 /* calculatePointToPointError (utils.hpp:538-589): aligned = T * source (float), both directions on the GPU */
 int dcreg_p2p_error(dcreg_ctx *, const double T[16], double error_threshold, double *rmse, double *fitness,
                     double *chamfer, int64_t *valid_correspondences);

@@ -62,6 +62,21 @@ def test_trial_poses_are_seeded_and_rank_independent():
     assert np.allclose(mc.pose6d_matrix(*BASE), h.pose6d_matrix(*BASE[:3], *BASE[3:]))
 
 
+def test_one_generator_for_every_driver():
+    """dcreg_trial_pose is THE definition (the C++ runner and montecarlo.py both call it): trial 0 is the base pose, trial k
+    draws six 53-bit doubles from MT19937 seeded with the low 32 bits of seed + k -- numpy's RandomState is the same
+    generator, so the values are pinned here independently of the C++ implementation."""
+    from dcreg_amd import api
+    assert np.array_equal(api.trial_pose(BASE, 123, 0, 0.3, 0.01), mc.pose6d_matrix(*BASE))
+    for seed, k in ((123, 1), (2024, 4999), (2 ** 40 + 3, 12)):
+        u = np.random.RandomState((seed + k) & 0xFFFFFFFF).random_sample(6) * 2.0 - 1.0
+        want = mc.pose6d_matrix(*(np.array(BASE) + np.concatenate([u[:3] * 0.3, u[3:] * 0.01])))
+        assert np.allclose(api.trial_pose(BASE, seed, k, 0.3, 0.01), want, rtol=0, atol=1e-15)
+    # first two uniforms of MT19937(1) as 53-bit doubles (known-answer: 0.417022004702574, 0.7203244934421581)
+    T = api.trial_pose((0, 0, 0, 0, 0, 0), 0, 1, 1.0, 0.0)
+    assert np.allclose(T[:3, 3][:2], [2 * 0.417022004702574 - 1, 2 * 0.7203244934421581 - 1], rtol=0, atol=1e-15)
+
+
 def test_statistics_definitions():
     recs = np.zeros((4, mc.REC))
     recs[:, mc.R_CONV] = [1, 0, 1, 1]
