@@ -4,13 +4,24 @@
 A "step" is ONE ICP iteration of one scan pair: dcreg_linearize (exact 5-NN + plane fit + Jacobian/residual
 + J^T J / J^T r on the GPU, inputs resident in HBM) followed by the host 6x6 Schur analysis + PCG solve and
 the SE(3) update -- exactly the reference's per-iteration loop body (icp_test_runner.cpp:1694-2004).
-Default workload = BASELINE.json configs[1]: 100k-point synthetic cylinder pair, runs of 20 ICP iterations.
-With --gpus N every rank runs its own scan pair (weak scaling, no data-path collective); RCCL is used only
-for the final statistics gather.  Rank 0 prints ONE JSON line.
+
+Default workload = BASELINE.json configs[3], the largest single-GPU configuration and the one the metric's roofline is
+quoted on: 1 M x 1 M-point synthetic corridor, runs of 50 ICP iterations, method Ours (Schur detection + PCG).  The steps
+are consecutive iterations of back-to-back 50-iteration runs from the same initial misalignment (a run's first iterations,
+0.87 m off at the corridor ends, cost several times an aligned one: they are part of the workload and of `value`).  The
+timed region of --steps K iterations is repeated --repeats times (each bracketed by barrier + synchronize, max over
+ranks); `value` = all timed steps / all timed time, `ms_per_step` = the same mean, with median / min / max alongside.
+The other BASELINE configs (C1 fixture, C2 100 k cylinder, C3 PK01-like 200 k, C5 Monte-Carlo batch) are measured briefly
+afterwards and reported under "configs", each with its own roofline block.
+
+--gpus N: one process per GPU (RCCL); when not already under torch.distributed.run the script re-executes itself under it.
+Every rank runs its own scan pair (weak scaling, no data-path collective); RCCL carries only the final statistics gather.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -22,18 +33,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_QUERY = 72           # 12 B source point + 5 x 12 B neighbours
-
-WORKLOADS = {
-    # name: (scene, n_points, radius, iterations per ICP run)
-    "c2_cylinder_100k": ("cylinder", 100_000, 1.0, 20),
-    "c4_corridor_1m": ("corridor", 1_000_000, 1.0, 50),
-    "c3_planes_200k": ("planes", 200_000, 0.5, 30),
-    "c1_fixture_7562": ("fixture", 7562, 1.0, 30),
-    # Monte-Carlo: 256 independent trials of the fixture pair advance in lock-step; ONE step = one batched launch
-    # = 256 ICP iterations (dcreg_icp_run_trials / dcreg_linearize_batch)
-    "c5_montecarlo_fixture": ("fixture", 7562, 1.0, 30),
-}
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max shader clock (MI355X_MICROARCH.md)
 MC_BATCH = 256
+KERNEL_TIMING_STRIDE = 8       # HIP-event pair around every 8th launch of the timed region (an event pair costs ~10 us of host time)
+
+# name: scene, points, radius, iterations per ICP run, weight-derivative Jacobian, BASELINE config
+WORKLOADS = {
+    "c4_corridor_1m": dict(scene="corridor", n=1_000_000, radius=1.0, run_len=50, wd=1, cfg="configs[3]"),
+    "c2_cylinder_100k": dict(scene="cylinder", n=100_000, radius=1.0, run_len=20, wd=1, cfg="configs[1]"),
+    "c3_pk01_200k": dict(scene="parkinglot", n=200_000, radius=0.5, run_len=30, wd=0, cfg="configs[2] (stand-in, 200 k-point frame variant)"),
+    "c1_fixture_7562": dict(scene="fixture", n=7562, radius=1.0, run_len=30, wd=1, cfg="configs[0]"),
+    # Monte-Carlo: 256 independent trials of the fixture pair advance in lock-step; ONE step = one batched launch
+    # = up to 256 ICP iterations (dcreg_icp_run_trials / dcreg_linearize_batch)
+    "c5_montecarlo_fixture": dict(scene="fixture", n=7562, radius=1.0, run_len=30, wd=1, cfg="configs[4] (one GPU's lock-step batch)"),
+}
 
 
 def make_pair(scene, n, seed):
@@ -41,357 +54,477 @@ def make_pair(scene, n, seed):
     if scene == "fixture":
         pts = h.cylinder_cloud()
         return pts, pts.copy()
+    if scene == "parkinglot":
+        return h.scene_parkinglot(n_map=n, n_frame=n, seed=7 + seed - 100, frame_range=100.0)
     gen = {"cylinder": lambda: h.scene_cylinder(n, seed=seed, noise=0.01),
-           "corridor": lambda: h.scene_corridor(n, seed=seed),
-           "planes": lambda: h.scene_planes(n, seed=seed)}[scene]
+           "corridor": lambda: h.scene_corridor(n, seed=seed)}[scene]
     tgt = gen()
     rng = np.random.default_rng(seed + 1000)
     src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)   # a second noisy scan of the same scene
     return tgt, src
 
 
-KERNEL_TIMING_STRIDE = 8   # HIP-event pair around every 8th launch of the timed region
+def initial_pose(scene):
+    import helpers as h
+    if scene == "parkinglot":
+        return h.pose6d_matrix(**h.PK01_INIT)          # config/icp_pk01.yaml:29-35
+    # a few cm / tenths of a degree (frame-to-frame LiDAR odometry regime); over the 200 m corridor the 0.5 deg yaw is
+    # 0.87 m at the ends
+    return h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--workload", default="c2_cylinder_100k", choices=list(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=30, help="the timed region of --steps iterations is repeated this many times")
+    ap.add_argument("--workload", default="c4_corridor_1m", choices=list(WORKLOADS))
     ap.add_argument("--method", default="Ours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--no-configs", action="store_true", help="skip the brief measurements of the other BASELINE configs")
     ap.add_argument("--sharding", default="pairs", choices=["pairs", "points"],
                     help="pairs (default): one independent scan pair per GPU, no data-path collective, weak scaling; "
-                         "points: ONE pair, source points split over the GPUs, one 256 B all_gather per iteration "
-                         "(dcreg_amd/pointshard.py), strong scaling")
-    ap.add_argument("--concurrent-pairs", type=int, default=4,
+                         "points: ONE pair, source points split over the GPUs, one 256 B all_gather per iteration, strong scaling")
+    ap.add_argument("--concurrent-pairs", type=int, default=2,
                     help="after the main (one pair at a time) measurement, also time P independent scan pairs running "
-                         "CONCURRENTLY on this GPU (one context + stream + host thread each) and report the aggregate as "
-                         "'concurrent_pairs'; 0 = skip")
+                         "CONCURRENTLY on this GPU (one context + stream + host thread each); 0 = skip")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
-                    help="backend option (dcreg_backend_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
-    args = ap.parse_args()
+                    help="backend option (dcreg_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
+    return ap.parse_args(argv)
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks (control-flow check of the multi-rank path on a single-GPU box): several ranks on one device over gloo
-    backend = os.environ.get("DCREG_BENCH_BACKEND", "nccl")
-    if "DCREG_BENCH_LOCAL_RANK" in os.environ:
-        local_rank = int(os.environ["DCREG_BENCH_LOCAL_RANK"])
-    cdev = "cuda" if backend == "nccl" else "cpu"        # device of the (tiny) collective payloads
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
-    n_gpus = world
 
+def maybe_spawn(args):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: re-execute under torch.distributed.run, one rank per GPU.
+    Refuses (non-zero exit) when fewer than N devices are visible instead of reporting a smaller job as N GPUs."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to report a job of a different size" % (args.gpus, world_env))
+        return
+    if args.gpus <= 1:
+        return
+    shared = os.environ.get("DCREG_BENCH_BACKEND", "nccl") != "nccl"      # test hook: all ranks on one device over gloo
+    if not shared and not os.environ.get("DCREG_BENCH_DRYRUN"):
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d requested but only %d HIP device(s) visible; not running a smaller job under that name" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # torch.distributed.run pins OMP_NUM_THREADS=1 unless told otherwise; the Monte-Carlo path solves its 6x6 systems with OpenMP
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1) // args.gpus))))
+    os.execv(sys.executable, cmd)
+
+
+class Dist:
+    """torch.distributed plumbing: rank / world, the barrier + synchronize fence, max-over-ranks of a time."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # test hooks (control flow of the multi-rank path on a single-GPU box / on CPU): ranks share one device over gloo
+        self.backend = os.environ.get("DCREG_BENCH_BACKEND", "nccl")
+        if "DCREG_BENCH_LOCAL_RANK" in os.environ:
+            self.local_rank = int(os.environ["DCREG_BENCH_LOCAL_RANK"])
+        self.dry = bool(os.environ.get("DCREG_BENCH_DRYRUN"))
+        self.cdev = "cuda" if self.backend == "nccl" else "cpu"       # device of the (tiny) collective payloads
+        import torch
+        self.torch = torch
+        self.dist = None
+        if not self.dry:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))   # RCCL over xGMI
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+
+    def fence(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_rows(self, rec):
+        t = self.torch.tensor(rec, dtype=self.torch.float64, device=self.cdev)
+        if self.dist is None:
+            return t.cpu().numpy()[None, :]
+        allrec = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(allrec, t)
+        return self.torch.stack(allrec).cpu().numpy()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+class Pair:
+    """One scan pair on one device context, stepped through the product's engine seam."""
+
+    def __init__(self, name, D, args, seed):
+        import ctypes as C
+        import dcreg_amd
+        from dcreg_amd import api
+        self.C, self.api, self.name = C, api, name
+        w = WORKLOADS[name]
+        self.w = w
+        self.by_points = args.sharding == "points" and name == args.workload
+        self.mc = name.startswith("c5_")
+        self.tgt, src = make_pair(w["scene"], w["n"], seed)
+        self.n_src_total = len(src)
+        self.reducer = None
+        if self.by_points:                                        # points: the same pair everywhere, this rank's slice
+            from dcreg_amd import pointshard
+            lo, hi = pointshard.slice_of(len(src), D.rank, D.world)
+            src = np.ascontiguousarray(src[lo:hi])
+            self.reducer = pointshard.make_reducer(D.dist, D.cdev)
+        self.src = src
+        self.ctx = dcreg_amd.Context(D.local_rank)
+        for kv in args.opt:
+            k, v = kv.split("=", 1)
+            self.ctx.set_option(k, float(v))
+        self.ctx.set_target(self.tgt, w["radius"])
+        self.ctx.set_source(src)
+        self.info = self.ctx.index_info()
+        self.method = args.method
+        self.det, self.hand = api.METHODS[args.method]
+        self.cfg = api.default_config(search_radius=w["radius"], max_iterations=w["run_len"], KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0,
+                                      CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0,   # fixed-length runs
+                                      use_weight_derivative=w["wd"], always_compute_schur=1)
+        self.T_init = initial_pose(w["scene"])
+        self.L = api.load()
+        self.dp = C.POINTER(C.c_double)
+        self.res = api.IcpResult()
+        self.pos = 0                                             # iterations done in the current run
+        self.R = np.ascontiguousarray(self.T_init[:3, :3]).reshape(9).copy()
+        self.t = self.T_init[:3, 3].copy()
+        self.mc_iters = 0
+        if self.mc:
+            from dcreg_amd import montecarlo as mcm
+            import helpers as h
+            base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+            T0s = np.stack([mcm.trial_pose(base, 1 + k + 1000 * D.rank, 2024, 0.3, h.deg2rad(1.0)) for k in range(MC_BATCH)])
+            self.R0s = np.ascontiguousarray(T0s[:, :3, :3]).reshape(MC_BATCH, 9)
+            self.t0s = np.ascontiguousarray(T0s[:, :3, 3]).reshape(MC_BATCH, 3)
+            self.trial_res = (api.TrialResult * MC_BATCH)()
+
+    def _restart(self):
+        self.pos = 0
+        self.R[:] = np.ascontiguousarray(self.T_init[:3, :3]).reshape(9)
+        self.t[:] = self.T_init[:3, 3]
+
+    def run_steps(self, k):
+        """k ICP iterations: consecutive iterations of back-to-back runs of run_len iterations, each run from T_init."""
+        if self.mc:
+            return self._run_steps_mc(k)
+        api, C, L = self.api, self.C, self.L
+        left = k
+        while left > 0:
+            n = min(self.w["run_len"] - self.pos, left)
+            self.cfg.max_iterations = n
+            if self.by_points:
+                T = np.eye(4); T[:3, :3] = self.R.reshape(3, 3); T[:3, 3] = self.t
+                out, _ = self.ctx.icp_run_sharded(T, self.method, self.cfg, self.n_src_total, self.reducer, log_capacity=0)
+                it, st = out.iterations, out.status
+                self.R[:] = out.R[:]; self.t[:] = out.t[:]
+                self.res.R[:] = out.R[:]; self.res.t[:] = out.t[:]
+            else:
+                rc = L.dcreg_icp_run(self.ctx._h, self.R.ctypes.data_as(self.dp), self.t.ctypes.data_as(self.dp), api.DETECTION[self.det],
+                                     api.HANDLING[self.hand], C.byref(self.cfg), None, 0, C.byref(self.res))
+                if rc != 0:
+                    raise RuntimeError("dcreg_icp_run failed: rc=%d %s" % (rc, L.dcreg_last_error(self.ctx._h)))
+                it, st = self.res.iterations, self.res.status
+                self.R[:] = self.res.R[:]; self.t[:] = self.res.t[:]
+            if it != n or st != 0:
+                raise RuntimeError("%s: run stopped early: iterations=%d of %d status=%d" % (self.name, it, n, st))
+            self.pos += n
+            left -= n
+            if self.pos >= self.w["run_len"]:
+                self._restart()
+
+    def _run_steps_mc(self, k):
+        """k lock-step iterations of MC_BATCH independent trials (each iteration = one batched launch per group)."""
+        api, C, L = self.api, self.C, self.L
+        left = k
+        while left > 0:
+            n = min(self.w["run_len"], left)
+            self.cfg.max_iterations = n
+            rc = L.dcreg_icp_run_trials(self.ctx._h, MC_BATCH, self.R0s.ctypes.data_as(self.dp), self.t0s.ctypes.data_as(self.dp),
+                                        api.DETECTION[self.det], api.HANDLING[self.hand], C.byref(self.cfg), self.trial_res)
+            if rc != 0:
+                raise RuntimeError("dcreg_icp_run_trials failed: %s" % L.dcreg_last_error(self.ctx._h))
+            self.mc_iters += sum(self.trial_res[i].iterations for i in range(MC_BATCH))   # trials that abort stop counting
+            left -= n
+
+    def close(self):
+        self.ctx.close()
+
+
+def measure(P, D, steps, warmup, repeats):
+    """warm-up, then `repeats` timed regions of exactly `steps` iterations, each bracketed by the fence; times are
+    max-over-ranks.  Returns dict(times=[s per block], kernel_us, iters_per_step)."""
+    P.run_steps(warmup)
+    P.ctx.set_option("time_kernels", KERNEL_TIMING_STRIDE)
+    P.ctx.kernel_time(reset=True)
+    mc0 = P.mc_iters
+    times = []
+    for _ in range(repeats):
+        D.fence()
+        t0 = time.perf_counter()
+        P.run_steps(steps)
+        D.fence()
+        times.append(D.max_over_ranks(time.perf_counter() - t0))
+    kern_ms, kern_n = P.ctx.kernel_time(reset=True)
+    P.ctx.set_option("time_kernels", 0)
+    per_step = (P.mc_iters - mc0) / float(steps * repeats) if P.mc else 1.0
+    return {"times": times, "kernel_us": 1e3 * kern_ms / max(kern_n, 1), "iters_per_step": per_step}
+
+
+def roofline_blocks(name, n_queries_per_launch, kern_us):
+    """The HBM block the contract asks for + the VALU-issue block that actually binds.  `achieved` is live
+    (algorithmic bytes / HIP-event kernel time of THIS run); `traffic` and the instruction count are per-launch PMC figures
+    of the same workload read from the committed rocprofv3 summaries (labelled with their source file)."""
+    algo = BYTES_PER_QUERY * n_queries_per_launch
+    achieved = algo / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+    prof = profile_record(name)
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("source"),
+           "kernel": "k_linearize (fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r reduction)",
+           "kernel_us_avg": kern_us, "algorithmic_bytes_per_launch": algo}
+    out = {"roofline": hbm}
+    if prof.get("valu_insts_per_launch") and kern_us > 0:
+        floor_us = prof["valu_insts_per_launch"] * 4.0 / N_SIMD / CLOCK_HZ * 1e6     # one VALU instruction = 4 issue cycles of its SIMD
+        out["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": prof["valu_insts_per_launch"] / (kern_us * 1e-6) / 1e12,
+                                      "peak": N_SIMD * CLOCK_HZ / 4.0 / 1e12, "unit": "T wave-instructions/s", "frac": floor_us / kern_us,
+                                      "floor_us": floor_us, "valu_insts_per_launch": prof["valu_insts_per_launch"], "source": prof.get("source")}
+    return out
+
+
+def profile_record(workload):
+    """Per-launch PMC figures of k_linearize from the newest committed rocprofv3 summary of this workload
+    (profiles/rNN_<workload>.json, written by scripts/summarize_profiles.py): HBM-side bytes (FETCH_SIZE x2 per the gfx950
+    note in MI355X_MICROARCH.md + WRITE_SIZE, separate passes) and wave-level VALU instructions."""
+    import glob
+    rec = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % workload))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        t = j.get("traffic") or {}
+        if t.get("bytes_fetch_x2"):
+            rec["traffic_bytes"] = t["bytes_fetch_x2"]
+            rec["source"] = os.path.relpath(f, ROOT)
+        v = (j.get("pmc") or {}).get("SQ_INSTS_VALU_per_launch")
+        if v:
+            rec["valu_insts_per_launch"] = v
+            rec["source"] = os.path.relpath(f, ROOT)
+    return rec
+
+
+def summarize(name, P, D, m, steps, n_gpus):
+    times = np.array(m["times"])
+    per_step_s = times / steps
+    total_iters = (1 if P.by_points else n_gpus) * steps * len(times) * m["iters_per_step"]
+    value = total_iters / float(times.sum())
+    w = WORKLOADS[name]
+    rec = {"value": value, "unit": "iterations/s", "ms_per_step": 1e3 * float(times.sum()) / (steps * len(times)),
+           "ms_per_step_median": 1e3 * float(np.median(per_step_s)), "ms_per_step_min": 1e3 * float(per_step_s.min()),
+           "ms_per_step_max": 1e3 * float(per_step_s.max()), "repeats": int(len(times)), "steps": steps,
+           "icp_iterations_per_step": m["iters_per_step"], "correspondence_queries_per_s": value * P.n_src_total,
+           "workload": "%s [%s]: %d-pt source x %d-pt target, radius %.2f, back-to-back runs of %d ICP iterations, method %s" % (
+               name, w["cfg"], P.n_src_total, len(P.tgt), w["radius"], w["run_len"], P.method)}
+    rec.update(roofline_blocks(name, len(P.src) * m["iters_per_step"], m["kernel_us"]))
+    return rec
+
+
+def concurrent_pairs(P0, D, args, steps, warmup):
+    """Throughput with several independent pairs in flight on the same GPU (extra figure, not `value`): the device idles
+    during every host step, so independent pairs interleave."""
+    import threading
+    Pn = args.concurrent_pairs
+    pairs = [P0] + [Pair(P0.name, D, args, seed=100 + D.rank + 1000 * q) for q in range(1, Pn)]
+    errors = []
+
+    def worker(p, k, barrier):
+        barrier.wait()
+        try:
+            p.run_steps(k)
+        except Exception as e:
+            errors.append(str(e))
+
+    t_conc = None
+    for k in (warmup, steps):
+        for p in pairs:
+            p._restart()
+        barrier = threading.Barrier(Pn + 1)
+        th = [threading.Thread(target=worker, args=(p, k, barrier)) for p in pairs]
+        for t_ in th:
+            t_.start()
+        D.fence()
+        barrier.wait()
+        ta = time.perf_counter()
+        for t_ in th:
+            t_.join()
+        D.fence()
+        t_conc = D.max_over_ranks(time.perf_counter() - ta)
+    for p in pairs[1:]:
+        p.close()
+    if errors:
+        raise RuntimeError("; ".join(errors))
+    n = WORKLOADS[P0.name]["n"]
+    return {"pairs_per_gpu": Pn, "value": D.world * Pn * steps / t_conc, "unit": "iterations/s", "us_per_iteration_per_pair": 1e6 * t_conc / steps,
+            "achieved_GBps_wall": Pn * BYTES_PER_QUERY * n * steps / t_conc / 1e9,
+            "frac_of_hbm_peak_wall": Pn * BYTES_PER_QUERY * n * steps / t_conc / 1e9 / HBM_PEAK_GBS,
+            "note": "%d independent %d-pt pairs in flight per GPU, one context + stream + host thread each, %d iterations each (whole runs); aggregate over all GPUs" % (Pn, n, steps)}
+
+
+def dry_run(args, D):
+    """DCREG_BENCH_DRYRUN=1 (CPU test hook): the launcher, rendezvous, fence, max-over-ranks and gather paths with a
+    synthetic per-rank record instead of device work.  Prints a line marked "dry_run": true that is NOT a measurement."""
+    times = []
+    for _ in range(2):
+        D.fence()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (1 + D.rank))
+        D.fence()
+        times.append(D.max_over_ranks(time.perf_counter() - t0))
+    recs = D.gather_rows([float(D.rank), float(100 + D.rank), 0.0, 0.0])
+    if D.rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "ICP iterations/sec", "value": None, "n_gpus": D.world, "steps": args.steps,
+                          "warmup": args.warmup, "rank_seeds": [int(r[1]) for r in recs], "ranks": [int(r[0]) for r in recs],
+                          "block_times_s": times}), flush=True)
+    D.close()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    maybe_spawn(args)
+    D = Dist()
+    if D.dry:
+        return dry_run(args, D)
+    n_gpus = D.world
     import helpers as h
-    import dcreg_amd
     from dcreg_amd import api
 
-    scene, n_pts, radius, run_len = WORKLOADS[args.workload]
-    by_points = args.sharding == "points"
-    tgt, src = make_pair(scene, n_pts, seed=100 + (0 if by_points else rank))   # pairs: every rank its own scan pair
-    n_src_total = len(src)
-    if by_points:                                                # points: the same pair everywhere, this rank's slice
-        from dcreg_amd import pointshard
-        lo, hi = pointshard.slice_of(len(src), rank, world)
-        src = np.ascontiguousarray(src[lo:hi])
-        reducer = pointshard.make_reducer(dist, cdev)
-    ctx = dcreg_amd.Context(local_rank)
-    for kv in args.opt:
-        k, v = kv.split("=", 1)
-        ctx.set_option(k, float(v))
-    ctx.set_target(tgt, radius)
-    ctx.set_source(src)
-    info = ctx.index_info()
-    det, hand = api.METHODS[args.method]
-    cfg = api.default_config(search_radius=radius, max_iterations=run_len, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0,
-                             CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0,   # fixed-length runs
-                             use_weight_derivative=1, always_compute_schur=1)
-    prm = api.default_lin_params(radius, 1)
-    # initial misalignment of every run: a few cm / tenths of a degree (frame-to-frame LiDAR odometry regime);
-    # the synthetic pair converges from it, so every iteration keeps ~all correspondences alive
-    T_init = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
-    import ctypes as C
-    L = api.load()
-    dp = C.POINTER(C.c_double)
-    R0 = np.ascontiguousarray(T_init[:3, :3]).reshape(9).copy()
-    t0 = T_init[:3, 3].copy()
-    res = api.IcpResult()
-    state = {"done": 0, "mc_iters": 0}
+    P = Pair(args.workload, D, args, seed=100 + (0 if args.sharding == "points" else D.rank))   # pairs: every rank its own scan pair
+    m = measure(P, D, args.steps, args.warmup, args.repeats)
+    main_rec = summarize(args.workload, P, D, m, args.steps, n_gpus)
 
-    mc = args.workload.startswith("c5_")
-    if mc:
-        from dcreg_amd import montecarlo as mcm
-        base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
-        T0s = np.stack([mcm.trial_pose(base, k + 1000 * rank, 2024, 0.3, h.deg2rad(1.0)) for k in range(MC_BATCH)])
-        R0s = np.ascontiguousarray(T0s[:, :3, :3]).reshape(MC_BATCH, 9)
-        t0s = np.ascontiguousarray(T0s[:, :3, 3]).reshape(MC_BATCH, 3)
-        trial_res = (api.TrialResult * MC_BATCH)()
-
-    def run_steps_mc(k):
-        """k lock-step iterations of MC_BATCH independent trials (each iteration = one batched launch)."""
-        left = k
-        while left > 0:
-            n = min(run_len, left)
-            cfg.max_iterations = n
-            rc = L.dcreg_icp_run_trials(ctx._h, MC_BATCH, R0s.ctypes.data_as(dp), t0s.ctypes.data_as(dp), api.DETECTION[det],
-                                        api.HANDLING[hand], C.byref(cfg), trial_res)
-            if rc != 0:
-                raise RuntimeError("dcreg_icp_run_trials failed: %s" % L.dcreg_last_error(ctx._h))
-            state["mc_iters"] += sum(trial_res[i].iterations for i in range(MC_BATCH))   # trials that abort stop counting
-            left -= n
-
-    def run_steps_points(k):
-        """k lock-step iterations of ONE scan pair whose source points are split over the ranks: per iteration one
-        linearisation of the local slice, one all_gather of 32 doubles, the host step on every rank."""
-        left = k
-        while left > 0:
-            n = min(run_len, left)
-            cfg.max_iterations = n
-            out, _ = ctx.icp_run_sharded(T_init, args.method, cfg, n_src_total, reducer, log_capacity=0)
-            if out.iterations != n or out.status != 0:
-                raise RuntimeError("point-sharded run stopped early: iterations=%d status=%d" % (out.iterations, out.status))
-            res.R[:] = out.R[:]; res.t[:] = out.t[:]
-            left -= n
-        state["done"] += k
-
-    def run_steps(k):
-        if mc:
-            return run_steps_mc(k)
-        if by_points:
-            return run_steps_points(k)
-        return run_steps_single(k)
-
-    def run_steps_single(k):
-        """k ICP iterations through the product's engine seam (dcreg_icp_run: device linearisation + host
-        Schur analysis / PCG / SE(3) update per iteration, all in C++), as runs of `run_len` iterations from the
-        initial pose; convergence thresholds are 0 so every run has exactly its max_iterations iterations."""
-        left = k
-        while left > 0:
-            n = min(run_len, left)
-            cfg.max_iterations = n
-            rc = L.dcreg_icp_run(ctx._h, R0.ctypes.data_as(dp), t0.ctypes.data_as(dp), api.DETECTION[det], api.HANDLING[hand],
-                                 C.byref(cfg), None, 0, C.byref(res))
-            if rc != 0 or res.iterations != n:
-                raise RuntimeError("dcreg_icp_run failed: rc=%d iterations=%d status=%d %s" % (rc, res.iterations, res.status, L.dcreg_last_error(ctx._h)))
-            left -= n
-        state["done"] += k
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_steps(args.warmup)
-    # HIP events around every 8th linearisation of the timed region (an event pair costs ~10 us of host time per
-    # launch: bracketing every launch would slow the measured loop by ~25 %)
-    ctx.set_option("time_kernels", KERNEL_TIMING_STRIDE)
-    ctx.kernel_time(reset=True)
-    fence()
-    mc_before = state["mc_iters"]
-    t_start = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t_start
-    kern_ms, kern_n = ctx.kernel_time(reset=True)
-    ctx.set_option("time_kernels", 0)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # ---- throughput with several independent pairs in flight on the same GPU (extra figure, not `value`): at 100 k points
-    # one linearisation occupies 1.5 of the 4 waves/SIMD the register budget allows and the device idles during every
-    # host step, so independent pairs interleave almost for free
     conc = None
-    P = args.concurrent_pairs
-    if P > 1 and not mc and not by_points and n_gpus == 1:     # (single-GPU runs only, like the CPU baseline: it needs P host threads)
-        import threading
-        ctxs = [ctx]
-        for q in range(1, P):
-            tq, sq = make_pair(scene, n_pts, seed=100 + rank + 1000 * q)
-            cq = dcreg_amd.Context(local_rank)
-            for kv in args.opt:
-                k2, v2 = kv.split("=", 1)
-                cq.set_option(k2, float(v2))
-            cq.set_target(tq, radius); cq.set_source(sq)
-            ctxs.append(cq)
+    if args.concurrent_pairs > 1 and not P.mc and not P.by_points and n_gpus == 1:
+        run_len = WORKLOADS[args.workload]["run_len"]
+        conc = concurrent_pairs(P, D, args, steps=2 * run_len, warmup=run_len)
+        P._restart()
 
-        def pair_worker(cq, k, barrier):
-            cfg_q = api.default_config(search_radius=radius, max_iterations=run_len, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0,
-                                       CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0, use_weight_derivative=1, always_compute_schur=1)
-            res_q = api.IcpResult()
-            barrier.wait()
-            left = k
-            while left > 0:
-                n = min(run_len, left)
-                cfg_q.max_iterations = n
-                rc = L.dcreg_icp_run(cq._h, R0.ctypes.data_as(dp), t0.ctypes.data_as(dp), api.DETECTION[det], api.HANDLING[hand],
-                                     C.byref(cfg_q), None, 0, C.byref(res_q))
-                if rc != 0 or res_q.iterations != n:
-                    pair_errors.append("concurrent pair failed: rc=%d iterations=%d %s" % (rc, res_q.iterations, L.dcreg_last_error(cq._h)))
-                    return
-                left -= n
+    # final statistics gather (the only collective): per-rank pose error / rmse / correspondences after one whole run
+    P._restart()
+    if not P.mc:
+        P.run_steps(WORKLOADS[args.workload]["run_len"])
+    T_fin = np.eye(4); T_fin[:3, :3] = np.array(P.res.R[:]).reshape(3, 3); T_fin[:3, 3] = P.res.t[:]
+    gt = h.pose6d_matrix(**h.PK01_GT) if WORKLOADS[args.workload]["scene"] == "parkinglot" else np.eye(4)
+    te, re_ = api.pose_error(gt, T_fin)
+    last = P.ctx.linearize(T_fin[:3, :3], T_fin[:3, 3], api.default_lin_params(WORKLOADS[args.workload]["radius"], WORKLOADS[args.workload]["wd"]))
+    recs = D.gather_rows([te, re_, float(last["n_eff"]), float(100 + D.rank)])
 
-        pair_errors = []
-        t_conc = None
-        for k in (args.warmup, args.steps):
-            barrier = threading.Barrier(P + 1)
-            th = [threading.Thread(target=pair_worker, args=(cq, k, barrier)) for cq in ctxs]
-            for t_ in th:
-                t_.start()
-            fence()
-            barrier.wait()
-            ta = time.perf_counter()
-            for t_ in th:
-                t_.join()
-            fence()
-            t_conc = time.perf_counter() - ta
-        if pair_errors:
-            raise RuntimeError("; ".join(pair_errors))
-        if dist is not None:
-            tm = torch.tensor([t_conc], dtype=torch.float64, device=cdev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            t_conc = float(tm.item())
-        conc = {"pairs_per_gpu": P, "value": n_gpus * P * args.steps / t_conc, "unit": "iterations/s",
-                "us_per_iteration_per_pair": 1e6 * t_conc / args.steps,
-                # device-level: algorithmic bytes of all P pairs' launches over the WALL time of the region (host steps included)
-                "achieved_GBps_wall": P * BYTES_PER_QUERY * n_pts * args.steps / t_conc / 1e9,
-                "frac_of_hbm_peak_wall": P * BYTES_PER_QUERY * n_pts * args.steps / t_conc / 1e9 / HBM_PEAK_GBS,
-                "note": "P independent %d-pt pairs in flight per GPU, one context + stream + host thread each; aggregate over all GPUs" % n_pts}
-        for cq in ctxs[1:]:
-            cq.close()
+    sub = {}
+    if not args.no_configs and n_gpus == 1 and args.sharding == "pairs":
+        for name in WORKLOADS:
+            if name == args.workload:
+                continue
+            w = WORKLOADS[name]
+            Q = Pair(name, D, args, seed=100)
+            k = w["run_len"] * (1 if name.startswith("c5_") else 2)
+            mq = measure(Q, D, steps=k, warmup=w["run_len"], repeats=5)
+            sub[name] = summarize(name, Q, D, mq, k, 1)
+            Q.close()
 
-    # final statistics gather (the only collective): per-rank pose error / rmse / correspondences
-    T_fin = np.eye(4); T_fin[:3, :3] = np.array(res.R[:]).reshape(3, 3); T_fin[:3, 3] = res.t[:]
-    te, re_ = api.pose_error(np.eye(4), T_fin)
-    last = ctx.linearize(T_fin[:3, :3], T_fin[:3, 3], prm)
-    rec = torch.tensor([te, re_, float(last["n_eff"]), kern_ms / max(kern_n, 1)], dtype=torch.float64, device=cdev)
-    if dist is not None:
-        allrec = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        recs = torch.stack(allrec).cpu().numpy()
-    else:
-        recs = rec.cpu().numpy()[None, :]
-
-    if rank == 0:
-        per_step = (state["mc_iters"] - mc_before) / args.steps if mc else 1
-        iters_per_s = (1 if by_points else n_gpus) * args.steps * per_step / elapsed
-        kern_us = float(np.mean(recs[:, 3])) * 1e3
-        algo_bytes = BYTES_PER_QUERY * len(src) * per_step          # per launch of THIS kernel (a rank's slice when sharded by points)
-        traffic = measured_traffic(args.workload)
-        achieved = algo_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+    if D.rank == 0:
         result = {
-            "metric": "ICP iterations/sec", "value": iters_per_s, "unit": "iterations/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if by_points else "weak",
+            "metric": "ICP iterations/sec", "value": main_rec["value"], "unit": "iterations/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
+            "ms_per_step": main_rec["ms_per_step"], "ms_per_step_median": main_rec["ms_per_step_median"],
+            "ms_per_step_min": main_rec["ms_per_step_min"], "ms_per_step_max": main_rec["ms_per_step_max"],
+            "higher_is_better": True, "scaling": "strong" if P.by_points else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d-pt source x %d-pt target, radius %.2f, runs of %d ICP iterations, method %s "
-                                   "(Schur detection + PCG), %s" % (args.workload, n_src_total, len(tgt), radius, run_len, args.method,
-                                                                    "ONE scan pair, source points split over the GPUs" if by_points else "one scan pair per GPU"),
-                       "n_src": int(n_src_total), "n_tgt": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells)},
-            "correspondence_queries_per_s": iters_per_s * n_src_total, "icp_iterations_per_step": per_step,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_linearize (fused exact 5-NN + plane fit + point-to-plane row + J^T J / J^T r reduction)",
-                         "kernel_us_avg": kern_us, "algorithmic_bytes_per_launch": algo_bytes},
+            "config": {"workload": main_rec["workload"] + (", ONE scan pair, source points split over the GPUs" if P.by_points else ", one scan pair per GPU"),
+                       "n_src": int(P.n_src_total), "n_tgt": int(len(P.tgt)), "grid_cell_m": P.info.cell, "grid_cells": int(P.info.n_cells),
+                       "parallelism": "%s x%d" % ("point-sharded" if P.by_points else "pair-sharded", n_gpus),
+                       "rank_pair_seeds": [int(r[3]) for r in recs]},
+            "correspondence_queries_per_s": main_rec["correspondence_queries_per_s"],
+            "icp_iterations_per_step": main_rec["icp_iterations_per_step"],
+            "roofline": main_rec["roofline"],
             "final_stats": {"mean_trans_error_m": float(np.mean(recs[:, 0])), "mean_rot_error_deg": float(np.mean(recs[:, 1])),
                             "mean_correspondences": float(np.mean(recs[:, 2]))},
         }
+        if "roofline_valu_issue" in main_rec:
+            result["roofline_valu_issue"] = main_rec["roofline_valu_issue"]
         if conc is not None:
             result["concurrent_pairs"] = conc
+        if sub:
+            result["configs"] = sub
         if n_gpus == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(tgt, src, T_init, radius, run_len, args.method, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(P.tgt, P.src, P.T_init, WORKLOADS[args.workload], args.method, args.cpu_seconds)
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    P.close()
+    D.close()
 
 
-def measured_traffic(workload):
-    """HBM-side bytes per k_linearize launch from the rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE,
-    separate passes, KB -> bytes, read side x2 per the gfx950 note in MI355X_MICROARCH.md), recorded by
-    scripts/collect_profiles.sh + scripts/summarize_profiles.py under profiles/.  None if no profile is committed."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % workload))):
-        try:
-            t = json.load(open(f)).get("traffic")
-            if t:
-                best = t["bytes_fetch_x2"]
-        except Exception:
-            pass
-    return best
-
-
-def cpu_baseline(tgt, src, T_init, radius, run_len, method, budget_s):
+def cpu_baseline(tgt, src, T_init, w, method, budget_s):
     """The CPU oracle (oracle/, a C/OpenMP restatement of the reference path; the reference itself needs
-    Eigen/PCL/FLANN and cannot be built here) timed on this box's host cores on a bounded sample: first the reference's own
-    configuration (ONE pair, the 8 OpenMP threads it hard-codes, :1714), then the whole box as cores/8 concurrent
-    8-thread runs of the same pair (the CPU counterpart of the GPU's concurrent_pairs figure)."""
-    import threading
+    Eigen/PCL/FLANN and cannot be built here) timed on this box's host cores on a bounded sample of the SAME workload:
+    the reference's own configuration -- ONE pair, the 8 OpenMP threads it hard-codes (:1714) -- stepping through the
+    same runs from the same initial pose."""
     from oracle import pyoracle as po
     tree = po.KdTree(tgt)                       # kd-tree build is untimed in the reference too (:408-442)
     ncpu = os.cpu_count() or 1
-    threads = min(8, ncpu)
-
-    def run(budget, counter, slot, barrier=None):
-        cfg = po.default_config(search_radius=radius, max_iterations=1, thresh_rot=0.0, thresh_trans=0.0, kappa_target=10.0,
-                                std_reg_gamma=100.0, use_weight_derivative=1, always_compute_schur=1, num_threads=threads)
-        T = T_init.copy()
-        po.icp_run(tree, src, T, method, cfg)       # warm-up (thread pool, page faults)
-        if barrier is not None:
-            barrier.wait()
-        n = 0
-        t0 = time.perf_counter()
-        while True:
-            res, logs = po.icp_run(tree, src, T, method, cfg)
-            T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
-            n += 1
-            if n % run_len == 0:
-                T = T_init.copy()
-            el = time.perf_counter() - t0
-            if el > budget or n >= 100 * run_len:
-                break
-        counter[slot] = (n, el)
-
-    one = [None]
-    run(budget_s / 2, one, 0)
-    n, el = one[0]
-    out = {"value": n / el, "unit": "iterations/s", "cores": threads, "kind": "port",
-           "sample": "%d ICP iterations of the same scan pair (%d-pt source), one pair at a time, OpenMP x%d, %.1f s" % (n, len(src), threads, el)}
-    teams = max(1, ncpu // threads)
-    if teams > 1:
-        res = [None] * teams
-        barrier = threading.Barrier(teams)
-        th = [threading.Thread(target=run, args=(budget_s / 2, res, i, barrier)) for i in range(teams)]
-        c0, w0 = os.times(), time.perf_counter()
-        for t_ in th:
-            t_.start()
-        for t_ in th:
-            t_.join()
-        c1, w1 = os.times(), time.perf_counter()
-        busy = ((c1.user + c1.system) - (c0.user + c0.system)) / max(w1 - w0, 1e-9)     # CPUs this process actually got
-        agg = sum(r[0] / r[1] for r in res if r)
-        out["all_cores"] = {"value": agg, "unit": "iterations/s", "cores": teams * threads, "cpus_obtained": busy,
-                            "sample": "%d concurrent runs of the same pair x %d OpenMP threads each" % (teams, threads)}
-        out["sample"] += "; %d such runs side by side on %d hardware threads (%.0f CPUs obtained): %.1f it/s aggregate" % (
-            teams, teams * threads, busy, agg)
-    return out
+    try:
+        ncpu_avail = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu_avail = ncpu
+    threads = min(8, ncpu_avail)
+    cfg = po.default_config(search_radius=w["radius"], max_iterations=1, thresh_rot=0.0, thresh_trans=0.0, kappa_target=10.0,
+                            std_reg_gamma=100.0, use_weight_derivative=w["wd"], always_compute_schur=1, num_threads=threads)
+    T = T_init.copy()
+    po.icp_run(tree, src, T, method, cfg)       # warm-up (thread pool, page faults)
+    n, run_len = 0, w["run_len"]
+    c0, t0 = os.times(), time.perf_counter()
+    while True:
+        res, _ = po.icp_run(tree, src, T, method, cfg)
+        T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
+        n += 1
+        if n % run_len == 0:
+            T = T_init.copy()
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 100 * run_len:
+            break
+    c1 = os.times()
+    busy = ((c1.user + c1.system) - (c0.user + c0.system)) / max(el, 1e-9)
+    return {"value": n / el, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d ICP iterations of the same scan pair (%d-pt source, the first %d of a %d-iteration run from the same initial pose), "
+                      "one pair at a time, OpenMP x%d (%.1f CPUs busy on average; the box shows %d hardware threads, %d usable by this "
+                      "process), %.1f s" % (n, len(src), min(n, run_len), run_len, threads, busy, ncpu, ncpu_avail, el)}
 
 
 if __name__ == "__main__":

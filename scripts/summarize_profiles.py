@@ -13,7 +13,7 @@ def short(name):
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
-      "Command: `python bench.py --steps 200 --warmup 20 --no-cpu-baseline --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
+      "Command: `python bench.py --steps 50 --warmup 50 --repeats 4 --no-cpu-baseline --no-configs --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
       "`rocprofv3 --kernel-trace --stats` and separate `--pmc` passes (scripts/collect_profiles.sh).", ""]
 md[2] = md[2] % wl
 bp = os.path.join(src, "bench_plain.json")
@@ -83,6 +83,10 @@ if pm:
                    w, lin.get("SQ_INSTS_VALU", 0) / w, lin.get("SQ_INSTS_SALU", 0) / w, lin.get("SQ_INSTS_LDS", 0) / w,
                    lin.get("SQ_INSTS_VMEM_RD", 0) / w, lin.get("SQ_WAIT_ANY", 0) / max(lin.get("SQ_WAVE_CYCLES", 1), 1)), ""]
         out["per_wave"] = {"valu": lin.get("SQ_INSTS_VALU", 0) / w, "salu": lin.get("SQ_INSTS_SALU", 0) / w}
+        # wave-level VALU instructions of one launch -> the VALU-issue floor bench.py prices the kernel against
+        out["pmc"] = {"SQ_INSTS_VALU_per_launch": lin.get("SQ_INSTS_VALU", 0), "SQ_WAVES_per_launch": w}
+        floor_us = lin.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 * 1e6
+        md += ["VALU-issue floor of one launch: %.3g wave instructions x 4 cycles / 1024 SIMDs / 2.4 GHz = %.1f us" % (lin.get("SQ_INSTS_VALU", 0), floor_us), ""]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", "%s_%s.md" % (tag, wl)), "w").write("\n".join(md) + "\n")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, wl)), "w"), indent=1)

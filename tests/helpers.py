@@ -142,3 +142,63 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+# ------------------------------------------------------------------ PK01 stand-in (BASELINE config 3)
+# The reference's parking-lot pair (config/icp_pk01.yaml:13-14: parkinglot_raw_2415_frame.pcd / target_prior_map.pcd) is
+# not in the repository (Google-Drive link only, README.md:69).  Stand-in: a planar prior map around the yaml's ground-truth
+# position (ground + sparse poles + a few low kerbs: X-Y-yaw weakly constrained, README.md:96) and one LiDAR frame cut out
+# of it, expressed in the sensor frame by gt^-1 and perturbed by range noise.  Poses = the yaml's own numbers.
+PK01_GT = dict(x=-109.831089, y=-395.052129, z=-1.025780, roll=deg2rad(-2.635654), pitch=deg2rad(-4.141885), yaw=deg2rad(117.972711))
+PK01_INIT = dict(x=-109.979288618688, y=-395.174034820224, z=-0.900523132121, roll=deg2rad(-2.650863295637),
+                 pitch=deg2rad(-2.836418366839), yaw=deg2rad(120.142832419935))
+
+
+def scene_parkinglot(n_map=200_000, n_frame=8_000, seed=7, extent=45.0, frame_range=30.0, noise=0.02):
+    """-> (target map [n_map,3] float32 in the map frame, source frame [n_frame,3] float32 in the sensor frame)."""
+    rng = np.random.default_rng(seed)
+    T_gt = pose6d_matrix(**PK01_GT)
+    c = T_gt[:3, 3]
+    n_pole, n_kerb = n_map // 25, n_map // 50
+    n_ground = n_map - n_pole - n_kerb
+    # ground: a gently tilted plane through the sensor's footprint
+    gx, gy = rng.uniform(-extent, extent, n_ground), rng.uniform(-extent, extent, n_ground)
+    ground = np.stack([c[0] + gx, c[1] + gy, c[2] - 1.8 + 0.01 * gx - 0.005 * gy + rng.normal(0, 0.01, n_ground)], 1)
+    # lamp poles / tree trunks: 24 thin vertical cylinders
+    pc = rng.uniform(-extent * 0.8, extent * 0.8, (24, 2))
+    k = rng.integers(0, 24, n_pole)
+    ang = rng.uniform(0, 2 * np.pi, n_pole)
+    pz = rng.uniform(0, 4.0, n_pole)
+    poles = np.stack([c[0] + pc[k, 0] + 0.15 * np.cos(ang), c[1] + pc[k, 1] + 0.15 * np.sin(ang),
+                      c[2] - 1.8 + 0.01 * pc[k, 0] - 0.005 * pc[k, 1] + pz], 1)
+    # kerbs: 3 low (0.4 m) vertical strips, 12 m long, random heading
+    kc = rng.uniform(-extent * 0.7, extent * 0.7, (3, 2))
+    kh = rng.uniform(0, np.pi, 3)
+    j = rng.integers(0, 3, n_kerb)
+    s = rng.uniform(-6, 6, n_kerb)
+    kx, ky = kc[j, 0] + s * np.cos(kh[j]), kc[j, 1] + s * np.sin(kh[j])
+    kerbs = np.stack([c[0] + kx, c[1] + ky, c[2] - 1.8 + 0.01 * kx - 0.005 * ky + rng.uniform(0, 0.4, n_kerb)], 1)
+    tgt = np.concatenate([ground, poles, kerbs], 0) + rng.normal(0, 0.005, (n_map, 3))
+    rng.shuffle(tgt)
+    tgt = tgt.astype(np.float32)
+    # one frame: map points within range of the sensor, in the sensor frame, with range noise
+    d = np.linalg.norm(tgt[:, :2].astype(np.float64) - c[:2], axis=1)
+    near = np.flatnonzero(d < frame_range)
+    sel = rng.choice(near, size=min(n_frame, len(near)), replace=False)
+    Rg, tg = T_gt[:3, :3], T_gt[:3, 3]
+    body = (tgt[sel].astype(np.float64) - tg) @ Rg          # R^T (p - t)
+    body += rng.normal(0, noise, body.shape)
+    return tgt, body.astype(np.float32)
+
+
+def write_pcd_xyzi(path, xyz):
+    """Binary PCD v0.7, fields x y z intensity (float32), like pcl::io::savePCDFileBinary<PointXYZI>."""
+    xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+    n = len(xyz)
+    rec = np.zeros((n, 4), np.float32)
+    rec[:, :3] = xyz
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\n"
+                 "COUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n)).encode("ascii"))
+        f.write(rec.tobytes())

@@ -1,0 +1,67 @@
+"""bench.py as the driver invokes it (`python bench.py --gpus N ...`, no external launcher): the script must spawn one
+rank per GPU itself, refuse to report a smaller job under a bigger name, and gather one record per rank.
+CPU part: DCREG_BENCH_DRYRUN=1 replaces the device work by a synthetic record so that launcher, rendezvous (gloo), fence,
+max-over-ranks and gather run here.  GPU part (-m gpu): the real workload with two ranks sharing the box's one device over
+gloo (control flow only; RCCL with one rank per GPU is what the 8-GPU node runs), both sharding modes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import helpers as h
+
+BENCH = os.path.join(h.REPO, "bench.py")
+
+
+def _bench(args, env_extra, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, BENCH] + args, cwd=h.REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(p):
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])       # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_self_spawn_two_ranks_dry_run():
+    p = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5"], {"DCREG_BENCH_DRYRUN": "1", "DCREG_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _json_line(p)
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["steps"] == 20 and j["warmup"] == 5
+    assert j["ranks"] == [0, 1] and j["rank_seeds"] == [100, 101]     # one record per rank, every rank its own pair
+    assert all(t >= 0.02 for t in j["block_times_s"])                 # max over ranks: rank 1 sleeps twice as long as rank 0
+
+
+def test_refuses_a_job_it_cannot_run():
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 devices")
+    p = _bench(["--gpus", "2"], {})
+    assert p.returncode != 0 and "--gpus 2 requested" in p.stderr and "{" not in p.stdout
+    p = _bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("sharding", ["pairs", "points"])
+def test_two_ranks_on_one_device_real_workload(sharding):
+    p = _bench(["--gpus", "2", "--steps", "20", "--warmup", "20", "--repeats", "3", "--workload", "c2_cylinder_100k", "--sharding", sharding,
+                "--no-cpu-baseline", "--no-configs", "--concurrent-pairs", "0"],
+               {"DCREG_BENCH_BACKEND": "gloo", "DCREG_BENCH_LOCAL_RANK": "0"}, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = _json_line(p)
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["repeats"] == 3 and j["value"] > 0
+    assert j["scaling"] == ("weak" if sharding == "pairs" else "strong")
+    assert j["config"]["rank_pair_seeds"] == [100, 101]
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["final_stats"]["mean_trans_error_m"] < 0.01
+    if sharding == "points":                                          # every rank holds a slice: half the queries per launch
+        assert j["roofline"]["algorithmic_bytes_per_launch"] == 72 * 50_000
