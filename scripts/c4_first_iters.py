@@ -8,7 +8,7 @@ import dcreg_amd
 from dcreg_amd import api
 import bench
 
-scene, n_pts, radius, run_len = bench.WORKLOADS["c4_corridor_1m"]
+W = bench.WORKLOADS["c4_corridor_1m"]; scene, n_pts, radius, run_len = W["scene"], W["n"], W["radius"], W["run_len"]
 tgt, src = bench.make_pair(scene, n_pts, seed=100)
 ctx = dcreg_amd.Context(0)
 ctx.set_target(tgt, radius); ctx.set_source(src)

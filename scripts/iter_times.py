@@ -10,7 +10,7 @@ from dcreg_amd import api
 import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c4_corridor_1m"
-scene, n_pts, radius, run_len = bench.WORKLOADS[wl]
+W = bench.WORKLOADS[wl]; scene, n_pts, radius, run_len = W["scene"], W["n"], W["radius"], W["run_len"]
 tgt, src = bench.make_pair(scene, n_pts, seed=100)
 ctx = dcreg_amd.Context(0)
 for kv in sys.argv[2:]:
