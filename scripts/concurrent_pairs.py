@@ -13,7 +13,7 @@ import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2_cylinder_100k"
 Ps = [int(v) for v in sys.argv[2:]] or [1, 2, 3, 4]
-scene, n_pts, radius, run_len = bench.WORKLOADS[wl]
+W = bench.WORKLOADS[wl]; scene, n_pts, radius, run_len = W["scene"], W["n"], W["radius"], W["run_len"]
 L = api.load()
 dp = C.POINTER(C.c_double)
 T_init = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))

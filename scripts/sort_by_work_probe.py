@@ -11,7 +11,7 @@ from dcreg_amd import api
 import bench
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2_cylinder_100k"
-scene, n_pts, radius, run_len = bench.WORKLOADS[wl]
+W = bench.WORKLOADS[wl]; scene, n_pts, radius, run_len = W["scene"], W["n"], W["radius"], W["run_len"]
 tgt, src = bench.make_pair(scene, n_pts, seed=100)
 T0 = h.pose6d_matrix(0.004, -0.003, 0.002, 0.0002, -0.0001, 0.0004)     # a nearly converged pose
 T1 = h.pose6d_matrix(0.003, -0.002, 0.001, 0.0001, -0.0001, 0.0003)
