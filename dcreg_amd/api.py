@@ -114,7 +114,7 @@ EXPORTS = [
     "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
-    "dcreg_linearize_batch_end", "dcreg_linearize_debug", "dcreg_knn",
+    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_linearize_debug", "dcreg_knn",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
@@ -153,6 +153,10 @@ def load():
     L.dcreg_default_lin_params.argtypes = [C.POINTER(LinParams), C.c_double]
     L.dcreg_linearize.argtypes = [vp, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut)]
     L.dcreg_linearize_batch.argtypes = [vp, C.c_int, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut)]
+    L.dcreg_linearize_batch_begin.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.POINTER(LinParams)]
+    L.dcreg_linearize_batch_begin_warm.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, C.POINTER(LinParams)]
+    L.dcreg_linearize_batch_end.argtypes = [vp, C.c_int, C.POINTER(LinOut)]
+    L.dcreg_reserve_warm_states.argtypes = [vp, C.c_int64]
     L.dcreg_linearize_debug.argtypes = [vp, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut), C.POINTER(LinDebug)]
     L.dcreg_knn.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int, C.c_double, ip, fp]
     L.dcreg_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
@@ -379,6 +383,22 @@ class Context:
         n = Rs.shape[0]
         outs = (LinOut * n)()
         self._check(self._L.dcreg_linearize_batch(self._h, n, _dp(Rs), _dp(ts), C.byref(params), outs), "dcreg_linearize_batch")
+        return [self._out_dict(o) for o in outs]
+
+    def reserve_warm_states(self, n_states):
+        self._check(self._L.dcreg_reserve_warm_states(self._h, int(n_states)), "dcreg_reserve_warm_states")
+
+    def linearize_batch_warm(self, Rs, ts, state_ids, params=None, slot=0):
+        """dcreg_linearize_batch_begin_warm + _end: pose i reads and updates warm-start state state_ids[i] (-1 = cold)."""
+        params = params or default_lin_params()
+        Rs = _f64(Rs).reshape(-1, 9)
+        ts = _f64(ts).reshape(-1, 3)
+        n = Rs.shape[0]
+        ids = np.ascontiguousarray(state_ids, dtype=np.int32).reshape(n)
+        outs = (LinOut * n)()
+        self._check(self._L.dcreg_linearize_batch_begin_warm(self._h, slot, n, _dp(Rs), _dp(ts), ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                             C.byref(params)), "dcreg_linearize_batch_begin_warm")
+        self._check(self._L.dcreg_linearize_batch_end(self._h, slot, outs), "dcreg_linearize_batch_end")
         return [self._out_dict(o) for o in outs]
 
     def knn(self, q, k=5, max_radius=0.0):

@@ -18,7 +18,7 @@ SOURCES = [
     "host/solver.cpp",
     "host/engine.cpp",
 ]
-HEADERS = ["device/kernels.hpp", "device/context.hpp", "host/linalg.hpp", "host/se3.hpp",
+HEADERS = ["device/kernels.hpp", "device/search.hpp", "device/context.hpp", "host/linalg.hpp", "host/se3.hpp",
            "../../include/dcreg.h"]
 
 

@@ -219,6 +219,7 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     rc = build_gap_field(c, radius_hint);
     if (rc) { c->n_tgt = 0; return rc; }
     c->prev_valid = false;   // positions refer to the old sort order
+    c->n_warm_states = 0;
     return DCREG_OK;
 }
 
@@ -251,6 +252,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     c->n_src = n;
     c->aux_valid = false;
     c->prev_valid = false;
+    c->n_warm_states = 0;
     return DCREG_OK;
 }
 
@@ -296,8 +298,13 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
 // the pinned result rows, unpack).  Two slots with their own pose / partial / result buffers let a caller keep one batch
 // on the device while the host works on the other (dcreg_linearize_batch_begin / _end); the blocking entry points use
 // slot 0.  Debug dumps are synchronous and only exist on slot 0.
-static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
-                           dcreg_lin_debug *dbg_host) {
+static void free_tmp(LinSlot &S) {
+    for (void *p2 : S.tmp_dev) (void)hipFree(p2);
+    S.tmp_dev.clear();
+}
+
+static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
+                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host) {
     if (!c) return DCREG_E_INVALID;
     if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
     LinSlot &S = c->slots[slot];
@@ -333,34 +340,54 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         HIP_TRY(c, hipHostGetDevicePointer((void **)&S.d_out, S.h_out, 0));
         S.out_cap = cap;
     }
-    PoseArg one{};
-    const PoseArg *d_poses = nullptr;
-    if (n_poses == 1) {
-        std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
-    } else {
-        if (ensure(c, S.d_poses, S.poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
-        S.h_poses.resize((size_t)n_poses);      // stays alive until end(): source of the asynchronous copy
-        for (int i = 0; i < n_poses; ++i) { std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t)); }
-        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
-        d_poses = S.d_poses;
-    }
-    DebugDev dd{};
     const int64_t n = c->n_src;
     a.prev = nullptr; a.prev_stride = 0;
-    if (c->opt_warm && n_poses == 1) {
-        if (!c->prev_valid) {
-            const size_t stride = ((size_t)n + 63) & ~(size_t)63;
-            if (ensure(c, c->d_prev, c->prev_cap, 5 * stride)) return DCREG_E_NOMEM;
-            HIP_TRY(c, hipMemsetAsync(c->d_prev, 0xFF, sizeof(uint32_t) * 5 * stride, c->stream));
-            c->prev_stride = stride; c->prev_valid = true;
+    a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
+    PoseArg one{};
+    const PoseArg *d_poses = nullptr;
+    if (n_poses == 1 && !state_ids) {
+        std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
+        one.state = 0;
+        if (c->opt_warm) {      // single pose: the ctx's own state
+            if (!c->prev_valid) {
+                const size_t stride = ((size_t)n + 63) & ~(size_t)63;
+                if (ensure(c, c->d_prev, c->prev_cap, 5 * stride)) return DCREG_E_NOMEM;
+                HIP_TRY(c, hipMemsetAsync(c->d_prev, 0xFF, sizeof(uint32_t) * 5 * stride, c->stream));
+                c->prev_stride = stride; c->prev_valid = true;
+            }
+            a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
         }
-        a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
+    } else {
+        // batched poses: each may own one of the reserved warm-start states (dcreg_reserve_warm_states); -1 = search cold
+        const bool use_states = state_ids && c->opt_warm && c->n_warm_states > 0;
+        if (state_ids && c->opt_warm) {
+            std::vector<uint8_t> seen((size_t)std::max<int64_t>(c->n_warm_states, 1), 0);
+            for (int i = 0; i < n_poses; ++i) {
+                const int32_t sid = state_ids[i];
+                if (sid < 0) continue;
+                if ((int64_t)sid >= c->n_warm_states) { c->fail("warm state %d was not reserved (dcreg_reserve_warm_states: %lld)", sid, (long long)c->n_warm_states); return DCREG_E_INVALID; }
+                if (seen[(size_t)sid]) { c->fail("warm state %d is used by two poses of one launch", sid); return DCREG_E_INVALID; }
+                seen[(size_t)sid] = 1;
+            }
+        }
+        if (ensure(c, S.d_poses, S.poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
+        S.h_poses.resize((size_t)n_poses);      // stays alive until end(): source of the asynchronous copy
+        for (int i = 0; i < n_poses; ++i) {
+            std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t));
+            S.h_poses[i].state = (use_states && state_ids[i] >= 0) ? (uint32_t)state_ids[i] : kNoIdx;
+            S.h_poses[i].pad_ = 0;
+        }
+        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
+        d_poses = S.d_poses;
+        if (use_states) { a.prev = c->d_prev_batch; a.prev_stride = (uint32_t)c->prev_batch_stride; }
     }
-    S.tmp_dev.clear();
+    DebugDev dd{};
+    free_tmp(S);
     if (dbg_host) {
+        bool oom = false;
         auto alloc = [&](size_t bytes, int fill) -> void * {
             void *p2 = nullptr;
-            if (hipMalloc(&p2, bytes) != hipSuccess) return nullptr;
+            if (hipMalloc(&p2, bytes) != hipSuccess) { oom = true; return nullptr; }
             (void)hipMemsetAsync(p2, fill, bytes, c->stream);
             S.tmp_dev.push_back(p2);
             return p2;
@@ -373,6 +400,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
         if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 8 * ((n + 63) / 64 + 4), 0);
+        if (oom) { free_tmp(S); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
     FinArgs fin{S.d_tickets, S.d_out, seq};
@@ -381,23 +409,47 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const bool timed = slot == 0 && c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
     if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
-    if (dbg_host)
-        hipLaunchKernelGGL((k_linearize<1, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd);
-    else if (fused)
-        hipLaunchKernelGGL((k_linearize<0, true>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd);
-    else
-        hipLaunchKernelGGL((k_linearize<0, false>), grid, dim3(kBlock), (size_t)c->opt_lds_pad, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd);
+    const size_t lds = (size_t)c->opt_lds_pad;
+#define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                            \
+    hipLaunchKernelGGL((k_linearize<MODE, FUSED, FAST>), grid, dim3(kBlock), lds, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, \
+                       S.d_partials, nbx, fin, dd)
+    if (c->opt_fast_plane) {
+        if (dbg_host) DCREG_LAUNCH_LIN(1, true, true);
+        else if (fused) DCREG_LAUNCH_LIN(0, true, true);
+        else DCREG_LAUNCH_LIN(0, false, true);
+    } else {
+        if (dbg_host) DCREG_LAUNCH_LIN(1, true, false);
+        else if (fused) DCREG_LAUNCH_LIN(0, true, false);
+        else DCREG_LAUNCH_LIN(0, false, false);
+    }
+#undef DCREG_LAUNCH_LIN
+    {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { free_tmp(S); c->fail("k_linearize launch failed: %s", hipGetErrorString(le)); return DCREG_E_DEVICE; }
+    }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
-    if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
+    if (!fused || dbg_host) {
+        if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { free_tmp(S); c->fail("k_finalize launch failed: %s", hipGetErrorString(le)); return DCREG_E_DEVICE; }
+    }
     if (dbg_host) {
-        if (dd.nn_idx) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.nn_d2) HIP_TRY(c, hipMemcpyAsync(dbg_host->nn_d2, dd.nn_d2, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.flag) HIP_TRY(c, hipMemcpyAsync(dbg_host->flag, dd.flag, n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.normal) HIP_TRY(c, hipMemcpyAsync(dbg_host->normal, dd.normal, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.r) HIP_TRY(c, hipMemcpyAsync(dbg_host->r, dd.r, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.s) HIP_TRY(c, hipMemcpyAsync(dbg_host->s, dd.s, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.stats) HIP_TRY(c, hipMemcpyAsync(dbg_host->stats, dd.stats, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
-        if (dd.clocks) HIP_TRY(c, hipMemcpyAsync(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 8 * ((n + 63) / 64), hipMemcpyDeviceToHost, c->stream));
+        hipError_t ce = hipSuccess;
+        auto back = [&](void *dst, const void *srcp, size_t bytes) { if (ce == hipSuccess && srcp) ce = hipMemcpyAsync(dst, srcp, bytes, hipMemcpyDeviceToHost, c->stream); };
+        back(dbg_host->nn_idx, dd.nn_idx, sizeof(int32_t) * 5 * n);
+        back(dbg_host->nn_d2, dd.nn_d2, sizeof(float) * 5 * n);
+        back(dbg_host->flag, dd.flag, (size_t)n);
+        back(dbg_host->normal, dd.normal, sizeof(double) * 3 * n);
+        back(dbg_host->r, dd.r, sizeof(double) * n);
+        back(dbg_host->s, dd.s, sizeof(double) * n);
+        back(dbg_host->stats, dd.stats, sizeof(uint32_t) * n);
+        back(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 8 * ((n + 63) / 64));
+        if (ce != hipSuccess) {
+            (void)hipStreamSynchronize(c->stream);
+            free_tmp(S);
+            c->fail("copying the debug dump back failed: %s", hipGetErrorString(ce));
+            return DCREG_E_DEVICE;
+        }
     }
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
@@ -429,8 +481,7 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
         }
     }
     S.tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
-    for (void *p2 : S.tmp_dev) (void)hipFree(p2);
-    S.tmp_dev.clear();
+    free_tmp(S);
     if (S.sync) HIP_TRY(c, hipGetLastError());
     if (S.timed) {
         float ms = 0.f;
@@ -460,7 +511,7 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
 int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
                      dcreg_lin_out *outs, dcreg_lin_debug *dbg_host) {
     if (c && !outs) { c->fail("null argument"); return DCREG_E_INVALID; }
-    int rc = linearize_begin(c, 0, n_poses, R9, t3, p, dbg_host);
+    int rc = linearize_begin(c, 0, n_poses, R9, t3, nullptr, p, dbg_host);
     if (rc) return rc;
     rc = linearize_end(c, 0, outs);
     if (rc && c) c->slots[0].pending = false;
@@ -538,7 +589,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_gap};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_prev_batch, c->d_gap};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -569,6 +620,8 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
     else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
+    else if (k == "xcd_chunk") c->opt_xcd_chunk = (int)v;   // 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks round-robin
+    else if (k == "fast_plane_fit") c->opt_fast_plane = v != 0.0;   // 1 (default) = plane_fit_qr_fast, 0 = the Eigen-shaped plane_fit_qr
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;
@@ -594,7 +647,25 @@ int dcreg_linearize_batch(dcreg_ctx *c, int n, const double *R9, const double *t
     return launch_linearize(c, n, R9, t3, p, outs, nullptr);
 }
 int dcreg_linearize_batch_begin(dcreg_ctx *c, int slot, int n, const double *R9, const double *t3, const dcreg_lin_params *p) {
-    return linearize_begin(c, slot, n, R9, t3, p, nullptr);
+    return linearize_begin(c, slot, n, R9, t3, nullptr, p, nullptr);
+}
+int dcreg_linearize_batch_begin_warm(dcreg_ctx *c, int slot, int n, const double *R9, const double *t3, const int32_t *state_ids,
+                                     const dcreg_lin_params *p) {
+    return linearize_begin(c, slot, n, R9, t3, state_ids, p, nullptr);
+}
+int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
+    if (!c) return DCREG_E_INVALID;
+    if (n_states < 0) { c->fail("negative state count"); return DCREG_E_INVALID; }
+    for (const LinSlot &S : c->slots) if (S.pending) { c->fail("a linearisation is still in flight"); return DCREG_E_STATE; }
+    c->n_warm_states = 0;
+    if (n_states == 0 || c->n_src <= 0) return DCREG_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t stride = ((size_t)c->n_src + 63) & ~(size_t)63;
+    if (ensure(c, c->d_prev_batch, c->prev_batch_cap, 5 * stride * (size_t)n_states)) return DCREG_E_NOMEM;
+    HIP_TRY(c, hipMemsetAsync(c->d_prev_batch, 0xFF, sizeof(uint32_t) * 5 * stride * (size_t)n_states, c->stream));
+    c->prev_batch_stride = stride;
+    c->n_warm_states = n_states;
+    return DCREG_OK;
 }
 int dcreg_linearize_batch_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) { return linearize_end(c, slot, outs); }
 int dcreg_linearize_debug(dcreg_ctx *c, const double R[9], const double t[3], const dcreg_lin_params *p, dcreg_lin_out *out, dcreg_lin_debug *dbg) {

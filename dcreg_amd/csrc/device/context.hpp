@@ -61,6 +61,10 @@ struct dcreg_ctx {
     uint32_t *d_prev = nullptr; size_t prev_cap = 0;
     size_t prev_stride = 0;
     bool prev_valid = false;       // false -> cleared to "none" before the next single-pose linearisation
+    // batched launches: n_warm_states states of the same layout, [state][5][prev_batch_stride] (dcreg_reserve_warm_states)
+    uint32_t *d_prev_batch = nullptr; size_t prev_batch_cap = 0;
+    size_t prev_batch_stride = 0;
+    int64_t n_warm_states = 0;
 
     // build scratch
     float *d_stage = nullptr; size_t stage_cap = 0;
@@ -88,6 +92,8 @@ struct dcreg_ctx {
     bool need_set_device = true;
     unsigned long long seq = 0;
     int opt_lds_pad = 0;
+    int opt_xcd_chunk = 0;         // query-block -> XCD mapping (kernels.hpp xcd_remap)
+    bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
     bool opt_keep_source_order = false;   // experiments only

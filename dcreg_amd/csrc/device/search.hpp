@@ -1,0 +1,961 @@
+// Per-thread device functions of the DCReg hot path (gfx950): exact 5-NN on the cell grid, 5x3 plane fit, point-to-plane
+// row (DCReg/src/icp_test_runner.cpp:1714-1907).  Included by kernels.hpp (the __global__ kernels and the reductions).
+//
+// The same functions also compile for the host when DCREG_HOST_EMUL is defined: tests/host_emul/ builds them with a small
+// shim (float4, bit casts, a fake threadIdx) into a TEST-ONLY library that replays the device algorithm on the CPU, so the
+// search logic (exactness on ties / borders / empty space, visit counts) and the plane fit can be checked against the
+// oracle without a GPU (tests/test_host_emul.py).  It is test infrastructure like oracle/: nothing under dcreg_amd/ links
+// or loads it and libdcreg_hip.so has no host path.
+//
+// Layout in HBM
+//   target : float4 {x,y,z,bits(orig_idx)} sorted by linear grid cell (x fastest) + cell_start[n_cells+1]
+//            -> the three x-adjacent cells of one (y,z) row are ONE contiguous run of points
+//   source : float4 {x,y,z,bits(orig_idx)} sorted by the Hilbert-curve key of the body-frame position, so the 64
+//            lanes of a wave walk neighbouring cells (a rigid pose keeps neighbours neighbours)
+// Arithmetic: k-NN distances float32, non-fused, summed x,y,z in that order (what FLANN's L2 functor does
+// and what the oracle does); everything after the neighbour set is fp64, like the reference.
+#pragma once
+#include <stdint.h>
+#if defined(DCREG_HOST_EMUL)
+#include "host_emul_shim.hpp"
+#define DCREG_DEVFN inline
+#define DCREG_ON_DEVICE 0
+#else
+#include <hip/hip_runtime.h>
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "these kernels are written for gfx950 (CDNA4): inline ISA, wave64 DPP, sc1 coherence protocol"
+#endif
+#define DCREG_DEVFN __device__ __forceinline__
+#define DCREG_ON_DEVICE 1
+#endif
+
+namespace dcreg {
+
+#if DCREG_ON_DEVICE
+DCREG_DEVFN float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+#define DCREG_STAT(field) ((void)0)
+#else
+inline float med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+#define DCREG_STAT(field) (++emu_stats.field)
+#endif
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kSlots = 32;           // doubles per partial row
+constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
+
+struct GridDev {
+    double ox, oy, oz;   // origin (min corner)
+    double inv_h, h;
+    int nx, ny, nz;
+    uint32_t n_pts;
+    const uint32_t *cell_start;   // [nx*ny*nz + 1]
+    const float4 *pts;            // sorted target
+    const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
+    int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
+};
+
+struct PoseArg {
+    double R[9]; double t[3];
+    uint32_t state;      // batched launches: which warm-start state this pose reads and updates (kNoIdx = search cold); single pose: 0
+    uint32_t pad_;
+};
+
+struct LinArgs {
+    double radius_sq;             // R^2 in double (gate :1726)
+    float radius_sq_f;            // smallest float >= R^2 (candidate prefilter)
+    double max_thick_sq, min_norm, w_slope, w_min;
+    int use_wd;
+    int max_ring;                 // rings needed to cover the radius
+    uint32_t *prev;               // [5][prev_stride] sorted-target positions of each query's last neighbour set, or null
+    uint32_t prev_stride;
+    uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
+    int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
+    double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
+};
+
+// ---------------------------------------------------------------- k-NN heaps (sorted, K entries)
+
+// Exact heap: key = (float bits of d2) << 32 | original index -> total order (d2, idx), ties -> lower index.
+template <int K_>
+struct HeapExact {
+    static constexpr int K = K_;
+    uint64_t key[K];
+    uint32_t pos[K];
+    uint32_t n_eval;     // candidates evaluated (statistics only; dead code unless read)
+    uint32_t n_shell;    // outermost shell scanned
+    DCREG_DEVFN void init(float bound_f) {
+        const uint64_t bound = ((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
+        n_eval = 0; n_shell = 1;
+    }
+    DCREG_DEVFN void push(float d2, uint32_t idx, uint32_t p, bool valid = true) {
+        n_eval += valid ? 1u : 0u;
+        const uint64_t k = ((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)idx;
+        if (valid && k < key[K - 1]) {
+            key[K - 1] = k; pos[K - 1] = p;
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                const bool sw = key[j] < key[j - 1];
+                const uint64_t ka = key[j - 1], kb = key[j];
+                const uint32_t pa = pos[j - 1], pb = pos[j];
+                key[j - 1] = sw ? kb : ka; key[j] = sw ? ka : kb;
+                pos[j - 1] = sw ? pb : pa; pos[j] = sw ? pa : pb;
+            }
+        }
+    }
+    DCREG_DEVFN float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)); }
+    DCREG_DEVFN float dist(int j) const { return __uint_as_float((uint32_t)(key[j] >> 32)); }
+    DCREG_DEVFN bool full() const { return pos[K - 1] != kNoIdx; }
+};
+
+// Fast heap: 32-bit keys (d2 only, strict <), branch-light insertion.  It yields the exact neighbour SET unless some
+// point outside the final heap has d2 == the K-th best d2; `outside_min` tracks the smallest d2 that was ever kept out
+// (rejected candidates and evicted entries alike: max(d2, K-th best before the push) is exactly that value), so the
+// tie is detected exactly and the caller re-runs the exact heap.  Order among equal d2 inside the heap is fixed
+// afterwards (canonical (d2, idx) order).
+template <int K_>
+struct HeapFast {
+    static constexpr int K = K_;
+    float d[K];
+    uint32_t pos[K];
+    float outside_min;   // smallest d2 among all points seen that are not in the heap
+    uint32_t n_eval, n_shell;
+    DCREG_DEVFN void init(float bound_f) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { d[i] = bound_f; pos[i] = kNoIdx; }
+        outside_min = __builtin_inff();
+        n_eval = 0; n_shell = 1;
+    }
+    // valid == false: the slot is padding (d2 must then be +inf).  Branch-free: with 64 queries per wave some lane
+    // accepts almost every candidate, so a divergent "if (d2 < worst)" is taken anyway and only adds exec-mask
+    // juggling and merge copies.  Sorted insertion without a dependency chain: entry i becomes the median of
+    // (d[i-1], d[i], d2); positions follow the same selection through the masks c[i] = d2 < d[i] (ties stay behind).
+    DCREG_DEVFN void push(float d2, uint32_t /*idx*/, uint32_t p, bool valid = true) {
+        n_eval += valid ? 1u : 0u;
+#if DCREG_ON_DEVICE
+        if constexpr (K == 5) {
+            // 21 VALU instructions, written out: the compiler's select canonicalisation turns the nine position
+            // selects into 13-20 when it sees several pushes at once.  All compares read the OLD distances and sit
+            // at least five instructions ahead of the v_cndmask that consumes their SGPR mask.
+            unsigned long long m0, m1, m2, m3, m4;
+            float t;
+            asm("v_cmp_lt_f32_e64 %[m0], %[x], %[d0]\n\t"
+                "v_cmp_lt_f32_e64 %[m1], %[x], %[d1]\n\t"
+                "v_cmp_lt_f32_e64 %[m2], %[x], %[d2]\n\t"
+                "v_cmp_lt_f32_e64 %[m3], %[x], %[d3]\n\t"
+                "v_cmp_lt_f32_e64 %[m4], %[x], %[d4]\n\t"
+                "v_max_f32_e32 %[t], %[x], %[d4]\n\t"
+                "v_min_f32_e32 %[om], %[om], %[t]\n\t"
+                "v_med3_f32 %[d4], %[d3], %[d4], %[x]\n\t"
+                "v_med3_f32 %[d3], %[d2], %[d3], %[x]\n\t"
+                "v_med3_f32 %[d2], %[d1], %[d2], %[x]\n\t"
+                "v_med3_f32 %[d1], %[d0], %[d1], %[x]\n\t"
+                "v_min_f32_e32 %[d0], %[d0], %[x]\n\t"
+                "v_cndmask_b32_e64 %[p4], %[p4], %[p], %[m4]\n\t"
+                "v_cndmask_b32_e64 %[p4], %[p4], %[p3], %[m3]\n\t"
+                "v_cndmask_b32_e64 %[p3], %[p3], %[p], %[m3]\n\t"
+                "v_cndmask_b32_e64 %[p3], %[p3], %[p2], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p1], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p0], %[m0]\n\t"
+                "v_cndmask_b32_e64 %[p0], %[p0], %[p], %[m0]"
+                : [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [d4] "+v"(d[4]),
+                  [p0] "+v"(pos[0]), [p1] "+v"(pos[1]), [p2] "+v"(pos[2]), [p3] "+v"(pos[3]), [p4] "+v"(pos[4]),
+                  [om] "+v"(outside_min), [t] "=&v"(t),
+                  [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4)
+                : [x] "v"(d2), [p] "v"(p));
+        } else
+#endif
+        {
+            outside_min = fminf(outside_min, fmaxf(d2, d[K - 1]));
+            bool c[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) c[i] = d2 < d[i];
+#pragma unroll
+            for (int i = K - 1; i >= 1; --i) {
+                pos[i] = c[i - 1] ? pos[i - 1] : (c[i] ? p : pos[i]);
+                d[i] = med3f(d[i - 1], d[i], d2);
+            }
+            pos[0] = c[0] ? p : pos[0];
+            d[0] = fminf(d[0], d2);
+        }
+    }
+    DCREG_DEVFN float worst_d2() const { return d[K - 1]; }
+    DCREG_DEVFN float dist(int j) const { return d[j]; }
+    DCREG_DEVFN bool full() const { return pos[K - 1] != kNoIdx; }
+    // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
+    DCREG_DEVFN bool boundary_tie() const { return full() && outside_min == d[K - 1]; }
+};
+
+// float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
+DCREG_DEVFN float dist2_nofma(float qx, float qy, float qz, const float4 &c) {
+#pragma clang fp contract(off)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 dxy = f2{qx, qy} - f2{c.x, c.y};       // (x,y) is the register pair a dwordx4 load leaves aligned for v_pk_*
+    dxy = dxy * dxy;
+    const float dz = qz - c.z;
+    float d2 = dxy.x + dxy.y;
+    d2 = d2 + dz * dz;
+    return d2;
+}
+
+// utils.hpp:630-636 pointBodyToGlobal: double arithmetic (separate mul/add, as un-fused x86 code does), float store
+DCREG_DEVFN void body_to_global(const PoseArg &P, double px, double py, double pz, float &qx, float &qy, float &qz) {
+#pragma clang fp contract(off)
+    qx = (float)(P.R[0] * px + P.R[1] * py + P.R[2] * pz + P.t[0]);
+    qy = (float)(P.R[3] * px + P.R[4] * py + P.R[5] * pz + P.t[1]);
+    qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
+}
+
+// one run of the ring walk: four candidates per trip, their loads issued together (slots past the end are clamped
+// loads that push +inf)
+template <class H>
+DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp);
+
+DCREG_DEVFN int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <class H>
+DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
+
+// Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
+// Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
+// divergent candidate loop costs one ds_read instead of a 9-way register select.
+struct RunList {
+    uint32_t s[9][kBlock];
+    uint32_t e[9][kBlock];
+    float gap2[9][kBlock];     // squared distance from the query to the row's (y,z) slab
+};
+
+template <class H>
+DCREG_DEVFN void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p, bool valid) {
+    const float d2 = dist2_nofma(qx, qy, qz, c);
+    hp.push(valid ? d2 : __builtin_inff(), __float_as_uint(c.w), p, valid);     // padding slots can never enter
+}
+
+template <class H>
+DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
+    DCREG_STAT(runs);
+    for (uint32_t p = s; p < e; p += 4) {
+        DCREG_STAT(trips);
+        const uint32_t last = e - 1;
+        float4 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = g.pts[min(p + u, last)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) push_point<H>(hp, qx, qy, qz, c[u], p + u, p + u < e);
+    }
+}
+
+// Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
+// Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
+// closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
+// the ball covers the search radius.
+template <class H>
+DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
+                                           int max_ring, H &hp, unsigned long long *stamp = nullptr) {   // max_ring < 0: unbounded
+    hp.init(bound_f);
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+    const double lim = (double)max_ring + 1.0;
+    if (max_ring >= 0) {
+        // bounded search: a query farther than max_ring cells from the grid has no neighbour inside the radius
+        if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
+    }
+    const double big = 1.0e9;
+    const double flx = floor(fmin(fmax(fx, -big), big)), fly = floor(fmin(fmax(fy, -big), big)), flz = floor(fmin(fmax(fz, -big), big));
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    if (max_ring < 0) {   // unbounded: enough rings to sweep the whole grid from this cell
+        const int ex = max(abs(cx), abs(cx - (nx - 1))), ey = max(abs(cy), abs(cy - (ny - 1))), ez = max(abs(cz), abs(cz - (nz - 1)));
+        max_ring = max(ex, max(ey, ez)) + 1;
+    }
+
+    // ---- rings 0+1, phase A: the 9 (y,z) rows of the 3x3x3 block, each one contiguous x-run; all 18 table
+    // loads are issued together, empty / out-of-reach rows are dropped, nearest rows come first
+    const int tid = threadIdx.x;
+    int nrun = 0;
+    {
+        const float hf = (float)g.h;
+        const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
+        const float gxl = frx * hf, gxh = (1.f - frx) * hf;
+        const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
+        // visiting order (dy,dz): centre, 4 edge rows, 4 corner rows
+        constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        uint32_t rs[9], re[9];
+        float g2s[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const float gy = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.f), gz = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.f);
+            const float g2 = (gy * gy + gz * gz) * 0.99999f;
+            g2s[r] = g2;
+            // x-cells of this row the ball of radius sqrt(bound) can reach (conservative): a tight bound (warm
+            // start) trims the three-cell run to one or two cells, or drops the row
+            const float xr = sqrtf(fmaxf(bound_f - g2, 0.f)) * 1.00001f + 1e-6f * hf;
+            const int x0 = clampi(cx - (gxl <= xr ? 1 : 0), 0, nx), x1 = clampi(cx + 1 + (gxh <= xr ? 1 : 0), 0, nx);   // [x0, x1)
+            const int y = cy + DY[r], z = cz + DZ[r];
+            const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz && !(g2 > bound_f);
+            const int64_t row = ok ? ((int64_t)z * ny + y) * nx : 0;
+            rs[r] = ok ? g.cell_start[row + x0] : 0u;
+            re[r] = ok ? g.cell_start[row + x1] : 0u;
+            if (ok) { DCREG_STAT(table_loads); DCREG_STAT(table_loads); }
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            if (re[r] > rs[r]) {
+                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2[nrun][tid] = g2s[r];
+                ++nrun;
+            }
+        }
+    }
+    if (stamp) stamp[0] = clock64();
+    // ---- phase B: flattened walk over the runs (the wave iterates max-over-lanes of the total, not the
+    // sum of per-row maxima), 4 candidates in flight per trip
+    {
+        int ri = 0;
+        uint32_t p = 0, e = 0;
+        // switch to the next listed row (one per call, no inner loop: a row that the K-th best has meanwhile put out
+        // of reach becomes an empty run and costs one idle trip, which is rare once the search is bounded)
+        auto next_run = [&]() {
+            const float g2 = rl.gap2[ri][tid];
+            const uint32_t s_ = rl.s[ri][tid], e_ = rl.e[ri][tid];
+            ++ri;
+            const bool keep = !(g2 > hp.worst_d2());
+            p = keep ? s_ : 0u; e = keep ? e_ : 0u;
+            DCREG_STAT(runs);
+        };
+        // software-pipelined over two register sets, unrolled twice (no copies): the loads of trip t+1 are in flight
+        // while trip t is inserted (a third set, two trips ahead: +2.5 % at 100 k points, -8 % at 1 M where the extra
+        // registers cost a wave of occupancy).  Slots past the end of a run are clamped loads that push +inf.
+        constexpr int W = 4;
+        struct Slot { float4 c[W]; uint32_t cp, ce; bool live; };
+        bool have = nrun > 0;
+        if (have) next_run();
+        auto fetch = [&](Slot &sl) {
+            sl.live = have; sl.cp = p; sl.ce = e;
+            if (have) {
+                DCREG_STAT(trips);
+                const uint32_t last = max(e, 1u) - 1u;
+#pragma unroll
+                for (int u = 0; u < W; ++u) sl.c[u] = g.pts[min(p + u, last)];
+                p += W;
+                if (p >= e) {
+                    have = ri < nrun;
+                    if (have) next_run();
+                }
+            }
+        };
+        auto consume = [&](const Slot &sl) {
+#pragma unroll
+            for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, sl.c[u], sl.cp + u, sl.cp + u < sl.ce);
+        };
+        Slot A, B;
+        fetch(A);
+        while (A.live) {
+            fetch(B); consume(A);
+            if (!B.live) break;
+            fetch(A); consume(B);
+        }
+    }
+    if (stamp) stamp[1] = clock64();
+    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+}
+
+// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
+// (fx,fy,fz) = query position in cell units.  Ring kk is walked as its six FACES, not as (2kk+1)^2 rows:
+//   * a face whose cell layer lies beyond the current K-th best is dropped by arithmetic alone;
+//   * the empty-space field is read ONCE per remaining face, at the face cell under the query: if its nearest occupied
+//     cell is farther (Chebyshev) than the cap the K-th-best ball cuts out of the face, the whole cap is empty - a query
+//     hovering 6 cells off a wall asks 6 bytes per ring instead of walking ~250 empty cells;
+//   * the rows of a face are visited CENTRE-OUT (the row under the query first), so the heap holds near points before the
+//     far rows are tested, and each side stops at the first row the ball no longer reaches (distances grow monotonically);
+//   * every row's x-run is trimmed to the cells the K-th-best ball can still reach, as before.
+// Exact: a cell is skipped only when its minimal distance to the query exceeds the K-th best, or when the field proves it
+// empty.  Faces: +-z (rows y in [cy-kk, cy+kk]), +-y (rows z in (cz-kk, cz+kk)), +-x (single cells, y and z in the open range).
+// slab distance (metres, float) from the query (cell cq, cell coordinate f) to cell index c along one axis
+DCREG_DEVFN float slab_dist(int c, int cq, double f, float hf) {
+    return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
+}
+
+// centre-out offsets 0, +1, -1, +2, -2, ... up to +-omax; a side is closed when its row falls outside the grid on that side
+// or the caller reports that the ball no longer reaches it
+struct CentreOut {
+    int o, omax;
+    bool plus, up, dn;      // plus: the next offset to hand out is +o (else -o)
+    DCREG_DEVFN void init(int omax_) { o = 0; omax = omax_; plus = true; up = true; dn = true; }
+    // next signed offset, or false when both sides are exhausted
+    DCREG_DEVFN bool next(int &off) {
+        for (;;) {
+            if (o == 0) { o = 1; plus = true; off = 0; return true; }
+            if (o > omax || !(up || dn)) return false;
+            if (plus) { plus = false; if (up) { off = o; return true; } }
+            else { plus = true; const int oo = o; ++o; if (dn) { off = -oo; return true; } }
+        }
+    }
+    DCREG_DEVFN void close(int off) { if (off > 0) up = false; else if (off < 0) dn = false; else { /* centre row: sides stay open */ } }
+};
+
+template <class H>
+DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const float hf = (float)g.h;
+    // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
+    int k0 = 1;
+    if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
+        const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
+        k0 = max(1, f - 1);
+    }
+    // nearer side of each axis first
+    const bool zf = (fz - (double)cz) >= 0.5, yf = (fy - (double)cy) >= 0.5, xf = (fx - (double)cx) >= 0.5;
+    for (int k = k0; k < max_ring; ++k) {
+        // after ring k: every point within k*h (minus a rounding guard) has been seen
+        const double safe = (double)k * g.h * (1.0 - 1e-9);
+        const double safe2 = safe * safe * (1.0 - 1e-6);
+        if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
+        if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
+        const int kk = k + 1;                                   // scan shell kk
+        hp.n_shell = (uint32_t)kk;
+        // ONE loop body for the six faces (a single copy of the row scan in the instruction stream): face f = 2 * axis + side,
+        // axis 0 = z, 1 = y, 2 = x.  A face is a centre-out double loop over (z offset, y offset) around (zc, yc):
+        //   z face, layer zl : zc = zl, no z offsets;  yc = cy, y offsets up to kk;      x-cells [cx-kk, cx+kk]
+        //   y face, layer yl : zc = cz, z offsets up to kk-1;  yc = yl, no y offsets;    x-cells [cx-kk, cx+kk]
+        //   x face, layer xl : zc = cz, z offsets up to kk-1;  yc = cy, up to kk-1;      the single cell xl
+#pragma unroll 1
+        for (int f = 0; f < 6; ++f) {
+            const int axis = f >> 1;
+            const bool first = (f & 1) == 0;
+            const bool lean = axis == 0 ? zf : (axis == 1 ? yf : xf);
+            const int sgn = (first == lean) ? 1 : -1;
+            const int cq = axis == 0 ? cz : (axis == 1 ? cy : cx);
+            const int nq = axis == 0 ? nz : (axis == 1 ? ny : nx);
+            const double fq = axis == 0 ? fz : (axis == 1 ? fy : fx);
+            const int layer = cq + sgn * kk;
+            if (layer < 0 || layer >= nq) continue;
+            const float gl = slab_dist(layer, cq, fq, hf);
+            const float gl2 = gl * gl;
+            if (gl2 * 0.99999f > hp.worst_d2()) continue;       // the whole cell layer lies beyond the K-th best
+            DCREG_STAT(faces);
+            if (g.gap) {
+                // the cap the K-th-best ball cuts out of this face reaches floor(rho / h) + 1 cells from the face cell under the
+                // query; the field value there is the Chebyshev distance to the nearest occupied cell: nothing closer -> cap empty
+                const float rho = sqrtf(fmaxf(hp.worst_d2() - gl2 * 0.99999f, 0.f)) * 1.00001f + 1e-6f * hf;
+                const double rho_c = (double)rho * g.inv_h;     // may be astronomically large (unbounded searches): compare before converting
+                const int need = rho_c >= (double)kk ? kk : min(kk, (int)rho_c + 1);
+                const int xq = clampi(axis == 2 ? layer : cx, 0, nx - 1), yq = clampi(axis == 1 ? layer : cy, 0, ny - 1),
+                          zq = clampi(axis == 0 ? layer : cz, 0, nz - 1);
+                DCREG_STAT(table_loads);
+                const int gv = (int)g.gap[((int64_t)zq * ny + yq) * nx + xq];
+                const int free_r = gv == 255 ? g.gap_cap + 1 : gv;   // every cell closer (Chebyshev) than free_r to that cell is empty
+                if (need < free_r) { DCREG_STAT(face_skips); continue; }
+            }
+            const int zc = axis == 0 ? layer : cz, yc = axis == 1 ? layer : cy;
+            const int ozmax = axis == 0 ? 0 : kk - 1, oymax = axis == 0 ? kk : (axis == 1 ? 0 : kk - 1);
+            const int xa = axis == 2 ? layer : cx - kk, xb = axis == 2 ? layer : cx + kk;
+            const float gx2 = axis == 2 ? gl2 : 0.f;            // x faces: the cell's x distance is fixed
+            CentreOut oz;
+            oz.init(ozmax);
+            int dz;
+            while (oz.next(dz)) {
+                const int z = zc + dz;
+                if (z < 0) { if (dz < 0) oz.dn = false; continue; }
+                if (z >= nz) { if (dz > 0) oz.up = false; continue; }
+                const float gz = slab_dist(z, cz, fz, hf);
+                const float gz2 = gz * gz;
+                // offsets are taken around the query's own cell whenever there are several: distances grow monotonically per side
+                if ((gx2 + gz2) * 0.99999f > hp.worst_d2()) { oz.close(dz); continue; }
+                CentreOut oy;
+                oy.init(oymax);
+                int dy;
+                while (oy.next(dy)) {
+                    const int y = yc + dy;
+                    if (y < 0) { if (dy < 0) oy.dn = false; continue; }
+                    if (y >= ny) { if (dy > 0) oy.up = false; continue; }
+                    const float gy = slab_dist(y, cy, fy, hf);
+                    const float w = hp.worst_d2();
+                    DCREG_STAT(rows);
+                    if ((gx2 + gz2 + gy * gy) * 0.99999f > w) { oy.close(dy); continue; }
+                    // x-cells of this (y,z) row the ball still reaches (conservative), clipped to the ring and the grid
+                    const float dyz = (gz2 + gy * gy) * 0.99999f;
+                    const float xr = sqrtf(fmaxf(w - dyz, 0.f)) * 1.00001f + 1e-6f * hf;
+                    const double xr_c = (double)xr * g.inv_h;
+                    const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
+                    const int x0 = max(max(xa, xmin), 0), x1 = min(min(xb, xmax), nx - 1) + 1;
+                    if (x1 <= x0) continue;
+                    const int64_t r = ((int64_t)z * ny + y) * nx;
+                    DCREG_STAT(table_loads); DCREG_STAT(table_loads);
+                    scan_run<H>(g, g.cell_start[r + x0], g.cell_start[r + x1], qx, qy, qz, hp);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- exact K-NN of one query (fast path + fallback)
+// Runs the 32-bit-key search; if (and only if) a point outside the result ties with the K-th best distance,
+// re-runs the exact 64-bit-key search for this lane.  Output: neighbours in canonical (d2, idx) order.
+template <int K>
+struct KnnResult {
+    float d2[K];
+    uint32_t idx[K];     // original target index
+    float4 pt[K];        // neighbour coordinates (w = idx bits)
+    uint32_t pos[K];     // position in the sorted target (kNoIdx = none)
+    bool full;           // K neighbours found under the bound
+    uint32_t n_eval, n_shell;
+};
+
+template <int K>
+DCREG_DEVFN void knn_exact(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring,
+                                          KnnResult<K> &res, unsigned long long *stamp = nullptr) {
+    uint32_t pos[K];
+    {
+        HeapFast<K> hf;
+        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, stamp);
+        if (stamp) stamp[2] = clock64();
+        res.full = hf.full();
+        res.n_eval = hf.n_eval; res.n_shell = hf.n_shell;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { res.d2[j] = hf.d[j]; pos[j] = hf.pos[j]; }
+        if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo
+            HeapExact<K> he;
+            knn_search<HeapExact<K>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
+            res.n_eval += he.n_eval;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { res.d2[j] = he.dist(j); pos[j] = he.pos[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const bool ok = pos[j] != kNoIdx;
+        res.pos[j] = pos[j];
+        res.pt[j] = ok ? g.pts[pos[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        res.idx[j] = ok ? __float_as_uint(res.pt[j].w) : kNoIdx;
+        if (!ok) res.d2[j] = __builtin_inff();
+    }
+    // canonical order among equal distances (lower index first); entries are already sorted by d2
+    bool any_eq = false;
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) any_eq |= (res.d2[j] == res.d2[j + 1]) && res.idx[j + 1] != kNoIdx;
+    if (any_eq) {
+#pragma unroll
+        for (int a = 0; a + 1 < K; ++a)
+#pragma unroll
+            for (int b = 0; b + 1 < K - a; ++b) {
+                const bool sw = res.d2[b] == res.d2[b + 1] && res.idx[b] > res.idx[b + 1];
+                const uint32_t ia = res.idx[b], ib = res.idx[b + 1];
+                const float4 pa = res.pt[b], pb = res.pt[b + 1];
+                res.idx[b] = sw ? ib : ia; res.idx[b + 1] = sw ? ia : ib;
+                res.pt[b] = sw ? pb : pa; res.pt[b + 1] = sw ? pa : pb;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- 5x3 column-pivoted Householder QR
+// Restates Eigen 3.3.7 ColPivHouseholderQR::compute + solve (icp_test_runner.cpp:1747) for [q_j] x = -1,
+// including the nonzeroPivots() truncation that decides rank-deficient (coplanar-with-origin / constant-
+// zero column) neighbourhoods.  Columns are swapped with selects so everything stays in registers.
+DCREG_DEVFN void swap_col(double (&a)[5], double (&b)[5], bool doit) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const double ta = a[i], tb = b[i]; a[i] = doit ? tb : ta; b[i] = doit ? ta : tb; }
+}
+DCREG_DEVFN void swap_d(double &a, double &b, bool doit) { const double ta = a, tb = b; a = doit ? tb : ta; b = doit ? ta : tb; }
+DCREG_DEVFN void swap_i(int &a, int &b, bool doit) { const int ta = a, tb = b; a = doit ? tb : ta; b = doit ? ta : tb; }
+
+template <int KCOL>
+DCREG_DEVFN void householder_step(double (&c0)[5], double (&c1)[5], double (&c2)[5], double (&tau)[3],
+                                                 double (&nu)[3], double (&nd)[3]) {
+    // acts on column KCOL (rows KCOL..4) and updates the trailing columns; c0,c1,c2 are the CURRENT columns
+    double(&ck)[5] = (KCOL == 0) ? c0 : (KCOL == 1 ? c1 : c2);
+    double tail = 0.0;
+#pragma unroll
+    for (int i = KCOL + 1; i < 5; ++i) tail += ck[i] * ck[i];
+    const double a0 = ck[KCOL];
+    double beta, t;
+    if (tail <= 2.2250738585072014e-308) {
+        t = 0.0; beta = a0;
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) ck[i] = 0.0;
+    } else {
+        beta = sqrt(a0 * a0 + tail);
+        if (a0 >= 0.0) beta = -beta;
+        const double inv_den = 1.0 / (a0 - beta);      // one reciprocal + multiplies (fp64 division is ~11 instructions)
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) ck[i] = ck[i] * inv_den;
+        t = (beta - a0) / beta;
+    }
+    tau[KCOL] = t;
+    ck[KCOL] = beta;
+#pragma unroll
+    for (int j = KCOL + 1; j < 3; ++j) {
+        double(&cj)[5] = (j == 1) ? c1 : c2;
+        if (t != 0.0) {
+            double tmp = cj[KCOL];
+#pragma unroll
+            for (int i = KCOL + 1; i < 5; ++i) tmp += ck[i] * cj[i];
+            cj[KCOL] -= t * tmp;
+#pragma unroll
+            for (int i = KCOL + 1; i < 5; ++i) cj[i] -= t * ck[i] * tmp;
+        }
+        if (nu[j] != 0.0) {   // LAPACK norm downdate (lawn176), as Eigen does
+            double tt = fabs(cj[KCOL]) / nu[j];
+            tt = (1.0 + tt) * (1.0 - tt);
+            tt = tt < 0.0 ? 0.0 : tt;
+            const double ratio = nu[j] / nd[j];
+            if (tt * ratio * ratio <= 1.4901161193847656e-08) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = KCOL + 1; i < 5; ++i) s += cj[i] * cj[i];
+                nd[j] = nu[j] = sqrt(s);
+            } else {
+                nu[j] *= sqrt(tt);
+            }
+        }
+    }
+}
+
+// returns x (plane coefficients, unnormalised); Q row j = neighbour j
+DCREG_DEVFN void plane_fit_qr(const double (&qx)[5], const double (&qy)[5], const double (&qz)[5], double (&x)[3]) {
+    double c0[5], c1[5], c2[5], tau[3], nu[3], nd[3];
+    int p0 = 0, p1 = 1, p2 = 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { c0[i] = qx[i]; c1[i] = qy[i]; c2[i] = qz[i]; }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { s0 += c0[i] * c0[i]; s1 += c1[i] * c1[i]; s2 += c2[i] * c2[i]; }
+    nu[0] = nd[0] = sqrt(s0); nu[1] = nd[1] = sqrt(s1); nu[2] = nd[2] = sqrt(s2);
+    const double mx = fmax(nu[0], fmax(nu[1], nu[2]));
+    const double eps = 2.220446049250313e-16;
+    const double thr_helper = (mx * eps) * (mx * eps) / 5.0;
+    int nz = 3;
+    // k = 0
+    {
+        const bool b1 = nu[1] > nu[0], b2 = nu[2] > (b1 ? nu[1] : nu[0]);
+        const double big = b2 ? nu[2] : (b1 ? nu[1] : nu[0]);
+        if (big * big < thr_helper * 5.0) nz = 0;
+        const bool sw1 = b1 && !b2, sw2 = b2;
+        swap_col(c0, c1, sw1); swap_d(nu[0], nu[1], sw1); swap_d(nd[0], nd[1], sw1); swap_i(p0, p1, sw1);
+        swap_col(c0, c2, sw2); swap_d(nu[0], nu[2], sw2); swap_d(nd[0], nd[2], sw2); swap_i(p0, p2, sw2);
+        householder_step<0>(c0, c1, c2, tau, nu, nd);
+    }
+    // k = 1
+    {
+        const bool b2 = nu[2] > nu[1];
+        const double big = b2 ? nu[2] : nu[1];
+        if (nz == 3 && big * big < thr_helper * 4.0) nz = 1;
+        swap_col(c1, c2, b2); swap_d(nu[1], nu[2], b2); swap_d(nd[1], nd[2], b2); swap_i(p1, p2, b2);
+        householder_step<1>(c0, c1, c2, tau, nu, nd);
+    }
+    // k = 2
+    {
+        if (nz == 3 && nu[2] * nu[2] < thr_helper * 3.0) nz = 2;
+        householder_step<2>(c0, c1, c2, tau, nu, nd);
+    }
+    // solve: c = Q^T rhs (first nz reflectors), back-substitute the leading nz x nz triangle
+    double c[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
+    if (nz > 0 && tau[0] != 0.0) {
+        double tmp = c[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) tmp += c0[i] * c[i];
+        c[0] -= tau[0] * tmp;
+#pragma unroll
+        for (int i = 1; i < 5; ++i) c[i] -= tau[0] * c0[i] * tmp;
+    }
+    if (nz > 1 && tau[1] != 0.0) {
+        double tmp = c[1];
+#pragma unroll
+        for (int i = 2; i < 5; ++i) tmp += c1[i] * c[i];
+        c[1] -= tau[1] * tmp;
+#pragma unroll
+        for (int i = 2; i < 5; ++i) c[i] -= tau[1] * c1[i] * tmp;
+    }
+    if (nz > 2 && tau[2] != 0.0) {
+        double tmp = c[2];
+#pragma unroll
+        for (int i = 3; i < 5; ++i) tmp += c2[i] * c[i];
+        c[2] -= tau[2] * tmp;
+    }
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    // R = [c0[0] c1[0] c2[0]; 0 c1[1] c2[1]; 0 0 c2[2]]
+    if (nz > 2) y2 = c[2] / c2[2];
+    if (nz > 1) y1 = (c[1] - (nz > 2 ? c2[1] * y2 : 0.0)) / c1[1];
+    if (nz > 0) y0 = (c[0] - (nz > 1 ? c1[0] * y1 : 0.0) - (nz > 2 ? c2[0] * y2 : 0.0)) / c0[0];
+    // x[perm[i]] = y[i]
+    x[0] = (p0 == 0) ? y0 : ((p1 == 0) ? y1 : y2);
+    x[1] = (p0 == 1) ? y0 : ((p1 == 1) ? y1 : y2);
+    x[2] = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
+}
+
+// ---------------------------------------------------------------- the same plane fit with fewer instructions
+// fp64 division and square root cost ~14 instructions each on gfx950 (v_div_scale x2, v_rcp, Newton steps, v_div_fmas,
+// v_div_fixup); plane_fit_qr above spends ~17 divisions and ~12 square roots, two thirds of them in the LAPACK-style
+// norm downdating that only serves the pivot choice.  This variant computes the SAME factorisation (same pivot rule on the
+// remaining column norms, same nonzeroPivots() truncation, same basic solution) with
+//   * remaining column norms recomputed directly (squared, no root, no division) - they differ from the downdated
+//     estimates by rounding only, so the pivot order can differ only between columns whose norms agree to ~1e-8, where both
+//     orders give the same solution to rounding;
+//   * the reflector applied un-normalised, H = I - u u^T / (beta (beta - a0)), u = [a0 - beta, tail]: ONE reciprocal per
+//     step, which also yields 1 / R_kk = (beta - a0) / (beta (beta - a0)) for the back substitution;
+//   * reciprocal and square root by v_rcp_f64 / v_rsq_f64 + Newton steps without the IEEE corner-case scaffolding (the
+//     operands are coordinates in metres: no denormals, no overflow).
+// Result: the plane of plane_fit_qr to a few ulp (tests: normals / residuals / weights of the fixture, incl. its 751
+// rank-2 neighbourhoods, and of the synthetic scenes against the oracle; gate flags bit-exact).
+DCREG_DEVFN double fast_rcp(double x) {
+#if DCREG_ON_DEVICE
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
+DCREG_DEVFN double fast_sqrt(double x) {      // x >= 0, finite
+#if DCREG_ON_DEVICE
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+#else
+    return sqrt(x);
+#endif
+}
+
+template <int KCOL>
+DCREG_DEVFN void householder_fast(double (&c0)[5], double (&c1)[5], double (&c2)[5], double (&uk)[3], double (&coef)[3],
+                                  double (&rdiag)[3], double (&rinv)[3]) {
+    double(&ck)[5] = (KCOL == 0) ? c0 : (KCOL == 1 ? c1 : c2);
+    double tail = 0.0;
+#pragma unroll
+    for (int i = KCOL + 1; i < 5; ++i) tail += ck[i] * ck[i];
+    const double a0 = ck[KCOL];
+    if (tail <= 2.2250738585072014e-308) {        // Eigen makeHouseholder: no reflection, beta = c0
+        uk[KCOL] = 0.0; coef[KCOL] = 0.0; rdiag[KCOL] = a0;
+        rinv[KCOL] = fast_rcp(a0);                 // a0 == 0 only for a pivot the truncation has already dropped
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) ck[i] = 0.0;
+        return;
+    }
+    double beta = fast_sqrt(a0 * a0 + tail);
+    if (a0 >= 0.0) beta = -beta;
+    const double u = a0 - beta;                    // |u| >= |beta| > 0
+    const double c = fast_rcp(beta * (beta - a0)); // = 2 / (u^T u) > 0
+    uk[KCOL] = u; coef[KCOL] = c; rdiag[KCOL] = beta;
+    rinv[KCOL] = c * (beta - a0);                  // 1 / beta
+#pragma unroll
+    for (int j = KCOL + 1; j < 3; ++j) {
+        double(&cj)[5] = (j == 1) ? c1 : c2;
+        double w = u * cj[KCOL];
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) w += ck[i] * cj[i];
+        w *= c;
+        cj[KCOL] -= w * u;
+#pragma unroll
+        for (int i = KCOL + 1; i < 5; ++i) cj[i] -= w * ck[i];
+    }
+}
+
+DCREG_DEVFN void plane_fit_qr_fast(const double (&qx)[5], const double (&qy)[5], const double (&qz)[5], double (&x)[3]) {
+    double c0[5], c1[5], c2[5], uk[3], coef[3], rdiag[3], rinv[3];
+    int p0 = 0, p1 = 1, p2 = 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { c0[i] = qx[i]; c1[i] = qy[i]; c2[i] = qz[i]; }
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;          // squared norms of the remaining part of each column
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { n0 += c0[i] * c0[i]; n1 += c1[i] * c1[i]; n2 += c2[i] * c2[i]; }
+    const double mx2 = fmax(n0, fmax(n1, n2));
+    const double eps = 2.220446049250313e-16;
+    const double thr_helper = mx2 * (eps * eps) / 5.0;
+    int nz = 3;
+    {   // k = 0
+        const bool b1 = n1 > n0, b2 = n2 > (b1 ? n1 : n0);
+        const double big = b2 ? n2 : (b1 ? n1 : n0);
+        if (big < thr_helper * 5.0) nz = 0;
+        const bool sw1 = b1 && !b2, sw2 = b2;
+        swap_col(c0, c1, sw1); swap_i(p0, p1, sw1);
+        swap_col(c0, c2, sw2); swap_i(p0, p2, sw2);
+        householder_fast<0>(c0, c1, c2, uk, coef, rdiag, rinv);
+    }
+    {   // k = 1
+        n1 = 0.0; n2 = 0.0;
+#pragma unroll
+        for (int i = 1; i < 5; ++i) { n1 += c1[i] * c1[i]; n2 += c2[i] * c2[i]; }
+        const bool b2 = n2 > n1;
+        const double big = b2 ? n2 : n1;
+        if (nz == 3 && big < thr_helper * 4.0) nz = 1;
+        swap_col(c1, c2, b2); swap_i(p1, p2, b2);
+        householder_fast<1>(c0, c1, c2, uk, coef, rdiag, rinv);
+    }
+    {   // k = 2
+        n2 = 0.0;
+#pragma unroll
+        for (int i = 2; i < 5; ++i) n2 += c2[i] * c2[i];
+        if (nz == 3 && n2 < thr_helper * 3.0) nz = 2;
+        householder_fast<2>(c0, c1, c2, uk, coef, rdiag, rinv);
+    }
+    // c = Q^T rhs (first nz reflectors; a reflector with coef == 0 is the identity), then the leading nz x nz triangle
+    double c[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
+    if (nz > 0) {
+        double w = uk[0] * c[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) w += c0[i] * c[i];
+        w *= coef[0];
+        c[0] -= w * uk[0];
+#pragma unroll
+        for (int i = 1; i < 5; ++i) c[i] -= w * c0[i];
+    }
+    if (nz > 1) {
+        double w = uk[1] * c[1];
+#pragma unroll
+        for (int i = 2; i < 5; ++i) w += c1[i] * c[i];
+        w *= coef[1];
+        c[1] -= w * uk[1];
+#pragma unroll
+        for (int i = 2; i < 5; ++i) c[i] -= w * c1[i];
+    }
+    if (nz > 2) {
+        double w = uk[2] * c[2];
+#pragma unroll
+        for (int i = 3; i < 5; ++i) w += c2[i] * c[i];
+        w *= coef[2];
+        c[2] -= w * uk[2];
+    }
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    // R = [rdiag0 c1[0] c2[0]; 0 rdiag1 c2[1]; 0 0 rdiag2]
+    if (nz > 2) y2 = c[2] * rinv[2];
+    if (nz > 1) y1 = (c[1] - (nz > 2 ? c2[1] * y2 : 0.0)) * rinv[1];
+    if (nz > 0) y0 = (c[0] - (nz > 1 ? c1[0] * y1 : 0.0) - (nz > 2 ? c2[0] * y2 : 0.0)) * rinv[0];
+    x[0] = (p0 == 0) ? y0 : ((p1 == 0) ? y1 : y2);
+    x[1] = (p0 == 1) ? y0 : ((p1 == 1) ? y1 : y2);
+    x[2] = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
+}
+
+// ---------------------------------------------------------------- one source point: search, then row
+// Steps 1-2 of an iteration for one query (icp_test_runner.cpp:1716-1726): pose transform (double -> float store), warm
+// bound from the previous neighbour set, exact 5-NN.  `i` = position of the query in the sorted source (index into the
+// warm-start state), `prev` = base of this pose's state ([5][prev_stride]) or null.
+struct PointQuery {
+    float qx, qy, qz;     // transformed query, float (utils.hpp:630-636)
+    bool reach;           // the query is close enough to the grid for a neighbour inside the radius to exist
+};
+
+DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, const LinArgs &a, uint32_t *prev, bool have_q,
+                            const float4 &s4, uint32_t i, PointQuery &q, KnnResult<5> &nn, unsigned long long *sst = nullptr) {
+    // warm start: the K-th neighbour distance is at most the largest distance to ANY K distinct target points, so
+    // the neighbour set of the previous linearisation (any pose) bounds this search; the result is the same exact
+    // set, found after visiting only the cells that ball touches.  The position loads and the point gathers are
+    // issued here, ahead of the pose transform and the cell-table loads, so their latency overlaps with those.
+    uint32_t pp[5];
+    float4 pv[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) pp[j] = (prev && have_q) ? prev[(size_t)j * a.prev_stride + i] : kNoIdx;
+    const bool warm = pp[4] != kNoIdx;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) pv[j] = warm ? g.pts[pp[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
+    const double fx = ((double)q.qx - g.ox) * g.inv_h, fy = ((double)q.qy - g.oy) * g.inv_h, fz = ((double)q.qz - g.oz) * g.inv_h;
+    const double lim = (double)a.max_ring + 1.0;
+    // a query farther than max_ring cells from the grid has no neighbour inside the radius
+    q.reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
+    nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
+    float bound = a.radius_sq_f;
+    if (warm) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) m = fmaxf(m, dist2_nofma(q.qx, q.qy, q.qz, pv[j]));
+        // inclusive bound for a strict '<' heap: next float above m (m >= 0, finite)
+        const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
+        bound = fminf(bound, incl);
+    }
+    if (q.reach) knn_exact<5>(g, runs, q.qx, q.qy, q.qz, bound, a.max_ring, nn, sst);
+    if (prev && have_q) {
+        const bool keep = q.reach && nn.full;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) prev[(size_t)j * a.prev_stride + i] = keep ? nn.pos[j] : kNoIdx;
+    }
+}
+
+// Steps 3-5 for one query with its neighbour set (icp_test_runner.cpp:1727-1812, 1863-1907): plane fit, gates, weight,
+// Jacobian row, the 31 products.  acc must be zero on entry; it stays zero unless the point is effective (acc[30] counts
+// the points that passed the radius gate, :1731).  Returns the gate flag (dcreg_lin_debug::flag); nrm/r_out/s_out receive
+// the plane normal, residual and weight once they exist (flags 1 and 4).
+template <bool FASTMATH>
+DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4, const PointQuery &q, const KnnResult<5> &nn,
+                            double (&acc)[31], double (&nrm)[3], double &r_out, double &s_out) {
+    const double px = s4.x, py = s4.y, pz = s4.z;
+    const bool have5 = q.reach && nn.full;
+    const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
+    if (!in_radius) return 0;
+    acc[30] = 1.0;                                                          // :1731
+    double nqx[5], nqy[5], nqz[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { nqx[j] = nn.pt[j].x; nqy[j] = nn.pt[j].y; nqz[j] = nn.pt[j].z; }
+    double x[3];
+    if (FASTMATH) plane_fit_qr_fast(nqx, nqy, nqz, x); else plane_fit_qr(nqx, nqy, nqz, x);
+    const double ps2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    const double ps = FASTMATH ? fast_sqrt(ps2) : sqrt(ps2);
+    if (ps < a.min_norm) return 2;                                          // :1752
+    const double pd = FASTMATH ? fast_rcp(ps) : 1.0 / ps;
+    const double pa = x[0] * pd, pb = x[1] * pd, pc = x[2] * pd;
+    double maxd = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {                                           // :1763-1770
+        double d = pa * nqx[j] + pb * nqy[j] + pc * nqz[j] + pd;
+        d *= d;
+        maxd = d > maxd ? d : maxd;
+    }
+    if (!(maxd < a.max_thick_sq)) return 3;                                 // :1773
+    const double r = pa * (double)q.qx + pb * (double)q.qy + pc * (double)q.qz + pd;   // :1774
+    double s = 1.0 - a.w_slope * fabs(r);                                   // :1776
+    s = s < 0.0 ? 0.0 : s;
+    double ds = 0.0;
+    if (a.use_wd && s > 0.0 && s < 1.0) ds = -a.w_slope * (r > 0.0 ? 1.0 : -1.0);   // :1780-1783
+    nrm[0] = pa; nrm[1] = pb; nrm[2] = pc; r_out = r; s_out = s;
+    if (!(s > a.w_min)) return 4;                                           // :1785
+    const float cxf = (float)(s * pa), cyf = (float)(s * pb), czf = (float)(s * pc);   // :1787-1789
+    const float cif = (float)(s * r);                                                    // :1790
+    const double inv_s = FASTMATH ? fast_rcp(s) : 1.0 / s;
+    const double nx = (double)cxf * inv_s, ny = (double)cyf * inv_s, nz = (double)czf * inv_s;   // :1889
+    double A[6];
+    if (!a.euler) {
+        // J_r = [ (p x m)^T , m^T ],  m = R^T n   (math_utils.hpp:102-121)
+        const double m0 = P.R[0] * nx + P.R[3] * ny + P.R[6] * nz;
+        const double m1 = P.R[1] * nx + P.R[4] * ny + P.R[7] * nz;
+        const double m2 = P.R[2] * nx + P.R[5] * ny + P.R[8] * nz;
+        const double w = s + r * ds;                                                     // :1898
+        A[0] = w * (py * m2 - pz * m1); A[1] = w * (pz * m0 - px * m2); A[2] = w * (px * m1 - py * m0);
+        A[3] = w * m0; A[4] = w * m1; A[5] = w * m2;
+    } else {
+        // second engine (:2296-2347): row = [ c^T dR/droll p, c^T dR/dpitch p, c^T dR/dyaw p, c^T ] with
+        // c = the float-stored weighted normal s*n; no weight derivative, no division by s
+        const double c0 = (double)cxf, c1 = (double)cyf, c2 = (double)czf;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double *D = a.dR + 9 * k;
+            A[k] = c0 * (D[0] * px + D[1] * py + D[2] * pz) + c1 * (D[3] * px + D[4] * py + D[5] * pz) +
+                   c2 * (D[6] * px + D[7] * py + D[8] * pz);
+        }
+        A[3] = c0; A[4] = c1; A[5] = c2;
+    }
+    const double b = -(double)cif;                                                       // :1906
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int k = j; k < 6; ++k) acc[idx++] = A[j] * A[k];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[21 + j] = A[j] * b;
+    acc[27] = r * r;
+    acc[28] = b * b;
+    acc[29] = 1.0;
+    return 1;
+}
+
+}  // namespace dcreg

@@ -183,6 +183,7 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
                          const dcreg_config *cfg, dcreg_trial_result *results) {
     if (!ctx || !R0 || !t0 || !cfg || !results || n_trials < 0) return DCREG_E_INVALID;
     if (n_trials == 0) return DCREG_OK;
+    if (n_trials > 2 * 65535) return DCREG_E_INVALID;   // two groups of at most 65535 poses per launch (grid.y)
     const auto t_total = Clock::now();
     const dcreg_lin_params prm = lin_params_of(*cfg);
     dcreg_index_info info;
@@ -198,7 +199,12 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
     // The trials advance in lock-step, one batched launch per iteration and group.  With enough trials they are split into
     // two groups that alternate on the device: while the kernels of one group run, the host takes steps 6-9 of the other
     // (software pipeline over the two linearisation slots of the ctx), so the 6x6 solves cost no wall time.
-    struct Group { std::vector<int> live; std::vector<double> Rb, tb; std::vector<dcreg_lin_out> outs; int it = 0; bool in_flight = false; };
+    struct Group { std::vector<int> live; std::vector<int32_t> ids; std::vector<double> Rb, tb; std::vector<dcreg_lin_out> outs; int it = 0; bool in_flight = false; };
+    // one warm-start state per trial: every trial bounds its search by its own previous neighbour sets, like a single run
+    {
+        const int rc0 = dcreg_reserve_warm_states(ctx, n_trials);
+        if (rc0 != DCREG_OK) return rc0;
+    }
     Group grp[2];
     const int n_groups = n_trials >= 64 ? 2 : 1;
     for (int i = 0; i < n_trials; ++i) grp[n_groups == 2 ? (i & 1) : 0].live.push_back(i);
@@ -208,12 +214,13 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
         Group &G = grp[gi];
         if (G.live.empty() || G.it >= cfg->max_iterations) return DCREG_OK;
         const int nl = (int)G.live.size();
-        G.Rb.resize((size_t)nl * 9); G.tb.resize((size_t)nl * 3); G.outs.resize((size_t)nl);
+        G.Rb.resize((size_t)nl * 9); G.tb.resize((size_t)nl * 3); G.outs.resize((size_t)nl); G.ids.resize((size_t)nl);
         for (int j = 0; j < nl; ++j) {
+            G.ids[(size_t)j] = (int32_t)G.live[(size_t)j];
             std::memcpy(&G.Rb[(size_t)j * 9], &R[(size_t)G.live[(size_t)j] * 9], sizeof(double) * 9);
             std::memcpy(&G.tb[(size_t)j * 3], &t[(size_t)G.live[(size_t)j] * 3], sizeof(double) * 3);
         }
-        const int rc = dcreg_linearize_batch_begin(ctx, gi, nl, G.Rb.data(), G.tb.data(), &prm);
+        const int rc = dcreg_linearize_batch_begin_warm(ctx, gi, nl, G.Rb.data(), G.tb.data(), G.ids.data(), &prm);
         G.in_flight = rc == DCREG_OK;
         return rc;
     };

@@ -121,8 +121,11 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  * "time_kernels" (N > 0 = bracket every N-th linearisation with HIP events, 0 = off), "spin" (1 = wait on the pinned
  * result flag instead of hipStreamSynchronize, default), "warm_start" (1 = bound each search by the previous neighbour
  * set, default; results are identical either way), "gap_field" (1 = build the empty-space distance field at the next
- * dcreg_set_target, default; results are identical either way); experiment knobs: "lds_pad" (extra dynamic LDS bytes per
- * block), "keep_source_order" (1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert sort) */
+ * dcreg_set_target, default; results are identical either way), "fast_plane_fit" (1 = the reduced-instruction plane fit,
+ * default; 0 = the Eigen-shaped factorisation step for step; planes agree to a few ulp), "xcd_chunk" (query-block -> XCD
+ * mapping: 0 = one contiguous run per XCD, c = runs of c blocks round-robin); experiment knobs: "lds_pad" (extra dynamic LDS
+ * bytes per block), "keep_source_order" (1 = the next dcreg_set_source keeps the caller's point order instead of the
+ * Hilbert sort) */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
  * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */
@@ -141,6 +144,15 @@ int dcreg_linearize_batch(dcreg_ctx *, int n_poses, const double *R9, const doub
  * one batch on the device while the host solves the other (dcreg_icp_run_trials does).  R9 / t3 are copied by _begin. */
 int dcreg_linearize_batch_begin(dcreg_ctx *, int slot, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *);
 int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
+/* Warm-start states for batched launches.  A single-pose linearisation bounds its search by the neighbour set its own
+ * previous call found (kept inside the ctx); poses of a batch belong to different trajectories, so each needs a state of
+ * its own: reserve n_states of them (20 B per source point each; all reset to "none"), then name the state of every pose in
+ * state_ids (0 <= id < n_states, each id at most once per launch, -1 = search cold).  A state is read and overwritten by
+ * the launch, so consecutive launches of one Monte-Carlo trial under the same id search warm.  Results are identical with
+ * or without states (the bound only prunes).  dcreg_set_target / dcreg_set_source drop all states. */
+int dcreg_reserve_warm_states(dcreg_ctx *, int64_t n_states);
+int dcreg_linearize_batch_begin_warm(dcreg_ctx *, int slot, int n_poses, const double *R9, const double *t3,
+                                     const int32_t *state_ids, const dcreg_lin_params *);
 int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], const dcreg_lin_params *,
                           dcreg_lin_out *, dcreg_lin_debug *);
 /* exact k-NN (k = 1 or 5) of host queries against the target index; float sq. distances, (d2, idx) order */

@@ -1,0 +1,279 @@
+// TEST INFRASTRUCTURE ONLY: host replay of the device algorithm in dcreg_amd/csrc/device/search.hpp (see host_emul_shim.hpp).
+// Builds the same grid index the device builds (cell choice restated from context.hip build_index), then runs the very same
+// per-thread functions (lin_search / lin_row: warm bound, exact 5-NN with the ring walk, plane fit, gates, row) for every
+// query on the CPU and sums the rows in fp64.  C-ABI for ctypes (tests/emul.py).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#define DCREG_HOST_EMUL 1
+#include "../../dcreg_amd/csrc/device/search.hpp"
+
+using namespace dcreg;
+
+struct EmuIndex {
+    std::vector<float4> pts;            // sorted by cell, +8 padding
+    std::vector<uint32_t> cell_start;
+    std::vector<uint8_t> gap;
+    GridDev g{};
+    int64_t n_cells = 0;
+    uint32_t occupied = 0;
+};
+
+static void grid_dims(double h, const double mn[3], const double mx[3], GridDev &g) {
+    g.h = h; g.inv_h = 1.0 / h;
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    g.nx = (int)std::floor((mx[0] - mn[0]) * g.inv_h) + 1;
+    g.ny = (int)std::floor((mx[1] - mn[1]) * g.inv_h) + 1;
+    g.nz = (int)std::floor((mx[2] - mn[2]) * g.inv_h) + 1;
+}
+static double cap_cell_for_budget(double h, const double mn[3], const double mx[3], double max_cells) {
+    for (int it = 0; it < 64; ++it) {
+        const double nx = std::floor((mx[0] - mn[0]) / h) + 1, ny = std::floor((mx[1] - mn[1]) / h) + 1, nz = std::floor((mx[2] - mn[2]) / h) + 1;
+        if (nx * ny * nz <= max_cells && nx < 2e9 && ny < 2e9 && nz < 2e9) return h;
+        h *= 1.26;
+    }
+    return h;
+}
+static inline int clampi_h(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, const double mn[3], const double mx[3]) {
+    GridDev g{};
+    grid_dims(h, mn, mx, g);
+    const int64_t n_cells = (int64_t)g.nx * g.ny * g.nz;
+    std::vector<uint32_t> keys((size_t)n), order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int cx = clampi_h((int)std::floor(((double)xyz[3 * i] - g.ox) * g.inv_h), 0, g.nx - 1);
+        const int cy = clampi_h((int)std::floor(((double)xyz[3 * i + 1] - g.oy) * g.inv_h), 0, g.ny - 1);
+        const int cz = clampi_h((int)std::floor(((double)xyz[3 * i + 2] - g.oz) * g.inv_h), 0, g.nz - 1);
+        keys[(size_t)i] = (uint32_t)(((int64_t)cz * g.ny + cy) * g.nx + cx);
+    }
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });   // radix sort is stable too
+    E.pts.assign((size_t)n + 8, float4{0.f, 0.f, 0.f, 0.f});
+    E.cell_start.assign((size_t)n_cells + 1, 0u);
+    uint32_t occ = 0;
+    std::vector<uint32_t> cnt((size_t)n_cells, 0u);
+    for (int64_t i = 0; i < n; ++i) ++cnt[keys[(size_t)i]];
+    uint32_t run = 0;
+    for (int64_t c = 0; c < n_cells; ++c) { E.cell_start[(size_t)c] = run; run += cnt[(size_t)c]; occ += cnt[(size_t)c] ? 1u : 0u; }
+    E.cell_start[(size_t)n_cells] = run;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t o = order[(size_t)i];
+        E.pts[(size_t)i] = float4{xyz[3 * o], xyz[3 * o + 1], xyz[3 * o + 2], __uint_as_float(o)};
+    }
+    g.n_pts = (uint32_t)n;
+    E.g = g; E.n_cells = n_cells; E.occupied = occ;
+    return occ;
+}
+
+extern "C" {
+
+void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double opt_cell, double cell_factor, int gap_field) {
+    EmuIndex *E = new EmuIndex();
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], (double)xyz[3 * i + a]); mx[a] = std::max(mx[a], (double)xyz[3 * i + a]); }
+    const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
+    const double max_cells = (double)((int64_t)1 << 27);
+    const double h_cap = radius_hint > 0.0 ? radius_hint * 1.00001 : ext / std::cbrt((double)n) * 4.0;
+    double h = opt_cell > 0.0 ? opt_cell : h_cap;
+    h = cap_cell_for_budget(h, mn, mx, max_cells);
+    uint32_t occ = build_at(*E, xyz, n, h, mn, mx);
+    if (opt_cell <= 0.0) {     // density-adaptive cell, as context.hip build_index
+        const double target_occ = 1.59 * cell_factor * cell_factor;
+        double m1 = (double)n / std::max<uint32_t>(occ, 1);
+        double h1 = h, expo = 2.0;
+        for (int pass = 0; pass < 2 && m1 > target_occ * 1.3; ++pass) {
+            double h2 = h1 * std::pow(target_occ / m1, 1.0 / expo);
+            h2 = std::max(h2, h_cap / 64.0);
+            h2 = cap_cell_for_budget(h2, mn, mx, max_cells);
+            if (h2 >= h1 * 0.95) break;
+            occ = build_at(*E, xyz, n, h2, mn, mx);
+            const double m2 = (double)n / std::max<uint32_t>(occ, 1);
+            if (m2 < m1 && h2 < h1) expo = std::min(3.0, std::max(1.0, std::log(m1 / m2) / std::log(h1 / h2)));
+            h1 = h2; m1 = m2;
+        }
+    }
+    GridDev &g = E->g;
+    g.cell_start = E->cell_start.data();
+    g.pts = E->pts.data();
+    g.gap = nullptr; g.gap_cap = 0;
+    if (gap_field) {           // empty-space field, as build_gap_field / k_gap_dilate
+        int rings = 1;
+        while (rings < 12 && (double)rings * g.h < (radius_hint > 0.0 ? radius_hint : 4.0 * g.h)) ++rings;
+        if (rings >= 2) {
+            const int nx = g.nx, ny = g.ny, nz = g.nz;
+            E->gap.assign((size_t)E->n_cells, 255);
+            for (int64_t c = 0; c < E->n_cells; ++c) if (E->cell_start[(size_t)c + 1] > E->cell_start[(size_t)c]) E->gap[(size_t)c] = 0;
+            for (int r = 1; r <= rings; ++r) {
+                std::vector<uint8_t> nxt = E->gap;
+                for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
+                    const int64_t c = ((int64_t)z * ny + y) * nx + x;
+                    if (E->gap[(size_t)c] != 255) continue;
+                    bool hit = false;
+                    for (int dz = -1; dz <= 1 && !hit; ++dz) for (int dy = -1; dy <= 1 && !hit; ++dy) for (int dx = -1; dx <= 1 && !hit; ++dx) {
+                        const int xx = x + dx, yy = y + dy, zz = z + dz;
+                        if (xx < 0 || yy < 0 || zz < 0 || xx >= nx || yy >= ny || zz >= nz) continue;
+                        if (E->gap[(size_t)(((int64_t)zz * ny + yy) * nx + xx)] == (uint8_t)(r - 1)) hit = true;
+                    }
+                    if (hit) nxt[(size_t)c] = (uint8_t)r;
+                }
+                E->gap.swap(nxt);
+            }
+            g.gap = E->gap.data(); g.gap_cap = rings;
+        }
+    }
+    return E;
+}
+void emu_index_free(void *p) { delete (EmuIndex *)p; }
+void emu_index_info(void *p, double *h, int32_t dims[3], int64_t *n_cells, int32_t *gap_cap) {
+    EmuIndex *E = (EmuIndex *)p;
+    *h = E->g.h; dims[0] = E->g.nx; dims[1] = E->g.ny; dims[2] = E->g.nz; *n_cells = E->n_cells; *gap_cap = E->g.gap_cap;
+}
+
+// Hilbert-curve order of a cloud, as k_curve_keys + radix sort on the device
+static uint64_t spread21_h(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+void emu_hilbert_order(const float *xyz, int64_t n, uint32_t *order) {
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], (double)xyz[3 * i + a]); mx[a] = std::max(mx[a], (double)xyz[3 * i + a]); }
+    const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
+    const double inv_q = 2097151.0 / ext * 0.999999;
+    std::vector<uint64_t> keys((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t X[3];
+        for (int a = 0; a < 3; ++a) X[a] = (uint32_t)std::fmin(std::fmax(((double)xyz[3 * i + a] - mn[a]) * inv_q, 0.0), 2097151.0);
+        const uint32_t M = 1u << 20;
+        for (uint32_t Q = M; Q > 1; Q >>= 1) {
+            const uint32_t P = Q - 1;
+            for (int a = 0; a < 3; ++a) {
+                if (X[a] & Q) X[0] ^= P;
+                else { const uint32_t t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+            }
+        }
+        X[1] ^= X[0]; X[2] ^= X[1];
+        uint32_t t = 0;
+        for (uint32_t Q = M; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+        X[0] ^= t; X[1] ^= t; X[2] ^= t;
+        keys[(size_t)i] = (spread21_h(X[0]) << 2) | (spread21_h(X[1]) << 1) | spread21_h(X[2]);
+    }
+    std::iota(order, order + n, 0u);
+    std::stable_sort(order, order + n, [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+}
+
+struct EmuLinParams {
+    double search_radius, max_plane_thickness_sq, min_normal_norm, weight_slope, weight_min;
+    int32_t use_weight_derivative, fast_plane_fit;
+};
+
+// One linearisation of `n` queries (src_xyz in the order given; order[i] = original index written into the per-point
+// outputs, or null for identity).  prev: [5][prev_stride] warm-start state, read and updated (null = cold).
+// out32: 21 H + 6 g + sum r^2 + sum b^2 + n_eff + n_pt.  Per-point outputs may be null.  stats: [n][8] counters
+// {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}.
+int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_t n, const double R[9], const double t[3],
+                  const EmuLinParams *p, uint32_t *prev, int64_t prev_stride, double *out32, int32_t *nn_idx, float *nn_d2,
+                  uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats) {
+    EmuIndex *E = (EmuIndex *)idx;
+    const GridDev &g = E->g;
+    LinArgs a{};
+    a.radius_sq = p->search_radius * p->search_radius;
+    float rf = (float)a.radius_sq;
+    if ((double)rf < a.radius_sq) rf = std::nextafterf(rf, INFINITY);
+    a.radius_sq_f = std::nextafterf(rf, INFINITY);
+    a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm; a.w_slope = p->weight_slope; a.w_min = p->weight_min;
+    a.use_wd = p->use_weight_derivative;
+    int k = 1;
+    while (k < 100000) { const double safe = (double)k * g.h * (1.0 - 1e-9); if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break; ++k; }
+    a.max_ring = k;
+    a.prev = prev; a.prev_stride = (uint32_t)prev_stride; a.euler = 0;
+    PoseArg P{};
+    std::memcpy(P.R, R, sizeof(P.R)); std::memcpy(P.t, t, sizeof(P.t));
+    static thread_local RunList runs;
+    double tot[31];
+    for (double &v : tot) v = 0.0;
+    threadIdx.x = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t oi = order ? order[i] : (uint32_t)i;
+        const float4 s4{src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], __uint_as_float(oi)};
+        PointQuery q;
+        KnnResult<5> nn;
+        emu_stats = EmuStats{};
+        lin_search(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
+        double acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
+        for (double &v : acc) v = 0.0;
+        const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, acc, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, acc, nrm, rr, ss);
+        for (int j = 0; j < 31; ++j) tot[j] += acc[j];
+        if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = (q.reach && nn.idx[j] != kNoIdx) ? (int32_t)nn.idx[j] : -1;
+        if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = (q.reach && nn.idx[j] != kNoIdx) ? nn.d2[j] : INFINITY;
+        if (flag_out) flag_out[oi] = fl;
+        if (fl == 1 || fl == 4) {
+            if (normal) { normal[3 * (size_t)oi] = nrm[0]; normal[3 * (size_t)oi + 1] = nrm[1]; normal[3 * (size_t)oi + 2] = nrm[2]; }
+            if (r_out) r_out[oi] = rr;
+            if (s_out) s_out[oi] = ss;
+        }
+        if (stats) {
+            uint32_t *s = stats + 8 * (size_t)i;      // in processing order (the wave model groups consecutive queries)
+            s[0] = nn.n_eval; s[1] = nn.n_shell; s[2] = emu_stats.table_loads; s[3] = emu_stats.rows; s[4] = emu_stats.runs;
+            s[5] = emu_stats.trips; s[6] = emu_stats.faces; s[7] = emu_stats.face_skips;
+        }
+    }
+    for (int j = 0; j < 31; ++j) out32[j] = tot[j];
+    out32[31] = 0.0;
+    return 0;
+}
+
+// plain exact k-NN (k = 1 or 5) of host queries, as k_knn / dcreg_knn: max_radius <= 0 -> unbounded
+int emu_knn(void *idx, const float *q_xyz, int64_t n, int k, double max_radius, int32_t *out_idx, float *out_d2) {
+    EmuIndex *E = (EmuIndex *)idx;
+    const GridDev &g = E->g;
+    float bound = 3.0e38f;
+    int max_ring = -1;
+    if (max_radius > 0.0 && std::isfinite(max_radius)) {
+        const double r2 = max_radius * max_radius;
+        float rf = (float)r2; if ((double)rf < r2) rf = std::nextafterf(rf, INFINITY);
+        bound = std::nextafterf(rf, INFINITY);
+        int kk = 1;
+        while (kk < 100000) { const double s = (double)kk * g.h * (1.0 - 1e-9); if (s * s * (1.0 - 1e-6) >= (double)bound) break; ++kk; }
+        max_ring = kk;
+    }
+    static thread_local RunList runs;
+    threadIdx.x = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float qx = q_xyz[3 * i], qy = q_xyz[3 * i + 1], qz = q_xyz[3 * i + 2];
+        if (k == 1) {
+            KnnResult<1> nn;
+            knn_exact<1>(g, runs, qx, qy, qz, bound, max_ring, nn);
+            out_idx[i] = nn.idx[0] != kNoIdx ? (int32_t)nn.idx[0] : -1;
+            out_d2[i] = nn.idx[0] != kNoIdx ? nn.d2[0] : INFINITY;
+        } else {
+            KnnResult<5> nn;
+            knn_exact<5>(g, runs, qx, qy, qz, bound, max_ring, nn);
+            for (int j = 0; j < 5; ++j) {
+                out_idx[5 * i + j] = nn.idx[j] != kNoIdx ? (int32_t)nn.idx[j] : -1;
+                out_d2[5 * i + j] = nn.idx[j] != kNoIdx ? nn.d2[j] : INFINITY;
+            }
+        }
+    }
+    return 0;
+}
+
+// plane fit alone: Q = 5 neighbours (row-major 5x3); fast = 1 -> plane_fit_qr_fast
+void emu_plane_fit(const double *Q, int fast, double x[3]) {
+    double qx[5], qy[5], qz[5];
+    for (int j = 0; j < 5; ++j) { qx[j] = Q[3 * j]; qy[j] = Q[3 * j + 1]; qz[j] = Q[3 * j + 2]; }
+    double y[3];
+    if (fast) plane_fit_qr_fast(qx, qy, qz, y); else plane_fit_qr(qx, qy, qz, y);
+    x[0] = y[0]; x[1] = y[1]; x[2] = y[2];
+}
+
+}  // extern "C"
