@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdcreg_hip.so")
+LIB_PATH = os.environ.get("DCREG_LIB") or os.path.join(_HERE, "lib", "libdcreg_hip.so")   # DCREG_LIB: an experiment variant (build.py)
 
 # enum values of DCReg/include/utils.hpp:106-121
 DETECTION = {"NONE_DETE": 0, "SCHUR_CONDITION_NUMBER": 1, "FULL_EVD_MIN_EIGENVALUE": 2,

@@ -7,8 +7,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libdcreg_hip.so")
-OBJDIR = os.path.join(HERE, "build")
+# DCREG_BUILD_TAG=<tag> (with DCREG_EXTRA_FLAGS=-D...) builds an experiment variant next to the product library:
+# lib/libdcreg_hip_<tag>.so, loaded when DCREG_LIB points at it (dcreg_amd/api.py).  The product is the untagged library.
+_TAG = os.environ.get("DCREG_BUILD_TAG", "")
+LIB = os.path.join(LIBDIR, "libdcreg_hip%s.so" % (("_" + _TAG) if _TAG else ""))
+OBJDIR = os.path.join(HERE, "build" + (("_" + _TAG) if _TAG else ""))
 BINDIR = os.path.join(HERE, "bin")
 RUNNER = os.path.join(BINDIR, "icp_test_runner")
 
@@ -59,6 +62,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if _TAG:
+        return LIB
     # the experiment driver (icp_test_runner surface) on top of the C-ABI
     os.makedirs(BINDIR, exist_ok=True)
     rsrc = os.path.join(CSRC, "runner", "test_runner.cpp")

@@ -99,7 +99,7 @@ static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double 
     hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, d.raw, c->d_vals2, n, *d.sorted);
     HIP_TRY(c, hipMemsetAsync(*d.sorted + n, 0, 8 * sizeof(float4), c->stream));   // tail padding
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, *d.cell_start, c->d_scratch);
+    hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n_cells + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, *d.cell_start, c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(occupied, c->d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());

@@ -374,6 +374,59 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //   * every row's x-run is trimmed to the cells the K-th-best ball can still reach, as before.
 // Exact: a cell is skipped only when its minimal distance to the query exceeds the K-th best, or when the field proves it
 // empty.  Faces: +-z (rows y in [cy-kk, cy+kk]), +-y (rows z in (cz-kk, cz+kk)), +-x (single cells, y and z in the open range).
+#if defined(DCREG_SHELLS_V1)
+// round-1 ring walk (row sweep), kept for A/B builds: -DDCREG_SHELLS_V1
+template <class H>
+DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const float hf = (float)g.h;
+    // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
+    int k0 = 1;
+    if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
+        const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
+        k0 = max(1, f - 1);
+    }
+    for (int k = k0; k < max_ring; ++k) {
+        // after ring k: every point within k*h (minus a rounding guard) has been seen
+        const double safe = (double)k * g.h * (1.0 - 1e-9);
+        const double safe2 = safe * safe * (1.0 - 1e-6);
+        if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
+        if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
+        const int kk = k + 1;                                   // scan shell kk
+        hp.n_shell = (uint32_t)kk;
+        const int z_lo = max(cz - kk, 0), z_hi = min(cz + kk, nz - 1);
+        const int y_lo = max(cy - kk, 0), y_hi = min(cy + kk, ny - 1);
+        for (int z = z_lo; z <= z_hi; ++z) {
+            const int dz = z - cz;
+            const float gz = dz < 0 ? (float)(fz - (double)(z + 1)) * hf : (dz > 0 ? (float)((double)z - fz) * hf : 0.f);
+            if (gz * gz * 0.99999f > hp.worst_d2()) continue;
+            for (int y = y_lo; y <= y_hi; ++y) {
+                const int dy = y - cy;
+                const float gy = dy < 0 ? (float)(fy - (double)(y + 1)) * hf : (dy > 0 ? (float)((double)y - fy) * hf : 0.f);
+                const float dyz = (gy * gy + gz * gz) * 0.99999f;
+                const float w = hp.worst_d2();
+                if (dyz > w) continue;
+                // cells the ball of radius sqrt(w) around q can reach in this row (conservative)
+                const float xr = sqrtf(w - dyz) * 1.00001f + 1e-6f * hf;
+                const double xr_c = (double)xr * g.inv_h;
+                const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
+                const int64_t row = ((int64_t)z * ny + y) * nx;
+                const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
+                if (full) {
+                    const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
+                    if (x1 > x0) scan_run<H>(g, g.cell_start[row + x0], g.cell_start[row + x1], qx, qy, qz, hp);
+                } else {
+                    const int xa = cx - kk, xb = cx + kk;
+                    if (xa >= 0 && xa < nx && xa >= xmin) scan_run<H>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
+                    if (xb >= 0 && xb < nx && xb <= xmax) scan_run<H>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
+                }
+            }
+        }
+    }
+}
+
+#else
 // slab distance (metres, float) from the query (cell cq, cell coordinate f) to cell index c along one axis
 DCREG_DEVFN float slab_dist(int c, int cq, double f, float hf) {
     return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
@@ -492,6 +545,8 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         }
     }
 }
+
+#endif  // DCREG_SHELLS_V1
 
 // ---------------------------------------------------------------- exact K-NN of one query (fast path + fallback)
 // Runs the 32-bit-key search; if (and only if) a point outside the result ties with the K-th best distance,
@@ -889,7 +944,11 @@ DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, c
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4, const PointQuery &q, const KnnResult<5> &nn,
                             double (&acc)[31], double (&nrm)[3], double &r_out, double &s_out) {
-    const double px = s4.x, py = s4.y, pz = s4.z;
+    float sxf = s4.x, syf = s4.y, szf = s4.z;
+#if DCREG_ON_DEVICE
+    asm volatile("" : "+v"(sxf), "+v"(syf), "+v"(szf));   // as below for the query: re-convert instead of keeping doubles alive
+#endif
+    const double px = sxf, py = syf, pz = szf;
     const bool have5 = q.reach && nn.full;
     const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
     if (!in_radius) return 0;
@@ -912,7 +971,13 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
         maxd = d > maxd ? d : maxd;
     }
     if (!(maxd < a.max_thick_sq)) return 3;                                 // :1773
-    const double r = pa * (double)q.qx + pb * (double)q.qy + pc * (double)q.qz + pd;   // :1774
+    // (the float -> double conversions are redone here on purpose: the cell lookup converted the same floats before the
+    // search, and keeping those three doubles alive across it costs six VGPRs at the register peak, i.e. scratch spills)
+    float qxf = q.qx, qyf = q.qy, qzf = q.qz;
+#if DCREG_ON_DEVICE
+    asm volatile("" : "+v"(qxf), "+v"(qyf), "+v"(qzf));
+#endif
+    const double r = pa * (double)qxf + pb * (double)qyf + pc * (double)qzf + pd;   // :1774
     double s = 1.0 - a.w_slope * fabs(r);                                   // :1776
     s = s < 0.0 ? 0.0 : s;
     double ds = 0.0;

@@ -1,15 +1,14 @@
 #!/bin/bash
-# Round-2 option sweep on the GPU box: per-iteration times of one C4 run under the kernel options, C2 / C5 spot checks.
+# Round-2 A/B on the GPU box: per-iteration times of one C4 run, product library vs the round-1 ring walk, kernel options.
 cd "$(dirname "$0")/.."
 O=gpurun_out/r02_sweep.txt; : > $O
-for opts in "fast_plane_fit=0 xcd_chunk=0" "fast_plane_fit=1 xcd_chunk=0" "fast_plane_fit=1 xcd_chunk=4" "fast_plane_fit=1 xcd_chunk=16" "fast_plane_fit=1 xcd_chunk=64"; do
-  echo "== c4 $opts" >> $O
-  python scripts/iter_times.py c4_corridor_1m $opts 2>&1 | cut -c1-420 >> $O
-done
+V1=$PWD/dcreg_amd/lib/libdcreg_hip_v1walk.so
+run() { echo "== $1 | $2 | $3" >> $O; DCREG_LIB=$2 python scripts/iter_times.py $1 $3 2>&1 | grep -v amdgpu.ids | cut -c1-330 >> $O; }
 for opts in "fast_plane_fit=0 xcd_chunk=0" "fast_plane_fit=1 xcd_chunk=0" "fast_plane_fit=1 xcd_chunk=16"; do
-  echo "== c2 $opts" >> $O
-  python scripts/iter_times.py c2_cylinder_100k $opts 2>&1 | cut -c1-300 >> $O
+  run c4_corridor_1m "" "$opts"
+  run c4_corridor_1m "$V1" "$opts"
 done
-echo "== c5" >> $O
-DCREG_TRIALS_TIMING=1 python bench.py --workload c5_montecarlo_fixture --steps 30 --warmup 30 --repeats 5 --no-configs --no-cpu-baseline --concurrent-pairs 0 2>&1 | cut -c1-700 >> $O
+run c2_cylinder_100k "" "fast_plane_fit=1 xcd_chunk=0"
+run c2_cylinder_100k "$V1" "fast_plane_fit=0 xcd_chunk=0"
+run c2_cylinder_100k "" "fast_plane_fit=1 xcd_chunk=16"
 cat $O

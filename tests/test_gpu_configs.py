@@ -47,9 +47,11 @@ def assert_runs_equal(res, logs, ores, ologs, h_rtol=1e-7, dx_atol=1e-8, pose_at
         assert L.effective_points == O.n_eff and L.corr_pt_count == O.n_pt, (L.iter_count, L.effective_points, O.n_eff)
         assert list(L.analysis.degenerate_mask[:]) == list(O.an.mask[:]), L.iter_count
         assert h.rel_err(L.H_upper[:], O.H_upper[:]) < h_rtol, (L.iter_count, h.rel_err(L.H_upper[:], O.H_upper[:]))
-        # g = sum_i a_i b_i cancels to ~0 at convergence: the rounding scale is the Cauchy-Schwarz bound sqrt(H_jj * sum b^2)
-        Hd = np.diag(api.unpack_hessian(np.array(O.H_upper[:])))
-        assert np.all(np.abs(np.array(L.gradient[:]) - O.gradient[:]) <= 1e-9 * np.sqrt(Hd * 2.0 * O.objective) + 1e-12), L.iter_count
+        # g = sum_i a_i b_i cancels to ~0 at convergence: its rounding scale is the Cauchy-Schwarz bound sqrt(H_jj * sum b^2), and
+        # the two trajectories differ by ~1e-12 in the pose, which moves g by H * that
+        Hm = api.unpack_hessian(np.array(O.H_upper[:]))
+        g_tol = 1e-9 * np.sqrt(np.diag(Hm) * 2.0 * O.objective) + 1e-11 * np.abs(Hm).sum(1) + 1e-12
+        assert np.all(np.abs(np.array(L.gradient[:]) - O.gradient[:]) <= g_tol), L.iter_count
         assert np.allclose(L.update_dx[:], O.dx[:], rtol=0, atol=dx_atol), (L.iter_count, np.max(np.abs(np.array(L.update_dx[:]) - O.dx[:])))
         assert np.isclose(L.rmse, O.rmse, rtol=1e-9) and np.isclose(L.fitness, O.fitness, rtol=1e-12)
         for a, b in ((L.analysis.cond_schur_rot, O.an.cond_schur_rot), (L.analysis.cond_schur_trans, O.an.cond_schur_trans)):
