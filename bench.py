@@ -503,6 +503,7 @@ def cpu_baseline(tgt, src, T_init, w, method, budget_s):
         ncpu_avail = len(os.sched_getaffinity(0))
     except Exception:
         ncpu_avail = ncpu
+    quota = cgroup_cpu_quota()
     threads = min(8, ncpu_avail)
     cfg = po.default_config(search_radius=w["radius"], max_iterations=1, thresh_rot=0.0, thresh_trans=0.0, kappa_target=10.0,
                             std_reg_gamma=100.0, use_weight_derivative=w["wd"], always_compute_schur=1, num_threads=threads)
@@ -523,8 +524,24 @@ def cpu_baseline(tgt, src, T_init, w, method, budget_s):
     busy = ((c1.user + c1.system) - (c0.user + c0.system)) / max(el, 1e-9)
     return {"value": n / el, "unit": "iterations/s", "cores": threads, "kind": "port",
             "sample": "%d ICP iterations of the same scan pair (%d-pt source, the first %d of a %d-iteration run from the same initial pose), "
-                      "one pair at a time, OpenMP x%d (%.1f CPUs busy on average; the box shows %d hardware threads, %d usable by this "
-                      "process), %.1f s" % (n, len(src), min(n, run_len), run_len, threads, busy, ncpu, ncpu_avail, el)}
+                      "one pair at a time, OpenMP x%d (%.1f CPUs busy on average; the box shows %d hardware threads, affinity %d, cgroup CPU "
+                      "quota %s), %.1f s" % (n, len(src), min(n, run_len), run_len, threads, busy, ncpu, ncpu_avail,
+                                             ("%.1f" % quota) if quota else "none", el)}
+
+
+def cgroup_cpu_quota():
+    """CPUs the container may actually use (cgroup v2 cpu.max / v1 cfs quota), or None: os.cpu_count() shows the host's threads."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":

@@ -335,7 +335,9 @@ def test_montecarlo_driver_on_gpu(ctx, cyl):
         ores, ologs = po.icp_run(tree, pts, mc.trial_pose(base, k, 7, 0.3, h.deg2rad(1.0)), "Ours", ocfg)
         assert recs[k, mc.R_CONV] == ores.converged and recs[k, mc.R_ITERS] == ores.iterations
         T = recs[k, mc.R_T:mc.R_T + 16].reshape(4, 4)
-        assert np.allclose(T[:3, :3].reshape(9), ores.R[:], atol=1e-9) and np.allclose(T[:3, 3], ores.t[:], atol=1e-9)
+        # north_star: final pose within 1e-5; the plane fits of the two paths differ by a few ulp, which the weakly constrained
+        # fixture (lambda_min 0.6 against entries of 1e4) amplifies to ~1e-8 over a dozen iterations
+        assert np.allclose(T[:3, :3].reshape(9), ores.R[:], atol=1e-7) and np.allclose(T[:3, 3], ores.t[:], atol=1e-7)
         if ologs:
             assert recs[k, mc.R_CORR] == ologs[-1].n_eff
 
