@@ -193,12 +193,14 @@ class Pair:
         self.mc = name.startswith("c5_")
         self.tgt, src = make_pair(w["scene"], w["n"], seed)
         self.n_src_total = len(src)
-        self.reducer = None
+        self.reducer, self.native = None, False
         if self.by_points:                                        # points: the same pair everywhere, this rank's slice
             from dcreg_amd import pointshard
             lo, hi = pointshard.slice_of(len(src), D.rank, D.world)
             src = np.ascontiguousarray(src[lo:hi])
-            self.reducer = pointshard.make_reducer(D.dist, D.cdev)
+            self.native = D.backend == "nccl"        # RCCL all_gather inside the C++ engine loop; gloo hook: Python callback
+            if not self.native:
+                self.reducer = pointshard.make_reducer(D.dist, D.cdev)
         self.src = src
         self.ctx = dcreg_amd.Context(D.local_rank)
         for kv in args.opt:
@@ -206,6 +208,9 @@ class Pair:
             self.ctx.set_option(k, float(v))
         self.ctx.set_target(self.tgt, w["radius"])
         self.ctx.set_source(src)
+        if self.by_points and self.native:
+            from dcreg_amd import pointshard
+            pointshard.init_native_exchange(self.ctx, D.dist, D.cdev)
         self.info = self.ctx.index_info()
         self.method = args.method
         self.det, self.hand = api.METHODS[args.method]
@@ -245,7 +250,10 @@ class Pair:
             self.cfg.max_iterations = n
             if self.by_points:
                 T = np.eye(4); T[:3, :3] = self.R.reshape(3, 3); T[:3, 3] = self.t
-                out, _ = self.ctx.icp_run_sharded(T, self.method, self.cfg, self.n_src_total, self.reducer, log_capacity=0)
+                if self.native:
+                    out, _ = self.ctx.icp_run_sharded_rccl(T, self.method, self.cfg, self.n_src_total, log_capacity=0)
+                else:
+                    out, _ = self.ctx.icp_run_sharded(T, self.method, self.cfg, self.n_src_total, self.reducer, log_capacity=0)
                 it, st = out.iterations, out.status
                 self.R[:] = out.R[:]; self.t[:] = out.t[:]
                 self.res.R[:] = out.R[:]; self.res.t[:] = out.t[:]

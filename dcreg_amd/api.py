@@ -118,6 +118,7 @@ EXPORTS = [
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
+    "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
 ]
 
 _lib = None
@@ -177,6 +178,12 @@ def load():
                                 C.POINTER(IcpResult)]
     L.dcreg_icp_run_sharded.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.c_int64, REDUCE_FN, vp,
                                         C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult)]
+    L.dcreg_comm_unique_id.argtypes = [vp]
+    L.dcreg_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.dcreg_comm_destroy.argtypes = [vp]
+    L.dcreg_comm_allgather_sum.argtypes = [vp, dp]
+    L.dcreg_icp_run_sharded_rccl.argtypes = [vp, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.c_int64, C.POINTER(IterLog), C.c_int,
+                                             C.POINTER(IcpResult)]
     L.dcreg_icp_run_many.argtypes = [C.c_int, C.POINTER(vp), dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IcpResult)]
     L.dcreg_icp_run_euler.argtypes = [vp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(IterLog), C.c_int,
                                       C.POINTER(IcpResult), dp]
@@ -276,6 +283,15 @@ def trial_pose(base_xyzrpy, seed, k, trans_amp, rot_amp_rad):
     if rc:
         raise DcregError("dcreg_trial_pose rc=%d" % rc)
     return T.reshape(4, 4)
+
+
+def comm_unique_id():
+    """dcreg_comm_unique_id: 128 opaque bytes identifying a new RCCL communicator (rank 0 calls it and shares the bytes)."""
+    buf = (C.c_char * 128)()
+    rc = load().dcreg_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc:
+        raise DcregError("dcreg_comm_unique_id rc=%d (RCCL unavailable?)" % rc)
+    return bytes(buf.raw)
 
 
 def icp_run_many(contexts, T0s, method, cfg):
@@ -452,6 +468,31 @@ class Context:
         if err:
             raise err[0]
         self._check(rc, "dcreg_icp_run_sharded")
+        n = min(res.iterations, cap)
+        if res.status == 1:
+            n = min(res.iterations - 1, cap)
+        return res, [logs[i] for i in range(max(n, 0))]
+
+    def comm_init(self, id128, rank, world):
+        """dcreg_comm_init: collective (every rank of the job calls it with the same 128 bytes from comm_unique_id())."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._check(self._L.dcreg_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)), "dcreg_comm_init")
+
+    def comm_allgather_sum(self, row):
+        row = _f64(row, 32).copy()
+        self._check(self._L.dcreg_comm_allgather_sum(self._h, _dp(row)), "dcreg_comm_allgather_sum")
+        return row
+
+    def icp_run_sharded_rccl(self, T0, method, cfg, n_source_total, log_capacity=None):
+        """dcreg_icp_run_sharded_rccl: point-sharded run, the per-iteration exchange is an RCCL all_gather inside the engine."""
+        T0 = _f64(T0).reshape(4, 4)
+        R0, t0 = np.ascontiguousarray(T0[:3, :3]).reshape(9), np.ascontiguousarray(T0[:3, 3])
+        det, hand = METHODS[method] if isinstance(method, str) else method
+        cap = cfg.max_iterations if log_capacity is None else log_capacity
+        logs = (IterLog * max(cap, 1))()
+        res = IcpResult()
+        self._check(self._L.dcreg_icp_run_sharded_rccl(self._h, _dp(R0), _dp(t0), DETECTION[det], HANDLING[hand], C.byref(cfg),
+                                                       int(n_source_total), logs, cap, C.byref(res)), "dcreg_icp_run_sharded_rccl")
         n = min(res.iterations, cap)
         if res.status == 1:
             n = min(res.iterations - 1, cap)

@@ -18,6 +18,7 @@ RUNNER = os.path.join(BINDIR, "icp_test_runner")
 SOURCES = [
     "device/context.hip",
     "device/metrics.hip",
+    "device/exchange.hip",
     "host/solver.cpp",
     "host/engine.cpp",
 ]
@@ -58,7 +59,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

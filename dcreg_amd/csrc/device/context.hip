@@ -585,6 +585,7 @@ int dcreg_backend_create(dcreg_ctx **out, int device) {
 
 void dcreg_backend_destroy(dcreg_ctx *c) {
     if (!c) return;
+    (void)dcreg_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,

@@ -84,6 +84,11 @@ struct dcreg_ctx {
     float *d_nn_d2 = nullptr; size_t nn_d2_cap = 0;
     double *d_p2p_part = nullptr; size_t p2p_part_cap = 0;
 
+    // native exchange of point-sharded runs (exchange.hip): an ncclComm_t on this ctx's device + staging rows
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    double *d_xrow = nullptr, *d_xall = nullptr, *h_xrow = nullptr, *h_xall = nullptr;
+
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
@@ -92,7 +97,7 @@ struct dcreg_ctx {
     bool need_set_device = true;
     unsigned long long seq = 0;
     int opt_lds_pad = 0;
-    int opt_xcd_chunk = 0;         // query-block -> XCD mapping (kernels.hpp xcd_remap)
+    int opt_xcd_chunk = 16;        // query-block -> XCD mapping (kernels.hpp xcd_remap): runs of 16 blocks round-robin (measured: C4 -13 %)
     bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;

@@ -1,0 +1,122 @@
+// The path's one real exchange step (point sharding of ONE scan pair): every rank linearises its slice of the
+// source, then the 32-double rows (21 H + 6 g + 4 sums + flag) of all ranks are all-gathered and added in rank order, so
+// every rank holds bitwise the same totals and takes the same host step - no broadcast.  Here the exchange is native:
+// ncclAllGather (RCCL over xGMI) on the ctx's stream, inside the C++ engine loop; a 256-byte message is latency-bound, not
+// link-bound.  RCCL is loaded lazily with dlopen so that libdcreg_hip.so does not drag the collective library into
+// single-GPU processes; the library already mapped by the process (torch ships one) is preferred.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include "../../../include/dcreg.h"
+#include "context.hpp"
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
+};
+
+RcclApi &rccl() {
+    static RcclApi api;
+    if (api.handle) return api;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.handle) break; }   // already in the process?
+    if (!api.handle) for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.handle) break; }
+    if (!api.handle) api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!api.handle) return api;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+    return api;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcreg_comm_unique_id(void *id128) {
+    if (!id128) return DCREG_E_INVALID;
+    RcclApi &A = rccl();
+    if (!A.ok()) return DCREG_E_DEVICE;
+    ncclUniqueId id;
+    if (A.GetUniqueId(&id) != ncclSuccess) return DCREG_E_DEVICE;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return DCREG_OK;
+}
+
+int dcreg_comm_destroy(dcreg_ctx *c) {
+    if (!c) return DCREG_E_INVALID;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        RcclApi &A = rccl();
+        if (A.ok()) (void)A.CommDestroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    if (c->d_xrow) { (void)hipFree(c->d_xrow); c->d_xrow = nullptr; }
+    if (c->d_xall) { (void)hipFree(c->d_xall); c->d_xall = nullptr; }
+    if (c->h_xrow) { (void)hipHostFree(c->h_xrow); c->h_xrow = nullptr; }
+    if (c->h_xall) { (void)hipHostFree(c->h_xall); c->h_xall = nullptr; }
+    c->comm_world = 0; c->comm_rank = 0;
+    return DCREG_OK;
+}
+
+int dcreg_comm_init(dcreg_ctx *c, const void *id128, int rank, int world) {
+    if (!c) return DCREG_E_INVALID;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { c->fail("invalid communicator arguments"); return DCREG_E_INVALID; }
+    RcclApi &A = rccl();
+    if (!A.ok()) { c->fail("RCCL is not available (dlopen librccl.so.1 failed: %s)", dlerror() ? dlerror() : "symbols missing"); return DCREG_E_DEVICE; }
+    (void)dcreg_comm_destroy(c);
+    if (hipSetDevice(c->device) != hipSuccess) { c->fail("hipSetDevice failed"); return DCREG_E_DEVICE; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = A.CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) { c->fail("ncclCommInitRank failed: %s", A.GetErrorString(r)); return DCREG_E_DEVICE; }
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    const size_t row = 32 * sizeof(double);
+    if (hipMalloc((void **)&c->d_xrow, row) != hipSuccess || hipMalloc((void **)&c->d_xall, row * (size_t)world) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_xrow, row, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_xall, row * (size_t)world, hipHostMallocDefault) != hipSuccess) {
+        (void)dcreg_comm_destroy(c);
+        c->fail("allocating the exchange buffers failed");
+        return DCREG_E_NOMEM;
+    }
+    return DCREG_OK;
+}
+
+// row[32] of this rank -> sum over all ranks, added in rank order (identical on every rank)
+int dcreg_comm_allgather_sum(dcreg_ctx *c, double row[32]) {
+    if (!c || !row) return DCREG_E_INVALID;
+    if (!c->comm) { c->fail("no communicator: call dcreg_comm_init first"); return DCREG_E_STATE; }
+    RcclApi &A = rccl();
+    const size_t bytes = 32 * sizeof(double);
+    std::memcpy(c->h_xrow, row, bytes);
+    hipError_t e = hipMemcpyAsync(c->d_xrow, c->h_xrow, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const ncclResult_t r = A.AllGather(c->d_xrow, c->d_xall, 32, ncclDouble, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess) { c->fail("ncclAllGather failed: %s", A.GetErrorString(r)); return DCREG_E_DEVICE; }
+        e = hipMemcpyAsync(c->h_xall, c->d_xall, bytes * (size_t)c->comm_world, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { c->fail("exchange failed: %s", hipGetErrorString(e)); return DCREG_E_DEVICE; }
+    for (int k = 0; k < 32; ++k) row[k] = 0.0;
+    for (int r = 0; r < c->comm_world; ++r)              // fixed association order
+        for (int k = 0; k < 32; ++k) row[k] += c->h_xall[(size_t)r * 32 + k];
+    return DCREG_OK;
+}
+
+}  // extern "C"

@@ -363,19 +363,14 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
     knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
-// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
-// (fx,fy,fz) = query position in cell units.  Ring kk is walked as its six FACES, not as (2kk+1)^2 rows:
-//   * a face whose cell layer lies beyond the current K-th best is dropped by arithmetic alone;
-//   * the empty-space field is read ONCE per remaining face, at the face cell under the query: if its nearest occupied
-//     cell is farther (Chebyshev) than the cap the K-th-best ball cuts out of the face, the whole cap is empty - a query
-//     hovering 6 cells off a wall asks 6 bytes per ring instead of walking ~250 empty cells;
-//   * the rows of a face are visited CENTRE-OUT (the row under the query first), so the heap holds near points before the
-//     far rows are tested, and each side stops at the first row the ball no longer reaches (distances grow monotonically);
-//   * every row's x-run is trimmed to the cells the K-th-best ball can still reach, as before.
-// Exact: a cell is skipped only when its minimal distance to the query exceeds the K-th best, or when the field proves it
-// empty.  Faces: +-z (rows y in [cy-kk, cy+kk]), +-y (rows z in (cz-kk, cz+kk)), +-x (single cells, y and z in the open range).
-#if defined(DCREG_SHELLS_V1)
-// round-1 ring walk (row sweep), kept for A/B builds: -DDCREG_SHELLS_V1
+#if !defined(DCREG_SHELLS_FACES)
+// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads: a sweep over
+// the (2kk+1)^2 (y,z) rows of ring kk in index order.  kd-tree style pruning on the grid: a row is skipped when its slab is
+// farther than the current K-th best, and its x-run is trimmed to the cells the K-th-best ball can still reach.
+// The loop bounds are the same for every lane of a wave, so the 64 queries walk the rows in lock-step; a face-by-face walk with
+// empty-space culling and centre-out row order (below, -DDCREG_SHELLS_FACES) visits 45 % fewer table entries and 60 % fewer rows
+// (host replay, scripts/emul_c4.py) and is still 25 % SLOWER on the GPU (profiles/r02_ablation.md): per-lane data-dependent
+// iteration order costs more than the visits it saves.
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
@@ -427,6 +422,18 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
 }
 
 #else
+// Experiment (rejected on measurement, see above).
+// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
+// (fx,fy,fz) = query position in cell units.  Ring kk is walked as its six FACES, not as (2kk+1)^2 rows:
+//   * a face whose cell layer lies beyond the current K-th best is dropped by arithmetic alone;
+//   * the empty-space field is read ONCE per remaining face, at the face cell under the query: if its nearest occupied
+//     cell is farther (Chebyshev) than the cap the K-th-best ball cuts out of the face, the whole cap is empty - a query
+//     hovering 6 cells off a wall asks 6 bytes per ring instead of walking ~250 empty cells;
+//   * the rows of a face are visited CENTRE-OUT (the row under the query first), so the heap holds near points before the
+//     far rows are tested, and each side stops at the first row the ball no longer reaches (distances grow monotonically);
+//   * every row's x-run is trimmed to the cells the K-th-best ball can still reach, as before.
+// Exact: a cell is skipped only when its minimal distance to the query exceeds the K-th best, or when the field proves it
+// empty.  Faces: +-z (rows y in [cy-kk, cy+kk]), +-y (rows z in (cz-kk, cz+kk)), +-x (single cells, y and z in the open range).
 // slab distance (metres, float) from the query (cell cq, cell coordinate f) to cell index c along one axis
 DCREG_DEVFN float slab_dist(int c, int cq, double f, float hf) {
     return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
@@ -546,7 +553,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
     }
 }
 
-#endif  // DCREG_SHELLS_V1
+#endif  // DCREG_SHELLS_FACES
 
 // ---------------------------------------------------------------- exact K-NN of one query (fast path + fallback)
 // Runs the 32-bit-key search; if (and only if) a point outside the result ties with the K-th best distance,

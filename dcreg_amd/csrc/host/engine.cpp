@@ -158,6 +158,14 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
     return rc_all;
 }
 
+static int rccl_reduce(double row[32], void *user) { return dcreg_comm_allgather_sum((dcreg_ctx *)user, row) == DCREG_OK ? 0 : 1; }
+
+int dcreg_icp_run_sharded_rccl(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
+                               const dcreg_config *cfg, int64_t n_source_total, dcreg_iter_log *log, int log_capacity,
+                               dcreg_icp_result *res) {
+    return dcreg_icp_run_sharded(ctx, R0, t0, detection, handling, cfg, n_source_total, rccl_reduce, ctx, log, log_capacity, res);
+}
+
 int dcreg_icp_run(dcreg_ctx *ctx, const double R0[9], const double t0[3], int detection, int handling,
                   const dcreg_config *cfg, dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res) {
     return dcreg_icp_run_sharded(ctx, R0, t0, detection, handling, cfg, 0, nullptr, nullptr, log, log_capacity, res);

@@ -9,8 +9,10 @@ Every rank holds the whole target (its own index) and a slice of the source poin
     all    :  host analyse / solve / SE(3) update (solver seam of the C-ABI) -> identical next pose on every rank
 
 so the ranks advance in lock-step without a broadcast.  Two drivers: `icp_run` below (Python loop over any `linearize`
-callable; what the CPU tests exercise) and `Context.icp_run_sharded` + `make_reducer` (the loop runs in the C++ engine,
-`dcreg_icp_run_sharded`, and calls back once per iteration for the exchange: what bench.py --sharding points uses).  Semantics per iteration are those of dcreg_icp_run
+callable; what the CPU tests exercise), `Context.icp_run_sharded` + `make_reducer` (the loop runs in the C++ engine,
+`dcreg_icp_run_sharded`, and calls back once per iteration for the exchange: any torch.distributed backend) and
+`init_native_exchange` + `Context.icp_run_sharded_rccl` (the exchange is an ncclAllGather issued by the engine itself on the
+ctx's stream: what bench.py --sharding points uses on the GPU node).  Semantics per iteration are those of dcreg_icp_run
 (DCReg/src/icp_test_runner.cpp:1611-2060): n_eff < 10 abort, non-finite update abort, convergence on |d omega|, |d t|.
 The sum of slice linearisations equals the linearisation of the whole cloud up to the association order of the fp64
 sums (tested: 1e-12 relative).  Trial / scan-pair sharding (dcreg_amd/montecarlo.py, bench.py --gpus N) remains the
@@ -77,6 +79,22 @@ def make_reducer(dist=None, device="cpu"):
             total = total + allr[r]
         row[:] = total
     return reduce_in_place
+
+
+def init_native_exchange(ctx, dist=None, device="cuda"):
+    """Set up the ctx's own RCCL communicator for dcreg_icp_run_sharded_rccl (the exchange then runs inside the C++ engine
+    loop, no Python callback per iteration).  Collective: rank 0 draws the 128-byte communicator id, torch.distributed carries
+    it to the other ranks (any backend), every rank calls dcreg_comm_init."""
+    import torch
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    buf = torch.zeros(128, dtype=torch.uint8, device=device if world > 1 else "cpu")
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(buf, src=0)
+    ctx.comm_init(bytes(buf.cpu().numpy().tobytes()), rank, world)
+    return rank, world
 
 
 def icp_run(linearize, n_src_total, T0, method, cfg, dist=None, device="cpu"):

@@ -252,6 +252,19 @@ int dcreg_icp_run_sharded(dcreg_ctx *, const double R0[9], const double t0[3], i
                           const dcreg_config *, int64_t n_source_total, dcreg_reduce_fn reduce, void *reduce_user,
                           dcreg_iter_log *log, int log_capacity, dcreg_icp_result *);
 
+/* The same with the exchange done natively: ONE ncclAllGather (RCCL over xGMI) of the 32-double rows per iteration on the
+ * ctx's stream, rows added in rank order, inside the C++ engine loop (no callback).  Set-up: rank 0 obtains 128 opaque bytes
+ * from dcreg_comm_unique_id and hands them to every rank by any means (the Python launcher broadcasts them with
+ * torch.distributed); every rank then calls dcreg_comm_init(ctx, id, rank, world) - collectively, like ncclCommInitRank - and
+ * dcreg_icp_run_sharded_rccl.  dcreg_comm_allgather_sum is the exchange step on its own.  RCCL is dlopen'ed on first use. */
+int dcreg_comm_unique_id(void *id128);
+int dcreg_comm_init(dcreg_ctx *, const void *id128, int rank, int world);
+int dcreg_comm_destroy(dcreg_ctx *);
+int dcreg_comm_allgather_sum(dcreg_ctx *, double row[32]);
+int dcreg_icp_run_sharded_rccl(dcreg_ctx *, const double R0[9], const double t0[3], int detection, int handling,
+                               const dcreg_config *, int64_t n_source_total, dcreg_iter_log *log, int log_capacity,
+                               dcreg_icp_result *);
+
 /* The second engine of the reference (selected by Config::use_so3_parameterization == false, icp_test_runner.cpp:443-458):
  * state = Pose6D {roll, pitch, yaw, x, y, z}, LOAM Jacobian with the float-stored weighted normal and no weight
  * derivative (:2296-2347), additive update (:2633-2638), convergence on |d rmse| < 1e-4 && |d fitness| < 1e-4

@@ -371,6 +371,62 @@ def test_sharded_engine_plumbing(ctx, cyl):
         ctx.icp_run_sharded(T0, "ME-SR", cfg, len(pts), boom)
 
 
+def test_native_rccl_exchange_world_of_one(cyl):
+    """dcreg_comm_* + dcreg_icp_run_sharded_rccl on the one GPU of the box: a communicator of one rank (the 8-GPU node runs the
+    same code with world = 8): the all_gather returns the row, the engine run is bitwise dcreg_icp_run."""
+    from dcreg_amd import pointshard as ps
+    pts, _ = cyl
+    c = api.Context(0)
+    try:
+        c.set_target(pts, 1.0); c.set_source(pts)
+        with pytest.raises(api.DcregError):
+            c.comm_allgather_sum(np.arange(32.0))                      # no communicator yet
+        assert ps.init_native_exchange(c) == (0, 1)
+        row = np.arange(32.0) * 0.5 - 3.0
+        assert np.array_equal(c.comm_allgather_sum(row), row)
+        T0 = h.pose6d_matrix(**h.PAPER_INIT)
+        cfg = _cfg(True)
+        a, la = c.icp_run(T0, "Ours", cfg)
+        b, lb = c.icp_run_sharded_rccl(T0, "Ours", cfg, len(pts))
+        assert a.iterations == b.iterations == 10 and a.converged == b.converged == 1
+        assert np.array_equal(np.array(a.R[:]), np.array(b.R[:])) and np.array_equal(np.array(a.t[:]), np.array(b.t[:]))
+        assert all(np.array_equal(np.array(x.H_upper[:]), np.array(y.H_upper[:])) and x.fitness == y.fitness for x, y in zip(la, lb))
+        assert ps.init_native_exchange(c) == (0, 1)                      # re-initialisation replaces the communicator
+    finally:
+        c.close()
+
+
+def test_sharded_run_never_leaves_a_rank_alone_in_the_exchange(cyl):
+    """A rank whose linearisation fails (no target here) still takes part in the exchange with a poisoned row, and every rank
+    stops together; an invalid total is refused before any exchange."""
+    pts, _ = cyl
+    c = api.Context(0)
+    try:
+        c.set_source(pts)                                             # target missing: dcreg_linearize would fail
+        calls = []
+
+        def reduce_rows(row):
+            calls.append(row.copy())                                  # a second, healthy rank would add its row here
+        res = api.IcpResult()
+        with pytest.raises(api.DcregError):
+            c.icp_run_sharded(h.pose6d_matrix(**h.PAPER_INIT), "Ours", _cfg(True), len(pts), reduce_rows)
+        assert len(calls) == 1 and calls[0][31] == 1.0 and np.all(calls[0][:31] == 0.0)
+        calls.clear()
+        c.set_target(pts, 1.0)
+
+        def poisoned_peer(row):
+            calls.append(1)
+            row[31] += 1.0                                            # another rank reports a failure
+        with pytest.raises(api.DcregError):
+            c.icp_run_sharded(h.pose6d_matrix(**h.PAPER_INIT), "Ours", _cfg(True), len(pts), poisoned_peer)
+        assert calls == [1]                                           # stopped after the first exchange, not before it
+        with pytest.raises(api.DcregError):
+            c.icp_run_sharded(h.pose6d_matrix(**h.PAPER_INIT), "Ours", _cfg(True), 0, poisoned_peer)
+        assert calls == [1]                                           # refused up front: no exchange entered
+    finally:
+        c.close()
+
+
 def test_run_many_equals_individual_runs(cyl):
     """dcreg_icp_run_many: independent pairs on their own contexts / streams / host threads give exactly the results of
     running each pair alone."""
