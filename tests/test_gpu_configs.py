@@ -182,5 +182,6 @@ def test_covariance_of_the_so3_engine_on_the_committed_run(ctx):
         ores, ologs = po.icp_run(po.KdTree(pts), pts, T0, method, ocfg)
         assert res.converged == ores.converged and (method != "Ours" or res.converged == 1)
         assert_cov_equal(res, ores)
-        Hl = api.unpack_hessian(np.array(logs[-1].H_upper[:]))
-        assert h.rel_err(np.array(res.icp_cov[:]).reshape(6, 6) @ Hl, np.eye(6)) < 1e-8
+        if res.converged:
+            Hl = api.unpack_hessian(np.array(logs[-1].H_upper[:]))
+            assert h.rel_err(np.array(res.icp_cov[:]).reshape(6, 6) @ Hl, np.eye(6)) < 1e-8
