@@ -3,10 +3,11 @@
 // every rank holds bitwise the same totals and takes the same host step - no broadcast.  Here the exchange is native:
 // ncclAllGather (RCCL over xGMI) on the ctx's stream, inside the C++ engine loop; a 256-byte message is latency-bound, not
 // link-bound.  RCCL is loaded lazily with dlopen so that libdcreg_hip.so does not drag the collective library into
-// single-GPU processes; the library already mapped by the process (torch ships one) is preferred.
+// single-GPU processes.
 #include <dlfcn.h>
 
 #include <cstring>
+#include <string>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -26,13 +27,23 @@ struct RcclApi {
     bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
 };
 
+// A process may hold two HIP runtimes (PyTorch ships its own libamdhip64 next to its own librccl; /opt/rocm has another
+// pair).  Device pointers and streams of one runtime mean nothing to the other, so the RCCL to use is the one that sits next
+// to the HIP runtime THIS library is bound to - found by asking the loader where hipMalloc lives.
 RcclApi &rccl() {
     static RcclApi api;
     if (api.handle) return api;
+    std::string dir;
+    Dl_info info;
+    if (dladdr((void *)&hipMalloc, &info) && info.dli_fname) {
+        dir = info.dli_fname;
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+    }
     const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.handle) break; }   // already in the process?
+    if (!dir.empty())
+        for (const char *n : names) { api.handle = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL); if (api.handle) break; }
     if (!api.handle) for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.handle) break; }
-    if (!api.handle) api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!api.handle) return api;
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
