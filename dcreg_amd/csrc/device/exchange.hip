@@ -35,7 +35,7 @@ RcclApi &rccl() {
     if (api.handle) return api;
     std::string dir;
     Dl_info info;
-    if (dladdr((void *)&hipMalloc, &info) && info.dli_fname) {
+    if (dladdr((void *)static_cast<hipError_t (*)(void **, size_t)>(&hipMalloc), &info) && info.dli_fname) {
         dir = info.dli_fname;
         const size_t slash = dir.rfind('/');
         dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
