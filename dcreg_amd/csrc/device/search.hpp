@@ -79,6 +79,7 @@ struct LinArgs {
 template <int K_>
 struct HeapExact {
     static constexpr int K = K_;
+    static constexpr bool kDeferred = false;
     uint64_t key[K];
     uint32_t pos[K];
     uint32_t n_eval;     // candidates evaluated (statistics only; dead code unless read)
@@ -117,6 +118,13 @@ struct HeapExact {
 template <int K_>
 struct HeapFast {
     static constexpr int K = K_;
+#if defined(DCREG_NO_DEFER)
+    static constexpr bool kDeferred = false;
+#else
+    static constexpr bool kDeferred = true;
+#endif
+    // a point that was never offered to push() (filtered out by a bound >= the K-th best) stays outside at distance d2
+    DCREG_DEVFN void note_outside(float d2) { outside_min = fminf(outside_min, d2); }
     float d[K];
     uint32_t pos[K];
     float outside_min;   // smallest d2 among all points seen that are not in the heap
@@ -131,8 +139,9 @@ struct HeapFast {
     // accepts almost every candidate, so a divergent "if (d2 < worst)" is taken anyway and only adds exec-mask
     // juggling and merge copies.  Sorted insertion without a dependency chain: entry i becomes the median of
     // (d[i-1], d[i], d2); positions follow the same selection through the masks c[i] = d2 < d[i] (ties stay behind).
+    template <bool COUNT = true>
     DCREG_DEVFN void push(float d2, uint32_t /*idx*/, uint32_t p, bool valid = true) {
-        n_eval += valid ? 1u : 0u;
+        if (COUNT) n_eval += valid ? 1u : 0u;
 #if DCREG_ON_DEVICE
         if constexpr (K == 5) {
             // 21 VALU instructions, written out: the compiler's select canonicalisation turns the nine position
@@ -223,11 +232,29 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
 // Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
 // Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
 // divergent candidate loop costs one ds_read instead of a 9-way register select.
+//
+// Deferred insertion (DCREG_DEFER, the default): while the runs are scanned a candidate is only FILTERED against the lane's
+// bound (one compare instead of the 21-instruction sorted insertion) and, if it passes, appended to the lane's pending list;
+// the list is inserted into the heap when some lane of the wave is about to run out of room, and at the end.  With a warm
+// bound ~6 of a query's ~34 candidates pass, so the insertion network runs ~10 times per wave instead of ~63 (it runs for
+// every lane whenever ANY lane has a candidate, which is always).  The pushes reach the heap in scan order, so the result -
+// neighbour set, order among ties, the exact-tie flag - is the one the immediate insertion gives (search.hpp knn_search).
+constexpr int kPend = 7;
+struct PendEntry { uint32_t d2_bits, pos; };
 struct RunList {
     uint32_t s[9][kBlock];
     uint32_t e[9][kBlock];
-    float gap2[9][kBlock];     // squared distance from the query to the row's (y,z) slab
+    uint16_t gap2h[9][kBlock];    // squared distance from the query to the row's (y,z) slab: upper half of the float, i.e.
+                                  // rounded toward zero - a row is never pruned on a distance it does not have
+    PendEntry pend[kPend][kBlock];
 };
+DCREG_DEVFN bool wave_any(bool x) {
+#if DCREG_ON_DEVICE
+    return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#else
+    return x;
+#endif
+}
 
 template <class H>
 DCREG_DEVFN void push_point(H &hp, float qx, float qy, float qz, const float4 &c, uint32_t p, bool valid) {
@@ -305,7 +332,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             if (re[r] > rs[r]) {
-                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2[nrun][tid] = g2s[r];
+                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2h[nrun][tid] = (uint16_t)(__float_as_uint(g2s[r]) >> 16);
                 ++nrun;
             }
         }
@@ -316,13 +343,17 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
     {
         int ri = 0;
         uint32_t p = 0, e = 0;
+        // deferred insertion state: lim = the lane's filter bound (the heap's K-th best as of the last flush: nothing at or
+        // beyond it can enter), om = smallest distance among the candidates filtered out, cnt = pending entries
+        float lim = bound_f, om = __builtin_inff();
+        int cnt = 0;
         // switch to the next listed row (one per call, no inner loop: a row that the K-th best has meanwhile put out
         // of reach becomes an empty run and costs one idle trip, which is rare once the search is bounded)
         auto next_run = [&]() {
-            const float g2 = rl.gap2[ri][tid];
+            const float g2 = __uint_as_float((uint32_t)rl.gap2h[ri][tid] << 16);
             const uint32_t s_ = rl.s[ri][tid], e_ = rl.e[ri][tid];
             ++ri;
-            const bool keep = !(g2 > hp.worst_d2());
+            const bool keep = !(g2 > (H::kDeferred ? lim : hp.worst_d2()));
             p = keep ? s_ : 0u; e = keep ? e_ : 0u;
             DCREG_STAT(runs);
         };
@@ -347,16 +378,44 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
                 }
             }
         };
+        auto flush = [&]() {
+            if constexpr (H::kDeferred) {
+                for (int j = 0; j < cnt; ++j) {
+                    const PendEntry pe = rl.pend[j][tid];
+                    hp.template push<false>(__uint_as_float(pe.d2_bits), 0u, pe.pos, true);
+                }
+                cnt = 0;
+                lim = hp.worst_d2();
+            }
+        };
         auto consume = [&](const Slot &sl) {
+            if constexpr (H::kDeferred) {
 #pragma unroll
-            for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, sl.c[u], sl.cp + u, sl.cp + u < sl.ce);
+                for (int u = 0; u < W; ++u) {
+                    const float d2 = dist2_nofma(qx, qy, qz, sl.c[u]);
+                    const bool valid = sl.cp + u < sl.ce;
+                    const bool pass = valid && d2 < lim;
+                    hp.n_eval += valid ? 1u : 0u;
+                    if (pass) { rl.pend[cnt][tid] = PendEntry{__float_as_uint(d2), sl.cp + u}; ++cnt; }
+                    om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, sl.c[u], sl.cp + u, sl.cp + u < sl.ce);
+            }
         };
         Slot A, B;
         fetch(A);
         while (A.live) {
+            if (H::kDeferred && wave_any(cnt > kPend - W)) flush();      // room for the next W candidates in every lane
             fetch(B); consume(A);
             if (!B.live) break;
+            if (H::kDeferred && wave_any(cnt > kPend - W)) flush();
             fetch(A); consume(B);
+        }
+        if constexpr (H::kDeferred) {
+            flush();
+            hp.note_outside(om);
         }
     }
     if (stamp) stamp[1] = clock64();

@@ -17,8 +17,8 @@ for kv in sys.argv[2:]:
     k, v = kv.split("="); ctx.set_option(k, float(v))
 ctx.set_target(tgt, radius); ctx.set_source(src)
 cfg = api.default_config(search_radius=radius, max_iterations=run_len, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0,
-                         CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0, use_weight_derivative=1, always_compute_schur=1)
-T_init = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
+                         CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0, use_weight_derivative=W["wd"], always_compute_schur=1)
+T_init = bench.initial_pose(scene)
 for rep in range(3):
     res, logs = ctx.icp_run(T_init, "Ours", cfg)
 t = np.array([L.iter_time_ms for L in logs]) * 1e3
