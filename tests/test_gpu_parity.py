@@ -427,6 +427,53 @@ def test_sharded_run_never_leaves_a_rank_alone_in_the_exchange(cyl):
         c.close()
 
 
+def test_in_kernel_reduction_is_stable_under_uneven_load():
+    """The fused reduction hands partial rows from block to block through agent-scope (sc1) stores / loads and a ticket, without
+    release / acquire fences (a fence is a full L2 write-back on gfx950).  That protocol is one of the hand-off forms measured
+    valid on this chip, but it is a property of the hardware, not of the language: hammer it.  6000 launches that reuse the same
+    partial-row buffer, alternating poses (so a stale row would belong to the OTHER pose and change the sums), while a second
+    context keeps the device unevenly busy with large launches; every result must be bitwise the first one of its pose."""
+    import threading
+    tgt = h.scene_cylinder(60_000, seed=21, noise=0.01)
+    rng = np.random.default_rng(3)
+    src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
+    big = h.scene_corridor(400_000, seed=5)
+    a, b = api.Context(0), api.Context(0)
+    stop = threading.Event()
+    try:
+        a.set_target(tgt, 1.0); a.set_source(src)
+        b.set_target(big, 1.0); b.set_source(big)
+
+        def noise():
+            k = 0
+            while not stop.is_set():
+                T = h.pose6d_matrix(0.01 * (k % 7), 0.0, 0.0, 0.0, 0.0, 0.001 * (k % 5))
+                b.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(1.0, 1))
+                k += 1
+        th = threading.Thread(target=noise)
+        th.start()
+        poses = [h.pose6d_matrix(0.05, -0.08, 0.03, 0.003, -0.002, 0.008), h.pose6d_matrix(-0.02, 0.04, 0.01, -0.001, 0.002, -0.004)]
+        prm = api.default_lin_params(1.0, 1)
+        out = api.LinOut()
+        import ctypes as C
+        Rs = [np.ascontiguousarray(T[:3, :3]).reshape(9) for T in poses]
+        ts = [np.ascontiguousarray(T[:3, 3]) for T in poses]
+        first = [None, None]
+        for it in range(6000):
+            k = it & 1
+            assert a.linearize_raw(Rs[k], ts[k], prm, out) == 0
+            row = (np.array(out.H_upper[:]), np.array(out.g[:]), out.sum_r2, out.sum_b2, out.n_eff, out.n_pt)
+            if first[k] is None:
+                first[k] = row
+            else:
+                assert np.array_equal(row[0], first[k][0]) and np.array_equal(row[1], first[k][1]) and row[2:] == first[k][2:], it
+        assert not np.array_equal(first[0][0], first[1][0])
+    finally:
+        stop.set()
+        th.join()
+        a.close(); b.close()
+
+
 def test_run_many_equals_individual_runs(cyl):
     """dcreg_icp_run_many: independent pairs on their own contexts / streams / host threads give exactly the results of
     running each pair alone."""
