@@ -5,6 +5,9 @@
 // link-bound.  RCCL is loaded lazily with dlopen so that libdcreg_hip.so does not drag the collective library into
 // single-GPU processes.
 #include <dlfcn.h>
+#include <unistd.h>
+
+#include <cstdio>
 
 #include <cstring>
 #include <string>
@@ -95,7 +98,14 @@ int dcreg_comm_init(dcreg_ctx *c, const void *id128, int rank, int world) {
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     ncclComm_t comm = nullptr;
+    // RCCL prints a version banner on stdout during the first initialisation; stdout belongs to the caller (bench.py prints
+    // exactly one JSON line there), so the banner is sent to stderr
+    std::fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
     const ncclResult_t r = A.CommInitRank(&comm, world, id, rank);
+    std::fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
     if (r != ncclSuccess) { c->fail("ncclCommInitRank failed: %s", A.GetErrorString(r)); return DCREG_E_DEVICE; }
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
     const size_t row = 32 * sizeof(double);
