@@ -379,7 +379,7 @@ class Context:
         n = self.index_info().n_source
         keep = {"nn_idx": np.full((n, 5), -1, np.int32), "nn_d2": np.full((n, 5), np.inf, np.float32),
                 "flag": np.zeros(n, np.uint8), "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n),
-                "stats": np.zeros(n, np.uint32), "clocks": np.zeros(((n + 63) // 64 + 4, 8), np.uint64)}
+                "stats": np.zeros(n, np.uint32), "clocks": np.zeros(((n + 63) // 64 + 4, 16), np.uint64)}
         dbg = LinDebug(keep["nn_idx"].ctypes.data_as(C.POINTER(C.c_int32)), keep["nn_d2"].ctypes.data_as(C.POINTER(C.c_float)),
                        keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8)), _dp(keep["normal"]), _dp(keep["r"]), _dp(keep["s"]),
                        keep["stats"].ctypes.data_as(C.POINTER(C.c_uint32)), keep["clocks"].ctypes.data_as(C.POINTER(C.c_uint64)))

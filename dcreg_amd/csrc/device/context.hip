@@ -400,7 +400,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (dbg_host->r) dd.r = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
-        if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 8 * ((n + 63) / 64 + 4), 0);
+        if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 16 * ((n + 63) / 64 + 4), 0);
         if (oom) { free_tmp(S); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
@@ -444,7 +444,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         back(dbg_host->r, dd.r, sizeof(double) * n);
         back(dbg_host->s, dd.s, sizeof(double) * n);
         back(dbg_host->stats, dd.stats, sizeof(uint32_t) * n);
-        back(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 8 * ((n + 63) / 64));
+        back(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 16 * ((n + 63) / 64));
         if (ce != hipSuccess) {
             (void)hipStreamSynchronize(c->stream);
             free_tmp(S);

@@ -168,7 +168,7 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     PointQuery q;
     KnnResult<5> nn;
-    unsigned long long sst[3] = {0, 0, 0};
+    unsigned long long sst[7] = {0, 0, 0, 0, 0, 0, 0};   // search sub-phase stamps; [3..6] ring-walk cycle / count sums (search.hpp)
     if (MODE == 1) clk[1] = clock64();
     // batched launches: every pose owns a warm-start state of its own, selected by the pose's state slot
     uint32_t *prev = a.prev ? a.prev + (size_t)P.state * 5u * a.prev_stride : nullptr;
@@ -246,11 +246,14 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     }
     if (MODE == 1 && dbg.clocks && lane == 0) {
         clk[5] = clock64();
-        unsigned long long *o = dbg.clocks + ((size_t)vb * (kBlock / 64) + wave) * 8;
+        unsigned long long *o = dbg.clocks + ((size_t)vb * (kBlock / 64) + wave) * 16;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = clk[k];
         o[6] = sst[0] ? (sst[0] - clk[1]) | ((sst[1] - sst[0]) << 20) | ((sst[2] - sst[1]) << 40) : 0;   // phase A | phase B | shells
         o[7] = blockIdx.x;
+        // ring walk of lane 0 of the wave (search.hpp knn_shells): cycles inside the candidate scans, cycles waiting for table
+        // entries, row iterations, scans
+        o[8] = sst[3]; o[9] = sst[4]; o[10] = sst[5]; o[11] = sst[6];
     }
 }
 

@@ -34,9 +34,11 @@ namespace dcreg {
 #if DCREG_ON_DEVICE
 DCREG_DEVFN float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 #define DCREG_STAT(field) ((void)0)
+#define DCREG_TRACE(kk, dz, dy, which, trips) ((void)0)
 #else
 inline float med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define DCREG_STAT(field) (++emu_stats.field)
+#define DCREG_TRACE(kk, dz, dy, which, trips) emu_trace_push(((((uint32_t)(kk) << 20) | ((uint32_t)((dz) + 512) << 10) | (uint32_t)((dy) + 512)) << 1) | (uint32_t)(which), (uint32_t)(trips))
 #endif
 
 constexpr int kBlock = 256;          // 4 waves
@@ -228,7 +230,8 @@ DCREG_DEVFN int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? h
 
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp,
+                                           unsigned long long *stamp = nullptr);
 
 // Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
 // Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
@@ -420,20 +423,27 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         }
     }
     if (stamp) stamp[1] = clock64();
-    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp, stamp);
 }
 
 #if !defined(DCREG_SHELLS_FACES)
-// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads: a sweep over
-// the (2kk+1)^2 (y,z) rows of ring kk in index order.  kd-tree style pruning on the grid: a row is skipped when its slab is
-// farther than the current K-th best, and its x-run is trimmed to the cells the K-th-best ball can still reach.
-// The loop bounds are the same for every lane of a wave, so the 64 queries walk the rows in lock-step; a face-by-face walk with
-// empty-space culling and centre-out row order (below, -DDCREG_SHELLS_FACES) visits 45 % fewer table entries and 60 % fewer rows
-// (host replay, scripts/emul_c4.py) and is still 25 % SLOWER on the GPU (profiles/r02_ablation.md): per-lane data-dependent
-// iteration order costs more than the visits it saves.
+// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
+// Ring kk = the surface of the cube of Chebyshev radius kk: its z faces and y faces are swept as (y,z) rows with the x-run of each
+// row trimmed to the cells the K-th-best ball can still reach (kd-tree style pruning on the grid); of the rows in between only the
+// two END CELLS belong to the ring (the x faces).  Measured on the GPU (instrumented kernel, scripts/c4_first_iters.py, C4's first
+// iteration, the slowest 1 % of the waves): of 857 k ring-walk cycles per wave 17 % were candidate scans, 8 % waits for table entries
+// and 76 % the row loop itself - round 1 walked all (2kk+1)^2 rows of every ring with the full x-range arithmetic (sqrt, two double
+// floors) although (2kk-1)^2 of them can only contribute an end cell.  So:
+//   * x faces: a cell (cx -+ kk, y, z) is reachable iff gx^2 + gy^2 + gz^2 <= K-th best with gx fixed for the ring - two compares per
+//     row, and the (y,z) loops stop at the radius the ball still has at that x distance;
+//   * faces whose cell layer lies beyond the K-th best are not entered;
+//   * the loop bounds are uniform over the wave's lanes up to that radius, so the 64 queries stay in lock-step (a face walk with
+//     per-lane iteration order, empty-space culling per face and centre-out rows - below, -DDCREG_SHELLS_FACES - visited fewer rows
+//     and was 25 % slower; batching the table loads of four rows, a flattened collect-then-scan walk and a 2x2x2 block occupancy
+//     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp, unsigned long long *stamp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
     // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
@@ -442,6 +452,38 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
         k0 = max(1, f - 1);
     }
+    // instrumented builds (MODE 1, stamp != null): stamp[3] += cycles inside the candidate scans, [4] += cycles waiting for table
+    // entries, [5] += row iterations, [6] += scans
+    auto lookup_scan = [&](int64_t c0, int64_t c1) {
+        DCREG_STAT(table_loads); DCREG_STAT(table_loads); DCREG_STAT(faces);
+        unsigned long long t_a = stamp ? clock64() : 0ull;
+        uint32_t s_ = g.cell_start[c0], e_ = g.cell_start[c1];
+#if DCREG_ON_DEVICE
+        if (stamp) asm volatile("" : "+v"(s_), "+v"(e_));      // the entries have arrived
+#endif
+        unsigned long long t_b = stamp ? clock64() : 0ull;
+        scan_run<H>(g, s_, e_, qx, qy, qz, hp);
+        if (stamp) { stamp[4] += t_b - t_a; stamp[3] += clock64() - t_b; stamp[6] += 1; }
+    };
+    // slab distance (metres, float) from the query to cell index c along an axis (cq = the query's cell, f = its cell coordinate)
+    auto slab = [&](int c, int cq, double f) -> float {
+        return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
+    };
+    // one (y,z) row of a z or y face: x-run [cx-kk, cx+kk] trimmed to the ball (conservative), then scanned
+    auto face_row = [&](int y, int z, float dyz, int kk, int dz, int dy) {
+        if (stamp) stamp[5] += 1;
+        DCREG_STAT(rows);
+        const float w = hp.worst_d2();
+        if (dyz > w) return;
+        const float xr = sqrtf(w - dyz) * 1.00001f + 1e-6f * hf;
+        const double xr_c = (double)xr * g.inv_h;
+        const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
+        const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
+        if (x1 <= x0) return;
+        const int64_t row = ((int64_t)z * ny + y) * nx;
+        DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + x1] - g.cell_start[row + x0] + 3u) / 4u);
+        lookup_scan(row + x0, row + x1);
+    };
     for (int k = k0; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
@@ -450,31 +492,64 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
         const int kk = k + 1;                                   // scan shell kk
         hp.n_shell = (uint32_t)kk;
-        const int z_lo = max(cz - kk, 0), z_hi = min(cz + kk, nz - 1);
-        const int y_lo = max(cy - kk, 0), y_hi = min(cy + kk, ny - 1);
-        for (int z = z_lo; z <= z_hi; ++z) {
-            const int dz = z - cz;
-            const float gz = dz < 0 ? (float)(fz - (double)(z + 1)) * hf : (dz > 0 ? (float)((double)z - fz) * hf : 0.f);
-            if (gz * gz * 0.99999f > hp.worst_d2()) continue;
-            for (int y = y_lo; y <= y_hi; ++y) {
-                const int dy = y - cy;
-                const float gy = dy < 0 ? (float)(fy - (double)(y + 1)) * hf : (dy > 0 ? (float)((double)y - fy) * hf : 0.f);
-                const float dyz = (gy * gy + gz * gz) * 0.99999f;
-                const float w = hp.worst_d2();
-                if (dyz > w) continue;
-                // cells the ball of radius sqrt(w) around q can reach in this row (conservative)
-                const float xr = sqrtf(w - dyz) * 1.00001f + 1e-6f * hf;
-                const double xr_c = (double)xr * g.inv_h;
-                const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
-                const int64_t row = ((int64_t)z * ny + y) * nx;
-                const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
-                if (full) {
-                    const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
-                    if (x1 > x0) scan_run<H>(g, g.cell_start[row + x0], g.cell_start[row + x1], qx, qy, qz, hp);
-                } else {
-                    const int xa = cx - kk, xb = cx + kk;
-                    if (xa >= 0 && xa < nx && xa >= xmin) scan_run<H>(g, g.cell_start[row + xa], g.cell_start[row + xa + 1], qx, qy, qz, hp);
-                    if (xb >= 0 && xb < nx && xb <= xmax) scan_run<H>(g, g.cell_start[row + xb], g.cell_start[row + xb + 1], qx, qy, qz, hp);
+        // ---- z faces: layers z = cz -+ kk, rows y = cy-kk .. cy+kk
+        for (int sz = -1; sz <= 1; sz += 2) {
+            const int z = cz + sz * kk;
+            const float gz = slab(z, cz, fz);
+            const bool zin = z >= 0 && z < nz && !(gz * gz * 0.99999f > hp.worst_d2());
+            if (!wave_any(zin)) continue;
+            for (int dy = -kk; dy <= kk; ++dy) {
+                const int y = cy + dy;
+                if (!(zin && y >= 0 && y < ny)) continue;
+                const float gy = slab(y, cy, fy);
+                face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, sz * kk, dy);
+            }
+        }
+        // ---- y faces: layers y = cy -+ kk, rows z = cz-kk+1 .. cz+kk-1
+        for (int sy = -1; sy <= 1; sy += 2) {
+            const int y = cy + sy * kk;
+            const float gy = slab(y, cy, fy);
+            const bool yin = y >= 0 && y < ny && !(gy * gy * 0.99999f > hp.worst_d2());
+            if (!wave_any(yin)) continue;
+            for (int dz = -kk + 1; dz <= kk - 1; ++dz) {
+                const int z = cz + dz;
+                if (!(yin && z >= 0 && z < nz)) continue;
+                const float gz = slab(z, cz, fz);
+                face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, dz, sy * kk);
+            }
+        }
+        // ---- x faces: the end cells (cx -+ kk, y, z) of the rows in between.  gx is fixed for the ring: the cell is reachable iff
+        // gx^2 + gy^2 + gz^2 <= K-th best, and rows farther than the ball's radius at that x distance need not be visited at all
+        {
+            const int xa = cx - kk, xb = cx + kk;
+            const bool a_in = xa >= 0 && xa < nx, b_in = xb >= 0 && xb < nx;
+            const float gxa = slab(xa, cx, fx), gxb = slab(xb, cx, fx);
+            const float gxa2 = a_in ? gxa * gxa * 0.99999f : __builtin_inff(), gxb2 = b_in ? gxb * gxb * 0.99999f : __builtin_inff();
+            const float w0 = hp.worst_d2();
+            const float rmax = fmaxf(w0 - gxa2, w0 - gxb2);     // squared (y,z) radius the ball still has on the nearer x face
+            // a row at offset o != 0 from the query's row is at least (|o| - 1) cells away: rows beyond m cannot be reached
+            const double m_c = (double)(sqrtf(fmaxf(rmax, 0.f)) * 1.00001f) * g.inv_h;     // may be astronomically large (unbounded searches)
+            const int m = rmax >= 0.f ? (m_c >= (double)kk ? kk - 1 : min(kk - 1, (int)m_c + 2)) : -1;
+            const bool any_x = rmax >= 0.f;
+            const int m_w = any_x ? m : -1;
+            // (per-lane bound m; the wave runs to the largest)
+            for (int dz = -m_w; dz <= m_w; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z >= nz) continue;
+                const float gz = slab(z, cz, fz);
+                const float gz2 = gz * gz;
+                if (fminf(gxa2, gxb2) + gz2 * 0.99999f > hp.worst_d2()) continue;
+                for (int dy = -m_w; dy <= m_w; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= ny) continue;
+                    if (stamp) stamp[5] += 1;
+                    DCREG_STAT(rows);
+                    const float gy = slab(y, cy, fy);
+                    const float dyz = (gy * gy + gz2) * 0.99999f;
+                    const float w = hp.worst_d2();
+                    const int64_t row = ((int64_t)z * ny + y) * nx;
+                    if (gxa2 + dyz <= w) { DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + xa + 1] - g.cell_start[row + xa] + 3u) / 4u); lookup_scan(row + xa, row + xa + 1); }
+                    if (gxb2 + dyz <= hp.worst_d2()) { DCREG_TRACE(kk, dz, dy, 1, (g.cell_start[row + xb + 1] - g.cell_start[row + xb] + 3u) / 4u); lookup_scan(row + xb, row + xb + 1); }
                 }
             }
         }
@@ -519,7 +594,7 @@ struct CentreOut {
 
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp, unsigned long long * /*stamp*/) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
     // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point

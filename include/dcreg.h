@@ -97,8 +97,9 @@ typedef struct dcreg_lin_debug {
     double *r;       /* [n] */
     double *s;       /* [n] */
     uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 */
-    uint64_t *clocks; /* [8 * ceil(n/64)] per-wave shader-clock stamps: start, query ready, search done, rows done,
-                         wave reduced, end, packed search sub-phases, hw block id */
+    uint64_t *clocks; /* [16 * ceil(n/64)] per-wave shader-clock stamps: start, query ready, search done, rows done,
+                         wave reduced, end, packed search sub-phases, hw block id; [8..11] ring walk of lane 0: cycles in
+                         candidate scans, cycles waiting for table entries, row iterations, scans; [12..15] unused */
 } dcreg_lin_debug;
 
 typedef struct dcreg_index_info {

@@ -41,7 +41,7 @@ def lib():
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
-                                    C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+                                    C.c_void_p, C.c_int64] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64]
         L.emu_plane_fit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         _lib = L
@@ -70,6 +70,8 @@ class Index:
     """The device's grid index over a target cloud, built on the host."""
 
     def __init__(self, xyz, radius, cell=0.0, cell_factor=2.0, gap_field=True):
+        """gap_field: True / False = with / without the empty-space distance field (the block occupancy bitmap is built either
+        way); -1 = neither structure."""
         self.xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         self.radius = radius
         self.ptr = lib().emu_index_build(_ptr(self.xyz), len(self.xyz), float(radius), float(cell), float(cell_factor), int(gap_field))
@@ -107,7 +109,7 @@ class Source:
         self.prev = None
 
 
-def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False):
+def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0):
     """One linearisation through the device functions on the host -> dict like Context.linearize (+ "stats" [n, 8] in
     processing order: candidates, outermost shell, table loads, rows, runs, trips, faces, face skips)."""
     radius = index.radius if radius is None else radius
@@ -122,16 +124,19 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
         keep = {"nn_idx": np.full((n, 5), -1, np.int32), "nn_d2": np.full((n, 5), np.inf, np.float32), "flag": np.zeros(n, np.uint8),
                 "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n)}
     st = np.zeros((n, 8), np.uint32) if stats else None
+    tr = np.zeros((n, trace_cap), np.uint32) if trace_cap else None
     R = np.ascontiguousarray(R, np.float64).reshape(9)
     t = np.ascontiguousarray(t, np.float64).reshape(3)
     lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(prev), source.stride,
                         _ptr(out), _ptr(keep.get("nn_idx")), _ptr(keep.get("nn_d2")), _ptr(keep.get("flag")), _ptr(keep.get("normal")),
-                        _ptr(keep.get("r")), _ptr(keep.get("s")), _ptr(st))
+                        _ptr(keep.get("r")), _ptr(keep.get("s")), _ptr(st), _ptr(tr), int(trace_cap))
     res = {"H_upper": out[:21].copy(), "g": out[21:27].copy(), "sum_r2": out[27], "sum_b2": out[28], "n_eff": int(round(out[29])),
            "n_pt": int(round(out[30]))}
     res.update(keep)
     if stats:
         res["stats"] = st
+    if trace_cap:
+        res["trace"] = tr          # per query (processing order): (key, trips) pairs of the ring walk's scans, last word = words used
     return res
 
 

@@ -182,7 +182,7 @@ struct EmuLinParams {
 // {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}.
 int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_t n, const double R[9], const double t[3],
                   const EmuLinParams *p, uint32_t *prev, int64_t prev_stride, double *out32, int32_t *nn_idx, float *nn_d2,
-                  uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats) {
+                  uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats, uint32_t *trace, int64_t trace_cap_per_query) {
     EmuIndex *E = (EmuIndex *)idx;
     const GridDev &g = E->g;
     LinArgs a{};
@@ -208,7 +208,9 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         PointQuery q;
         KnnResult<5> nn;
         emu_stats = EmuStats{};
+        if (trace) { emu_trace.buf = trace + (size_t)i * (size_t)trace_cap_per_query; emu_trace.cap = (uint32_t)trace_cap_per_query - 1; emu_trace.n = 0; }
         lin_search(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
+        if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
         double acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
         for (double &v : acc) v = 0.0;
         const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, acc, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, acc, nrm, rr, ss);

@@ -27,3 +27,9 @@ struct EmuStats {
     uint32_t face_skips;      // shell faces skipped by the empty-space field
 };
 static thread_local EmuStats emu_stats;
+// optional trace of the ring walk: (ring << 20 | (dz + 512) << 10 | (dy + 512)) * 2 + which, trips
+struct EmuTrace { uint32_t *buf = nullptr; uint32_t cap = 0, n = 0; };
+static thread_local EmuTrace emu_trace;
+inline void emu_trace_push(uint32_t key, uint32_t trips) {
+    if (emu_trace.buf && emu_trace.n + 2 <= emu_trace.cap) { emu_trace.buf[emu_trace.n++] = key; emu_trace.buf[emu_trace.n++] = trips; }
+}
