@@ -484,6 +484,22 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + x1] - g.cell_start[row + x0] + 3u) / 4u);
         lookup_scan(row + x0, row + x1);
     };
+    // Is the part of a face the K-th-best ball can reach provably empty?  (c0x,c0y,c0z) = the face cell under the query (clamped into
+    // the grid), d2 = squared distance to the face's cell layer: the ball cuts a cap out of the face that reaches floor(rho / h) + 1
+    // cells from that cell, and the empty-space field says how far (Chebyshev) the nearest occupied cell is from it.  One byte per
+    // face: five of the six faces around a query hovering off a wall are culled this way.
+    auto cap_empty = [&](int c0x, int c0y, int c0z, float d2, int kk) -> bool {
+        if (!g.gap) return false;
+        const float rho = sqrtf(fmaxf(hp.worst_d2() - d2, 0.f)) * 1.00001f + 1e-6f * hf;
+        const double rho_c = (double)rho * g.inv_h;             // may be astronomically large (unbounded searches): compare before converting
+        const int need = rho_c >= (double)kk ? kk : min(kk, (int)rho_c + 1);
+        const int xq = clampi(c0x, 0, nx - 1), yq = clampi(c0y, 0, ny - 1), zq = clampi(c0z, 0, nz - 1);
+        DCREG_STAT(table_loads);
+        const int gv = (int)g.gap[((int64_t)zq * ny + yq) * nx + xq];
+        const int free_r = gv == 255 ? g.gap_cap + 1 : gv;      // every cell closer (Chebyshev) than free_r to (xq,yq,zq) is empty
+        if (need < free_r) { DCREG_STAT(face_skips); return true; }
+        return false;
+    };
     for (int k = k0; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
@@ -496,7 +512,8 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         for (int sz = -1; sz <= 1; sz += 2) {
             const int z = cz + sz * kk;
             const float gz = slab(z, cz, fz);
-            const bool zin = z >= 0 && z < nz && !(gz * gz * 0.99999f > hp.worst_d2());
+            bool zin = z >= 0 && z < nz && !(gz * gz * 0.99999f > hp.worst_d2());
+            if (zin) zin = !cap_empty(cx, cy, z, gz * gz * 0.99999f, kk);
             if (!wave_any(zin)) continue;
             for (int dy = -kk; dy <= kk; ++dy) {
                 const int y = cy + dy;
@@ -509,7 +526,8 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         for (int sy = -1; sy <= 1; sy += 2) {
             const int y = cy + sy * kk;
             const float gy = slab(y, cy, fy);
-            const bool yin = y >= 0 && y < ny && !(gy * gy * 0.99999f > hp.worst_d2());
+            bool yin = y >= 0 && y < ny && !(gy * gy * 0.99999f > hp.worst_d2());
+            if (yin) yin = !cap_empty(cx, y, cz, gy * gy * 0.99999f, kk);
             if (!wave_any(yin)) continue;
             for (int dz = -kk + 1; dz <= kk - 1; ++dz) {
                 const int z = cz + dz;
@@ -524,7 +542,9 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const int xa = cx - kk, xb = cx + kk;
             const bool a_in = xa >= 0 && xa < nx, b_in = xb >= 0 && xb < nx;
             const float gxa = slab(xa, cx, fx), gxb = slab(xb, cx, fx);
-            const float gxa2 = a_in ? gxa * gxa * 0.99999f : __builtin_inff(), gxb2 = b_in ? gxb * gxb * 0.99999f : __builtin_inff();
+            float gxa2 = a_in ? gxa * gxa * 0.99999f : __builtin_inff(), gxb2 = b_in ? gxb * gxb * 0.99999f : __builtin_inff();
+            if (a_in && !(gxa2 > hp.worst_d2()) && cap_empty(xa, cy, cz, gxa2, kk)) gxa2 = __builtin_inff();     // face culled: never reachable
+            if (b_in && !(gxb2 > hp.worst_d2()) && cap_empty(xb, cy, cz, gxb2, kk)) gxb2 = __builtin_inff();
             const float w0 = hp.worst_d2();
             const float rmax = fmaxf(w0 - gxa2, w0 - gxb2);     // squared (y,z) radius the ball still has on the nearer x face
             // a row at offset o != 0 from the query's row is at least (|o| - 1) cells away: rows beyond m cannot be reached
