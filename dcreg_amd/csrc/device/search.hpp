@@ -484,22 +484,6 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + x1] - g.cell_start[row + x0] + 3u) / 4u);
         lookup_scan(row + x0, row + x1);
     };
-    // Is the part of a face the K-th-best ball can reach provably empty?  (c0x,c0y,c0z) = the face cell under the query (clamped into
-    // the grid), d2 = squared distance to the face's cell layer: the ball cuts a cap out of the face that reaches floor(rho / h) + 1
-    // cells from that cell, and the empty-space field says how far (Chebyshev) the nearest occupied cell is from it.  One byte per
-    // face: five of the six faces around a query hovering off a wall are culled this way.
-    auto cap_empty = [&](int c0x, int c0y, int c0z, float d2, int kk) -> bool {
-        if (!g.gap) return false;
-        const float rho = sqrtf(fmaxf(hp.worst_d2() - d2, 0.f)) * 1.00001f + 1e-6f * hf;
-        const double rho_c = (double)rho * g.inv_h;             // may be astronomically large (unbounded searches): compare before converting
-        const int need = rho_c >= (double)kk ? kk : min(kk, (int)rho_c + 1);
-        const int xq = clampi(c0x, 0, nx - 1), yq = clampi(c0y, 0, ny - 1), zq = clampi(c0z, 0, nz - 1);
-        DCREG_STAT(table_loads);
-        const int gv = (int)g.gap[((int64_t)zq * ny + yq) * nx + xq];
-        const int free_r = gv == 255 ? g.gap_cap + 1 : gv;      // every cell closer (Chebyshev) than free_r to (xq,yq,zq) is empty
-        if (need < free_r) { DCREG_STAT(face_skips); return true; }
-        return false;
-    };
     for (int k = k0; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
@@ -508,43 +492,66 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
         const int kk = k + 1;                                   // scan shell kk
         hp.n_shell = (uint32_t)kk;
+        // the six faces: in the grid, within the K-th best, and not provably empty.  The six field bytes are requested together
+        // (one wait per ring instead of six dependent ones)
+        const int fz_[2] = {cz - kk, cz + kk}, fy_[2] = {cy - kk, cy + kk}, fx_[2] = {cx - kk, cx + kk};
+        float d2f[6];
+        bool live[6];
+        int need[6], gv[6];
+        const float w_ring = hp.worst_d2();
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int axis = f >> 1, side = f & 1;
+            const int layer = axis == 0 ? fz_[side] : (axis == 1 ? fy_[side] : fx_[side]);
+            const int nq = axis == 0 ? nz : (axis == 1 ? ny : nx);
+            const float gl = axis == 0 ? slab(layer, cz, fz) : (axis == 1 ? slab(layer, cy, fy) : slab(layer, cx, fx));
+            d2f[f] = gl * gl * 0.99999f;
+            live[f] = layer >= 0 && layer < nq && !(d2f[f] > w_ring);
+            // the cap the ball cuts out of the face reaches floor(rho / h) + 1 cells from the face cell under the query
+            const float rho = sqrtf(fmaxf(w_ring - d2f[f], 0.f)) * 1.00001f + 1e-6f * hf;
+            const double rho_c = (double)rho * g.inv_h;         // may be astronomically large (unbounded searches): compare before converting
+            need[f] = rho_c >= (double)kk ? kk : min(kk, (int)rho_c + 1);
+            const int xq = clampi(axis == 2 ? layer : cx, 0, nx - 1), yq = clampi(axis == 1 ? layer : cy, 0, ny - 1),
+                      zq = clampi(axis == 0 ? layer : cz, 0, nz - 1);
+            gv[f] = (g.gap && live[f]) ? (int)g.gap[((int64_t)zq * ny + yq) * nx + xq] : 0;
+            if (g.gap && live[f]) DCREG_STAT(table_loads);
+        }
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const int free_r = gv[f] == 255 ? g.gap_cap + 1 : gv[f];     // every cell closer (Chebyshev) than free_r to that cell is empty
+            if (g.gap && live[f] && need[f] < free_r) { live[f] = false; DCREG_STAT(face_skips); }
+        }
         // ---- z faces: layers z = cz -+ kk, rows y = cy-kk .. cy+kk
-        for (int sz = -1; sz <= 1; sz += 2) {
-            const int z = cz + sz * kk;
-            const float gz = slab(z, cz, fz);
-            bool zin = z >= 0 && z < nz && !(gz * gz * 0.99999f > hp.worst_d2());
-            if (zin) zin = !cap_empty(cx, cy, z, gz * gz * 0.99999f, kk);
+        for (int sz = 0; sz < 2; ++sz) {
+            const int z = fz_[sz];
+            const bool zin = live[sz];
             if (!wave_any(zin)) continue;
+            const float gz = slab(z, cz, fz);
             for (int dy = -kk; dy <= kk; ++dy) {
                 const int y = cy + dy;
                 if (!(zin && y >= 0 && y < ny)) continue;
                 const float gy = slab(y, cy, fy);
-                face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, sz * kk, dy);
+                face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, sz ? kk : -kk, dy);
             }
         }
         // ---- y faces: layers y = cy -+ kk, rows z = cz-kk+1 .. cz+kk-1
-        for (int sy = -1; sy <= 1; sy += 2) {
-            const int y = cy + sy * kk;
-            const float gy = slab(y, cy, fy);
-            bool yin = y >= 0 && y < ny && !(gy * gy * 0.99999f > hp.worst_d2());
-            if (yin) yin = !cap_empty(cx, y, cz, gy * gy * 0.99999f, kk);
+        for (int sy = 0; sy < 2; ++sy) {
+            const int y = fy_[sy];
+            const bool yin = live[2 + sy];
             if (!wave_any(yin)) continue;
+            const float gy = slab(y, cy, fy);
             for (int dz = -kk + 1; dz <= kk - 1; ++dz) {
                 const int z = cz + dz;
                 if (!(yin && z >= 0 && z < nz)) continue;
                 const float gz = slab(z, cz, fz);
-                face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, dz, sy * kk);
+                face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, dz, sy ? kk : -kk);
             }
         }
         // ---- x faces: the end cells (cx -+ kk, y, z) of the rows in between.  gx is fixed for the ring: the cell is reachable iff
         // gx^2 + gy^2 + gz^2 <= K-th best, and rows farther than the ball's radius at that x distance need not be visited at all
         {
-            const int xa = cx - kk, xb = cx + kk;
-            const bool a_in = xa >= 0 && xa < nx, b_in = xb >= 0 && xb < nx;
-            const float gxa = slab(xa, cx, fx), gxb = slab(xb, cx, fx);
-            float gxa2 = a_in ? gxa * gxa * 0.99999f : __builtin_inff(), gxb2 = b_in ? gxb * gxb * 0.99999f : __builtin_inff();
-            if (a_in && !(gxa2 > hp.worst_d2()) && cap_empty(xa, cy, cz, gxa2, kk)) gxa2 = __builtin_inff();     // face culled: never reachable
-            if (b_in && !(gxb2 > hp.worst_d2()) && cap_empty(xb, cy, cz, gxb2, kk)) gxb2 = __builtin_inff();
+            const int xa = fx_[0], xb = fx_[1];
+            const float gxa2 = live[4] ? d2f[4] : __builtin_inff(), gxb2 = live[5] ? d2f[5] : __builtin_inff();
             const float w0 = hp.worst_d2();
             const float rmax = fmaxf(w0 - gxa2, w0 - gxb2);     // squared (y,z) radius the ball still has on the nearer x face
             // a row at offset o != 0 from the query's row is at least (|o| - 1) cells away: rows beyond m cannot be reached
