@@ -446,6 +446,13 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp, unsigned long long *stamp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
+    {   // what ring 1's test would say, before anything is loaded: an aligned query is done after the centre block (its K-th best lies
+        // within one cell edge), and when that holds for the whole wave the walk costs nothing - not even the field byte below
+        const double safe = g.h * (1.0 - 1e-9);
+        const double safe2 = safe * safe * (1.0 - 1e-6);
+        const bool done = max_ring <= 1 || (double)hp.worst_d2() <= safe2 || safe2 >= (double)bound_f;
+        if (!wave_any(!done)) return;
+    }
     // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
     int k0 = 1;
     if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
