@@ -30,6 +30,8 @@ for k, T in enumerate(poses[:5]):
     pa, pb, psh = ck[:, 6] & 0xFFFFF, (ck[:, 6] >> 20) & 0xFFFFF, (ck[:, 6] >> 40) & 0xFFFFF
     rings = search - pa - pb
     scan, wait, rows, scans = ck[:, 8], ck[:, 9], ck[:, 10], ck[:, 11]
+    ph = [ck[:, 1] - ck[:, 0], ck[:, 2] - ck[:, 1], ck[:, 3] - ck[:, 2], ck[:, 4] - ck[:, 3], ck[:, 5] - ck[:, 4]]
+    print("        phases (mean cycles per wave): prologue+warm gathers %d | search %d | plane fit + row %d | wave reduction %d | block reduction + ticket %d" % tuple(x.mean() for x in ph))
     heavy = total >= np.percentile(total, 99)
     f = lambda a: "%d/%d" % (a.mean(), a[heavy].mean())
     print("iter %d: cand mean %.0f p99 %d | rings>1 %.2f | wave cycles mean/p99-waves: total %s search %s (A %s B %s rings %s) | ring walk of lane 0: "
