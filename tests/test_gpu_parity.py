@@ -244,6 +244,34 @@ def test_engine_reproduces_committed_traces(ctx, cyl, family, method):
     assert np.allclose(res.R[:], ores.R[:], atol=1e-10) and np.allclose(res.t[:], ores.t[:], atol=1e-10)
 
 
+def test_batched_warm_states(ctx, cyl):
+    """dcreg_reserve_warm_states / dcreg_linearize_batch_begin_warm: every pose of a batch keeps the warm-start state a single run
+    keeps inside the ctx.  States only prune: results are bitwise those of the cold batch, whatever history the states hold;
+    misuse (a state that was not reserved, one state for two poses of a launch) is refused."""
+    pts, _ = cyl
+    ctx.set_target(pts, 1.0)
+    ctx.set_source(pts)
+    rng = np.random.default_rng(7)
+    prm = api.default_lin_params(1.0, 1)
+    Ts = [h.pose6d_matrix(*(rng.uniform(-0.3, 0.3, 3)), *(rng.uniform(-0.02, 0.02, 3))) for _ in range(6)]
+    Rs, ts = [T[:3, :3] for T in Ts], [T[:3, 3] for T in Ts]
+    cold = ctx.linearize_batch(Rs, ts, prm)
+    ctx.reserve_warm_states(8)
+    for ids in ([0, 1, 2, 3, 4, 5], [5, 4, 3, 2, 1, 0], [7, -1, 6, -1, 0, 1]):      # fresh, scrambled (foreign histories), partly cold
+        warm = ctx.linearize_batch_warm(Rs, ts, ids, prm)
+        for a, b in zip(cold, warm):
+            assert a["n_eff"] == b["n_eff"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
+    with pytest.raises(api.DcregError, match="not reserved"):
+        ctx.linearize_batch_warm(Rs, ts, [0, 1, 2, 3, 4, 8], prm)
+    with pytest.raises(api.DcregError, match="two poses"):
+        ctx.linearize_batch_warm(Rs, ts, [0, 1, 2, 3, 1, 5], prm)
+    ctx.set_source(pts)                                              # a new source drops the states
+    with pytest.raises(api.DcregError, match="not reserved"):
+        ctx.linearize_batch_warm(Rs, ts, [0, 1, 2, 3, 4, 5], prm)
+    with pytest.raises(api.DcregError, match="65535"):
+        ctx.linearize_batch([np.eye(3)] * 65536, [np.zeros(3)] * 65536, prm)
+
+
 def test_trials_match_individual_runs(ctx, cyl):
     pts, _ = cyl
     ctx.set_target(pts, 1.0)

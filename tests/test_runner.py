@@ -28,6 +28,31 @@ def test_runner_parses_config_and_fails_loudly_without_gpu(tmp_path):
     assert bad.returncode != 0 and "Failed to load configuration" in bad.stderr
 
 
+def test_pcd_reader_refuses_what_it_cannot_read(tmp_path):
+    """The binary reader copies 4 bytes per field: double-precision fields, short fields and headers that promise more points
+    than the file holds are refused (pcl::io::loadPCDFile converts or fails; silently reading garbage is neither)."""
+    import struct
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE %s\nTYPE %s\nCOUNT 1 1 1 1\n"
+           "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n")
+    cases = {
+        "double_xyz.pcd": (hdr % ("8 8 8 4", "F F F F", 3, 3)).encode() + struct.pack("<dddf", 1, 2, 3, 0) * 3,
+        "short_field.pcd": (hdr % ("2 2 2 4", "I I I F", 3, 3)).encode() + struct.pack("<hhhf", 1, 2, 3, 0) * 3,
+        "integer_xyz.pcd": (hdr % ("4 4 4 4", "U U U F", 3, 3)).encode() + struct.pack("<IIIf", 1, 2, 3, 0) * 3,
+        "lying_header.pcd": (hdr % ("4 4 4 4", "F F F F", 10 ** 9, 10 ** 9)).encode() + struct.pack("<ffff", 1, 2, 3, 0) * 3,
+    }
+    good = os.path.join(h.GOLDEN, "cylinder_7562.pcd")
+    for name, blob in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        cfg = open(os.path.join(h.REPO, "configs", "icp.yaml")).read()
+        cfg = cfg.replace('folder_path: "tests/golden/"', 'folder_path: "%s/"' % tmp_path).replace('source_pcd: "cylinder_7562.pcd"', 'source_pcd: "%s"' % name)
+        cfg = cfg.replace('target_pcd: "cylinder_7562.pcd"', 'target_pcd: "%s"' % good)
+        (tmp_path / "cfg.yaml").write_text(cfg)
+        p = subprocess.run([RUNNER, str(tmp_path / "cfg.yaml"), str(tmp_path) + "/out/"], cwd=h.REPO, capture_output=True, text=True, timeout=120)
+        assert p.returncode != 0, name
+        assert ("float32 scalar" in p.stderr or "truncated PCD" in p.stderr or "exceeds the file size" in p.stderr), (name, p.stderr[-400:])
+        assert "Loaded point clouds" not in p.stdout
+
+
 def _rows(path, method=None):
     rows = h.read_csv_rows(path)
     return [r for r in rows if method is None or r["Method"] == method]
