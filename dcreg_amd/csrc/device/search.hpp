@@ -472,9 +472,12 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         scan_run<H>(g, s_, e_, qx, qy, qz, hp);
         if (stamp) { stamp[4] += t_b - t_a; stamp[3] += clock64() - t_b; stamp[6] += 1; }
     };
-    // slab distance (metres, float) from the query to cell index c along an axis (cq = the query's cell, f = its cell coordinate)
-    auto slab = [&](int c, int cq, double f) -> float {
-        return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
+    // slab distance (metres, float) from the query to cell index c along an axis (cq = the query's cell, fr = the query's position
+    // inside that cell, in cells): single precision - every use carries a 1e-5 relative safety factor against 1e-7 of rounding
+    const float frx = (float)(fx - (double)cx), fry = (float)(fy - (double)cy), frz = (float)(fz - (double)cz);
+    const float inv_hf = (float)g.inv_h;
+    auto slab = [&](int c, int cq, float fr) -> float {
+        return c < cq ? ((float)(cq - c - 1) + fr) * hf : (c > cq ? ((float)(c - cq) - fr) * hf : 0.f);
     };
     // one (y,z) row of a z or y face: x-run [cx-kk, cx+kk] trimmed to the ball (conservative), then scanned
     auto face_row = [&](int y, int z, float dyz, int kk, int dz, int dy) {
@@ -482,10 +485,10 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         DCREG_STAT(rows);
         const float w = hp.worst_d2();
         if (dyz > w) return;
-        const float xr = sqrtf(w - dyz) * 1.00001f + 1e-6f * hf;
-        const double xr_c = (double)xr * g.inv_h;
-        const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
-        const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
+        // cells of the row the ball still reaches, relative to the query's cell (conservative: 1e-5 relative + 1e-4 of a cell)
+        const float xr_c = fminf((sqrtf(w - dyz) * 1.00001f) * inv_hf + 1e-4f, 1.0e6f);
+        const int dlo = (int)floorf(frx - xr_c), dhi = (int)floorf(frx + xr_c);         // cell offsets from cx
+        const int x0 = max(cx + max(dlo, -kk), 0), x1 = min(cx + min(dhi, kk), nx - 1) + 1;
         if (x1 <= x0) return;
         const int64_t row = ((int64_t)z * ny + y) * nx;
         DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + x1] - g.cell_start[row + x0] + 3u) / 4u);
@@ -511,7 +514,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const int axis = f >> 1, side = f & 1;
             const int layer = axis == 0 ? fz_[side] : (axis == 1 ? fy_[side] : fx_[side]);
             const int nq = axis == 0 ? nz : (axis == 1 ? ny : nx);
-            const float gl = axis == 0 ? slab(layer, cz, fz) : (axis == 1 ? slab(layer, cy, fy) : slab(layer, cx, fx));
+            const float gl = axis == 0 ? slab(layer, cz, frz) : (axis == 1 ? slab(layer, cy, fry) : slab(layer, cx, frx));
             d2f[f] = gl * gl * 0.99999f;
             live[f] = layer >= 0 && layer < nq && !(d2f[f] > w_ring);
             // the cap the ball cuts out of the face reaches floor(rho / h) + 1 cells from the face cell under the query
@@ -533,11 +536,11 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const int z = fz_[sz];
             const bool zin = live[sz];
             if (!wave_any(zin)) continue;
-            const float gz = slab(z, cz, fz);
+            const float gz = slab(z, cz, frz);
             for (int dy = -kk; dy <= kk; ++dy) {
                 const int y = cy + dy;
                 if (!(zin && y >= 0 && y < ny)) continue;
-                const float gy = slab(y, cy, fy);
+                const float gy = slab(y, cy, fry);
                 face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, sz ? kk : -kk, dy);
             }
         }
@@ -546,11 +549,11 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const int y = fy_[sy];
             const bool yin = live[2 + sy];
             if (!wave_any(yin)) continue;
-            const float gy = slab(y, cy, fy);
+            const float gy = slab(y, cy, fry);
             for (int dz = -kk + 1; dz <= kk - 1; ++dz) {
                 const int z = cz + dz;
                 if (!(yin && z >= 0 && z < nz)) continue;
-                const float gz = slab(z, cz, fz);
+                const float gz = slab(z, cz, frz);
                 face_row(y, z, (gy * gy + gz * gz) * 0.99999f, kk, dz, sy ? kk : -kk);
             }
         }
@@ -570,7 +573,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             for (int dz = -m_w; dz <= m_w; ++dz) {
                 const int z = cz + dz;
                 if (z < 0 || z >= nz) continue;
-                const float gz = slab(z, cz, fz);
+                const float gz = slab(z, cz, frz);
                 const float gz2 = gz * gz;
                 if (fminf(gxa2, gxb2) + gz2 * 0.99999f > hp.worst_d2()) continue;
                 for (int dy = -m_w; dy <= m_w; ++dy) {
@@ -578,7 +581,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
                     if (y < 0 || y >= ny) continue;
                     if (stamp) stamp[5] += 1;
                     DCREG_STAT(rows);
-                    const float gy = slab(y, cy, fy);
+                    const float gy = slab(y, cy, fry);
                     const float dyz = (gy * gy + gz2) * 0.99999f;
                     const float w = hp.worst_d2();
                     const int64_t row = ((int64_t)z * ny + y) * nx;
