@@ -343,7 +343,6 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const int64_t n = c->n_src;
     a.prev = nullptr; a.prev_stride = 0;
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
-    a.block_order = (uint32_t)std::max(c->opt_block_order, 0);
     PoseArg one{};
     const PoseArg *d_poses = nullptr;
     if (n_poses == 1 && !state_ids) {
@@ -623,7 +622,6 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
     else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
     else if (k == "xcd_chunk") c->opt_xcd_chunk = (int)v;   // 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks round-robin
-    else if (k == "block_order") c->opt_block_order = (int)v;   // experiment (kernels.hpp k_linearize)
     else if (k == "fast_plane_fit") c->opt_fast_plane = v != 0.0;   // 1 (default) = plane_fit_qr_fast, 0 = the Eigen-shaped plane_fit_qr
     else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }

@@ -98,7 +98,6 @@ struct dcreg_ctx {
     unsigned long long seq = 0;
     int opt_lds_pad = 0;
     int opt_xcd_chunk = 16;        // query-block -> XCD mapping (kernels.hpp xcd_remap): runs of 16 blocks round-robin (measured: C4 -13 %)
-    int opt_block_order = 0;       // experiment: order in which the query blocks are handed to the hardware blocks
     bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;

@@ -149,9 +149,7 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     __shared__ int s_role;
     __shared__ RunList runs;
     const uint32_t pose_id = blockIdx.y;
-    uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
-    if (a.block_order == 1) vb = n_blocks_x - 1u - vb;
-    else if (a.block_order == 2) vb = (vb & 1u) ? n_blocks_x - 1u - (vb >> 1) : (vb >> 1);
+    const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
     const uint32_t i = vb * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PoseArg P;

@@ -71,7 +71,6 @@ struct LinArgs {
     uint32_t *prev;               // [5][prev_stride] sorted-target positions of each query's last neighbour set, or null
     uint32_t prev_stride;
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
-    uint32_t block_order;         // experiment: 0 = query blocks in index order, 1 = reversed, 2 = both ends first (0, n-1, 1, n-2, ...)
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
 };
