@@ -530,13 +530,24 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const int free_r = gv[f] == 255 ? g.gap_cap + 1 : gv[f];     // every cell closer (Chebyshev) than free_r to that cell is empty
             if (g.gap && live[f] && need[f] < free_r) { live[f] = false; DCREG_STAT(face_skips); }
         }
+        // offsets of the rows a ball of squared radius r2 (in the plane of a face) can reach along an axis on which the query sits at
+        // `fr` inside its cell: a row at offset +o is (o - fr) cells away, one at -o is (o - 1 + fr) cells away (conservative by
+        // 1e-5 relative + 1e-4 of a cell); clipped to +-cap.  The loops below are bounded per lane; the wave runs to the widest.
+        auto reach = [&](float r2, float fr, int cap, int &lo, int &hi) {
+            const float rc = fminf(sqrtf(fmaxf(r2, 0.f)) * 1.00001f * inv_hf + 1e-4f, 1.0e6f);
+            lo = -min(cap, (int)floorf(rc + 1.f - fr));
+            hi = min(cap, (int)floorf(rc + fr));
+            if (r2 < 0.f) { lo = 1; hi = 0; }
+        };
         // ---- z faces: layers z = cz -+ kk, rows y = cy-kk .. cy+kk
         for (int sz = 0; sz < 2; ++sz) {
             const int z = fz_[sz];
             const bool zin = live[sz];
             if (!wave_any(zin)) continue;
             const float gz = slab(z, cz, frz);
-            for (int dy = -kk; dy <= kk; ++dy) {
+            int ylo, yhi;
+            reach(zin ? hp.worst_d2() - d2f[sz] : -1.f, fry, kk, ylo, yhi);
+            for (int dy = ylo; dy <= yhi; ++dy) {
                 const int y = cy + dy;
                 if (!(zin && y >= 0 && y < ny)) continue;
                 const float gy = slab(y, cy, fry);
@@ -549,7 +560,9 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const bool yin = live[2 + sy];
             if (!wave_any(yin)) continue;
             const float gy = slab(y, cy, fry);
-            for (int dz = -kk + 1; dz <= kk - 1; ++dz) {
+            int zlo, zhi;
+            reach(yin ? hp.worst_d2() - d2f[2 + sy] : -1.f, frz, kk - 1, zlo, zhi);
+            for (int dz = zlo; dz <= zhi; ++dz) {
                 const int z = cz + dz;
                 if (!(yin && z >= 0 && z < nz)) continue;
                 const float gz = slab(z, cz, frz);
@@ -563,19 +576,16 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const float gxa2 = live[4] ? d2f[4] : __builtin_inff(), gxb2 = live[5] ? d2f[5] : __builtin_inff();
             const float w0 = hp.worst_d2();
             const float rmax = fmaxf(w0 - gxa2, w0 - gxb2);     // squared (y,z) radius the ball still has on the nearer x face
-            // a row at offset o != 0 from the query's row is at least (|o| - 1) cells away: rows beyond m cannot be reached
-            const double m_c = (double)(sqrtf(fmaxf(rmax, 0.f)) * 1.00001f) * g.inv_h;     // may be astronomically large (unbounded searches)
-            const int m = rmax >= 0.f ? (m_c >= (double)kk ? kk - 1 : min(kk - 1, (int)m_c + 2)) : -1;
-            const bool any_x = rmax >= 0.f;
-            const int m_w = any_x ? m : -1;
-            // (per-lane bound m; the wave runs to the largest)
-            for (int dz = -m_w; dz <= m_w; ++dz) {
+            int zlo, zhi, ylo, yhi;
+            reach(rmax, frz, kk - 1, zlo, zhi);
+            reach(rmax, fry, kk - 1, ylo, yhi);
+            for (int dz = zlo; dz <= zhi; ++dz) {
                 const int z = cz + dz;
                 if (z < 0 || z >= nz) continue;
                 const float gz = slab(z, cz, frz);
                 const float gz2 = gz * gz;
                 if (fminf(gxa2, gxb2) + gz2 * 0.99999f > hp.worst_d2()) continue;
-                for (int dy = -m_w; dy <= m_w; ++dy) {
+                for (int dy = ylo; dy <= yhi; ++dy) {
                     const int y = cy + dy;
                     if (y < 0 || y >= ny) continue;
                     if (stamp) stamp[5] += 1;
