@@ -61,6 +61,44 @@ __device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32], int l
     return v[0] + shfl_xor_f64(v[0], 32);
 }
 
+// ---------------------------------------------------------------- wave reduction of the rows on the matrix cores
+// The 29 sums H = sum A A^T, g = sum A b, sum b^2, sum r^2 are the entries of the 8x8 Gram matrix X^T X of the wave's
+// 64 rows X[p] = [A0..A5, b, r] - a GEMM, so it runs as v_mfma_f64_16x16x4_f64 instead of 29 products per lane and a
+// 31-value cross-lane reduction on the VALU (which is what bounds this kernel).  Two points share one 16-wide operand row
+// (even point in columns 0-7, odd point in 8-15): the 16x16 result then holds the even points' Gram matrix in its upper
+// left 8x8 block and the odd points' in the lower right one, K = 32 instead of 64 and no zero padding; the two cross
+// blocks are discarded.  Staging: every lane stores its row to the wave's private LDS area (stride 9 doubles: the 64-bit
+// stores and the operand loads are bank-conflict free), the operand of step kb is ONE ds_read_b64 per lane and serves as
+// both A and B.  Operand layout: A[i][k] / B[k][j] in lane i + 16 k; result D[row][col]: col = lane & 15, row = (lane >> 4)
+// + 4 reg.  Returns u0 = M[lane >> 4][lane & 7], u1 = M[(lane >> 4) + 4][lane & 7] of the wave's Gram matrix M (all
+// lanes).  The summation order is fixed by the instruction sequence: deterministic.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wave_gram_mfma(const double (&row)[8], double *stage, int lane, double &u0, double &u1) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) stage[lane * kRowStride + c] = row[c];
+    const int c16 = lane & 15, k = lane >> 4;
+    const double *op = stage + (2 * k + (c16 >> 3)) * kRowStride + (c16 & 7);
+    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const double x = op[kb * 8 * kRowStride];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+    }
+    const bool even = c16 < 8;
+    u0 = even ? acc[0] : acc[2];
+    u1 = even ? acc[1] : acc[3];
+    u0 = dpp_add<0x128, 0xF>(u0);      // row_ror:8 - the lane holding the other half's block entry
+    u1 = dpp_add<0x128, 0xF>(u1);
+}
+// slot of the 32-double partial row -> entry (a, b) of the Gram matrix: 21 H (upper triangle, row-major), 6 g = (j, 6),
+// sum r^2 = (7, 7), sum b^2 = (6, 6)
+__device__ __forceinline__ int gram_entry_of_slot(int slot) {
+    constexpr uint8_t tab[29] = {0 * 8 + 0, 0 * 8 + 1, 0 * 8 + 2, 0 * 8 + 3, 0 * 8 + 4, 0 * 8 + 5, 1 * 8 + 1, 1 * 8 + 2, 1 * 8 + 3, 1 * 8 + 4,
+                                 1 * 8 + 5, 2 * 8 + 2, 2 * 8 + 3, 2 * 8 + 4, 2 * 8 + 5, 3 * 8 + 3, 3 * 8 + 4, 3 * 8 + 5, 4 * 8 + 4, 4 * 8 + 5,
+                                 5 * 8 + 5, 0 * 8 + 6, 1 * 8 + 6, 2 * 8 + 6, 3 * 8 + 6, 4 * 8 + 6, 5 * 8 + 6, 7 * 8 + 7, 6 * 8 + 6};
+    return tab[slot];
+}
+
 // XCD-aware block remap: hardware places block b on XCD b % 8 (as that XCD's (b / 8)-th block).
 //   chunk == 0: every XCD gets ONE contiguous run of query blocks, so spatially adjacent (Hilbert-ordered) queries share
 //               that XCD's L2 - best when the work per query is uniform;
@@ -146,8 +184,9 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg) {
     __shared__ double red[8][kSlots];
+    __shared__ double cnt[kBlock / 64][2];
     __shared__ int s_role;
-    __shared__ RunList runs;
+    __shared__ RunList runs[kBlock / kWave];
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
     const uint32_t i = vb * kBlock + threadIdx.x;
@@ -155,9 +194,10 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
 
-    double acc[31];
+    double row[8];
 #pragma unroll
-    for (int k = 0; k < 31; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 8; ++k) row[k] = 0.0;
+    uint8_t flag = 0;
     unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
     if (MODE == 1) clk[0] = clock64();
 
@@ -171,13 +211,13 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     // batched launches: every pose owns a warm-start state of its own, selected by the pose's state slot
     uint32_t *prev = a.prev ? a.prev + (size_t)P.state * 5u * a.prev_stride : nullptr;
     if (poses && P.state == kNoIdx) prev = nullptr;
-    lin_search(g, runs, P, a, prev, have_q, s4, i, q, nn, MODE == 1 ? sst : nullptr);
+    lin_search(g, runs[wave], P, a, prev, have_q, s4, i, q, nn, MODE == 1 ? sst : nullptr);
     if (MODE == 1) clk[2] = clock64();
 
     // ---- plane fit, gates, row (search.hpp)
     if (have_q) {
         double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
-        const uint8_t flag = lin_row<FAST>(P, a, s4, q, nn, acc, nrm, r_pt, s_pt);
+        flag = lin_row<FAST>(P, a, s4, q, nn, row, nrm, r_pt, s_pt);
         if (MODE == 1) {
             const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
@@ -197,24 +237,31 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     }
 
     if (MODE == 1) clk[3] = clock64();
-    // transposed wave64 reduction -> lane l holds the wave total of slot (l & 31) -> LDS -> block partial
-    // (fixed order, no float atomics)
+    // wave reduction on the matrix cores (the wave's RunList is free now: it stages the rows) -> the wave's 8x8 Gram
+    // matrix and its two counts in LDS -> block partial (fixed order, no float atomics)
     {
-        double v[32];
-#pragma unroll
-        for (int k = 0; k < 31; ++k) v[k] = acc[k];
-        v[31] = 0.0;
-        const double t = wave_transpose_reduce32(v, lane);
-        if (lane < 32) red[wave][lane] = t;
+        double u0, u1;
+        wave_gram_mfma(row, runs[wave].stage, lane, u0, u1);
+        double *gm = &red[0][0] + wave * 64;            // the wave's Gram matrix, M[a][b] at a * 8 + b
+        if ((lane & 15) < 8) {
+            gm[(lane >> 4) * 8 + (lane & 7)] = u0;
+            gm[32 + (lane >> 4) * 8 + (lane & 7)] = u1;
+        }
+        const unsigned long long eff = __builtin_amdgcn_ballot_w64(flag == 1), inr = __builtin_amdgcn_ballot_w64(flag != 0);
+        if (lane == 0) { cnt[wave][0] = (double)__builtin_popcountll(eff); cnt[wave][1] = (double)__builtin_popcountll(inr); }
     }
     if (MODE == 1) clk[4] = clock64();
     __syncthreads();
     double *my_rows = partials + (size_t)pose_id * n_blocks_x * kSlots;
     if (threadIdx.x < kSlots) {
         double t = 0.0;
-        if (threadIdx.x < 31) {
+        if (threadIdx.x < 29) {
+            const int e = gram_entry_of_slot(threadIdx.x);
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) t += red[w][threadIdx.x];
+            for (int w = 0; w < kBlock / 64; ++w) t += (&red[0][0])[w * 64 + e];
+        } else if (threadIdx.x < 31) {
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) t += cnt[w][threadIdx.x - 29];
         }
         if (FUSED) {
             st_agent(my_rows + (size_t)vb * kSlots + threadIdx.x, t);
@@ -278,7 +325,7 @@ static __global__ __launch_bounds__(kBlock) void k_finalize(const double *__rest
 template <int K>
 static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict__ q, uint32_t n, GridDev g, float bound_f, int max_ring,
                                                  PoseArg pose, int apply_pose, int32_t *__restrict__ idx, float *__restrict__ d2) {
-    __shared__ RunList runs;
+    __shared__ RunList runs[kBlock / kWave];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 s4 = q[i];
@@ -287,7 +334,7 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
         body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
     KnnResult<K> nn;
-    knn_exact<K>(g, runs, qx, qy, qz, bound_f, max_ring, nn);
+    knn_exact<K>(g, runs[threadIdx.x / kWave], qx, qy, qz, bound_f, max_ring, nn);
     const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
     for (int j = 0; j < K; ++j) {

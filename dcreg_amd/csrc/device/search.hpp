@@ -225,7 +225,7 @@ DCREG_DEVFN void body_to_global(const PoseArg &P, double px, double py, double p
 template <class H>
 DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp);
 
-DCREG_DEVFN int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+DCREG_DEVFN int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // lo <= hi at every call site
 
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
@@ -243,13 +243,22 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
 // every lane whenever ANY lane has a candidate, which is always).  The pushes reach the heap in scan order, so the result -
 // neighbour set, order among ties, the exact-tie flag - is the one the immediate insertion gives (search.hpp knn_search).
 constexpr int kPend = 7;
+constexpr int kWave = 64;
 struct PendEntry { uint32_t d2_bits, pos; };
-struct RunList {
-    uint32_t s[9][kBlock];
-    uint32_t e[9][kBlock];
-    uint16_t gap2h[9][kBlock];    // squared distance from the query to the row's (y,z) slab: upper half of the float, i.e.
-                                  // rounded toward zero - a row is never pruned on a distance it does not have
-    PendEntry pend[kPend][kBlock];
+// One RunList per WAVE ([slot][lane]); a wave's list is private to it, so once its search is over the same LDS serves as
+// that wave's staging area for the MFMA reduction of the rows (kernels.hpp) without a block barrier in between.
+constexpr int kRowStride = 9;          // doubles per staged row: 8 values + 1 pad (bank-conflict-free 64-bit writes)
+struct alignas(16) RunList {
+    union {
+        struct {
+            uint32_t s[9][kWave];
+            uint32_t e[9][kWave];
+            uint16_t gap2h[9][kWave];     // squared distance from the query to the row's (y,z) slab: upper half of the float, i.e.
+                                          // rounded toward zero - a row is never pruned on a distance it does not have
+            PendEntry pend[kPend][kWave];
+        };
+        double stage[kWave * kRowStride];
+    };
 };
 DCREG_DEVFN bool wave_any(bool x) {
 #if DCREG_ON_DEVICE
@@ -302,15 +311,27 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         max_ring = max(ex, max(ey, ez)) + 1;
     }
 
-    // ---- rings 0+1, phase A: the 9 (y,z) rows of the 3x3x3 block, each one contiguous x-run; all 18 table
-    // loads are issued together, empty / out-of-reach rows are dropped, nearest rows come first
-    const int tid = threadIdx.x;
+    // ---- rings 0+1, phase A: the 9 (y,z) rows of the 3x3x3 block, each one contiguous x-run.  Straight-line code: all 18
+    // table loads are unconditional and in flight together (a row that is outside the grid or out of reach loads entry 0
+    // twice and so yields an empty run), 32-bit cell arithmetic (the grid has at most 2^27 cells), and the reach tests
+    // compare SQUARED distances, shrunk so that a row / an end cell is never dropped on a distance it does not have
+    // (the float chain of dist2_nofma can come out below the exact value by a few ulp; these margins are 1e-5 .. 1e-4).
+    // Empty runs are dropped when the list is written, nearest rows come first.
+    const int tid = threadIdx.x & (kWave - 1);
     int nrun = 0;
     {
         const float hf = (float)g.h;
         const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
         const float gxl = frx * hf, gxh = (1.f - frx) * hf;
         const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
+        const float gy2[3] = {gyl * gyl * 0.99999f, 0.f, gyh * gyh * 0.99999f}, gz2[3] = {gzl * gzl * 0.99999f, 0.f, gzh * gzh * 0.99999f};
+        const float xl2 = gxl * gxl * 0.9999f, xh2 = gxh * gxh * 0.9999f;
+        const float lim_x = bound_f + 1e-12f * hf * hf;      // absolute slack: an end cell a hair away is always taken
+        const uint32_t unx = (uint32_t)nx, uny = (uint32_t)ny, sxy = unx * uny;
+        const uint32_t base_c = ((uint32_t)cz * uny + (uint32_t)cy) * unx;          // garbage when (cy, cz) is outside: not used then
+        const uint32_t yoff[3] = {base_c - unx, base_c, base_c + unx};
+        const bool yok[3] = {(uint32_t)(cy - 1) < uny, (uint32_t)cy < uny, (uint32_t)(cy + 1) < uny};
+        const bool zok[3] = {(uint32_t)(cz - 1) < (uint32_t)nz, (uint32_t)cz < (uint32_t)nz, (uint32_t)(cz + 1) < (uint32_t)nz};
         // visiting order (dy,dz): centre, 4 edge rows, 4 corner rows
         constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
         constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
@@ -318,18 +339,16 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         float g2s[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            const float gy = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.f), gz = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.f);
-            const float g2 = (gy * gy + gz * gz) * 0.99999f;
+            const float g2 = gy2[DY[r] + 1] + gz2[DZ[r] + 1];
             g2s[r] = g2;
-            // x-cells of this row the ball of radius sqrt(bound) can reach (conservative): a tight bound (warm
-            // start) trims the three-cell run to one or two cells, or drops the row
-            const float xr = sqrtf(fmaxf(bound_f - g2, 0.f)) * 1.00001f + 1e-6f * hf;
-            const int x0 = clampi(cx - (gxl <= xr ? 1 : 0), 0, nx), x1 = clampi(cx + 1 + (gxh <= xr ? 1 : 0), 0, nx);   // [x0, x1)
-            const int y = cy + DY[r], z = cz + DZ[r];
-            const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz && !(g2 > bound_f);
-            const int64_t row = ok ? ((int64_t)z * ny + y) * nx : 0;
-            rs[r] = ok ? g.cell_start[row + x0] : 0u;
-            re[r] = ok ? g.cell_start[row + x1] : 0u;
+            // x-cells of this row the ball of radius sqrt(bound) can reach (conservative): a tight bound (warm start)
+            // trims the three-cell run to one or two cells, or drops the row
+            const float rem = lim_x - g2;
+            const int x0 = clampi(cx - (xl2 <= rem ? 1 : 0), 0, nx), x1 = clampi(cx + 1 + (xh2 <= rem ? 1 : 0), 0, nx);   // [x0, x1)
+            const bool ok = yok[DY[r] + 1] && zok[DZ[r] + 1] && (x1 > x0) && !(g2 > bound_f);
+            const uint32_t row = yoff[DY[r] + 1] + (DZ[r] < 0 ? 0u - sxy : (DZ[r] > 0 ? sxy : 0u));
+            rs[r] = g.cell_start[ok ? row + (uint32_t)x0 : 0u];
+            re[r] = g.cell_start[ok ? row + (uint32_t)x1 : 0u];
             if (ok) { DCREG_STAT(table_loads); DCREG_STAT(table_loads); }
         }
 #pragma unroll
@@ -1126,12 +1145,14 @@ DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, c
 }
 
 // Steps 3-5 for one query with its neighbour set (icp_test_runner.cpp:1727-1812, 1863-1907): plane fit, gates, weight,
-// Jacobian row, the 31 products.  acc must be zero on entry; it stays zero unless the point is effective (acc[30] counts
-// the points that passed the radius gate, :1731).  Returns the gate flag (dcreg_lin_debug::flag); nrm/r_out/s_out receive
-// the plane normal, residual and weight once they exist (flags 1 and 4).
+// Jacobian row.  row = [A0..A5, b, r]: the weighted Jacobian row, the right-hand side entry and the residual; it must be
+// zero on entry and stays zero unless the point is effective (flag 1).  The 31 sums of the linearisation are the products
+// of this row with itself, added over the points (row_products below; on the device the MFMA reduction of kernels.hpp),
+// plus two counts: effective points (flag 1) and points that passed the radius gate (flag != 0, :1731).  Returns the gate
+// flag (dcreg_lin_debug::flag); nrm/r_out/s_out receive the plane normal, residual and weight once they exist (flags 1, 4).
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4, const PointQuery &q, const KnnResult<5> &nn,
-                            double (&acc)[31], double (&nrm)[3], double &r_out, double &s_out) {
+                            double (&row)[8], double (&nrm)[3], double &r_out, double &s_out) {
     float sxf = s4.x, syf = s4.y, szf = s4.z;
 #if DCREG_ON_DEVICE
     asm volatile("" : "+v"(sxf), "+v"(syf), "+v"(szf));   // as below for the query: re-convert instead of keeping doubles alive
@@ -1140,7 +1161,6 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
     const bool have5 = q.reach && nn.full;
     const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
     if (!in_radius) return 0;
-    acc[30] = 1.0;                                                          // :1731
     double nqx[5], nqy[5], nqz[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) { nqx[j] = nn.pt[j].x; nqy[j] = nn.pt[j].y; nqz[j] = nn.pt[j].z; }
@@ -1198,17 +1218,28 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
         A[3] = c0; A[4] = c1; A[5] = c2;
     }
     const double b = -(double)cif;                                                       // :1906
+#pragma unroll
+    for (int j = 0; j < 6; ++j) row[j] = A[j];
+    row[6] = b;
+    row[7] = r;
+    return 1;
+}
+
+// The 31 sums' contribution of one point, from its row and flag: [0..20] upper triangle of A A^T (row-major), [21..26]
+// A b, [27] r^2, [28] b^2, [29] effective, [30] passed the radius gate.  (Host replay and tests; the device sums the same
+// products on the matrix cores.)
+DCREG_DEVFN void row_products(const double (&row)[8], uint8_t flag, double (&acc)[31]) {
     int idx = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int k = j; k < 6; ++k) acc[idx++] = A[j] * A[k];
+        for (int k = j; k < 6; ++k) acc[idx++] = row[j] * row[k];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc[21 + j] = A[j] * b;
-    acc[27] = r * r;
-    acc[28] = b * b;
-    acc[29] = 1.0;
-    return 1;
+    for (int j = 0; j < 6; ++j) acc[21 + j] = row[j] * row[6];
+    acc[27] = row[7] * row[7];
+    acc[28] = row[6] * row[6];
+    acc[29] = flag == 1 ? 1.0 : 0.0;
+    acc[30] = flag != 0 ? 1.0 : 0.0;
 }
 
 }  // namespace dcreg

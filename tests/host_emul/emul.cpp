@@ -211,9 +211,9 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         if (trace) { emu_trace.buf = trace + (size_t)i * (size_t)trace_cap_per_query; emu_trace.cap = (uint32_t)trace_cap_per_query - 1; emu_trace.n = 0; }
         lin_search(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
         if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
-        double acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
-        for (double &v : acc) v = 0.0;
-        const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, acc, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, acc, nrm, rr, ss);
+        double row[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
+        const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, row, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, row, nrm, rr, ss);
+        row_products(row, fl, acc);
         for (int j = 0; j < 31; ++j) tot[j] += acc[j];
         if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = (q.reach && nn.idx[j] != kNoIdx) ? (int32_t)nn.idx[j] : -1;
         if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = (q.reach && nn.idx[j] != kNoIdx) ? nn.d2[j] : INFINITY;
