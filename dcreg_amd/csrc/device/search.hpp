@@ -51,7 +51,7 @@ struct GridDev {
     int nx, ny, nz;
     uint32_t n_pts;
     const uint32_t *cell_start;   // [nx*ny*nz + 1]
-    const float4 *pts;            // sorted target
+    const float4 *pts;            // sorted target; at least 3 readable entries follow the last point (candidate loads come in fours)
     const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
     int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
 };
@@ -220,8 +220,8 @@ DCREG_DEVFN void body_to_global(const PoseArg &P, double px, double py, double p
     qz = (float)(P.R[6] * px + P.R[7] * py + P.R[8] * pz + P.t[2]);
 }
 
-// one run of the ring walk: four candidates per trip, their loads issued together (slots past the end are clamped
-// loads that push +inf)
+// one run of the ring walk: four candidates per trip, their loads issued together (slots past the end read on in the
+// sorted array and push +inf)
 template <class H>
 DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp);
 
@@ -279,10 +279,10 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
     DCREG_STAT(runs);
     for (uint32_t p = s; p < e; p += 4) {
         DCREG_STAT(trips);
-        const uint32_t last = e - 1;
         float4 c[4];
+        const float4 *cp4 = g.pts + p;          // slots past the end read the array's padding / the next cell: masked below
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = g.pts[min(p + u, last)];
+        for (int u = 0; u < 4; ++u) c[u] = cp4[u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) push_point<H>(hp, qx, qy, qz, c[u], p + u, p + u < e);
     }
@@ -381,7 +381,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         };
         // software-pipelined over two register sets, unrolled twice (no copies): the loads of trip t+1 are in flight
         // while trip t is inserted (a third set, two trips ahead: +2.5 % at 100 k points, -8 % at 1 M where the extra
-        // registers cost a wave of occupancy).  Slots past the end of a run are clamped loads that push +inf.
+        // registers cost a wave of occupancy).  Slots past the end of a run are masked out.
         constexpr int W = 4;
         struct Slot { float4 c[W]; uint32_t cp, ce; bool live; };
         bool have = nrun > 0;
@@ -390,9 +390,11 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             sl.live = have; sl.cp = p; sl.ce = e;
             if (have) {
                 DCREG_STAT(trips);
-                const uint32_t last = max(e, 1u) - 1u;
+                // one address, four loads at immediate offsets: slots past the end of the run read the next points of the
+                // sorted array (it is padded by 8 entries) and are masked out by their position when consumed
+                const float4 *cp4 = g.pts + p;
 #pragma unroll
-                for (int u = 0; u < W; ++u) sl.c[u] = g.pts[min(p + u, last)];
+                for (int u = 0; u < W; ++u) sl.c[u] = cp4[u];
                 p += W;
                 if (p >= e) {
                     have = ri < nrun;
