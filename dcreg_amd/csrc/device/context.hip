@@ -77,7 +77,8 @@ struct GridDst {   // where a grid build puts its products
 };
 
 // builds keys/sort/cell_start for the given cell edge; returns number of occupied cells
-static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double mn[3], const double mx[3], uint32_t *occupied) {
+// (sx = x sub-cells per cell, GridDev::sx; *occupied then counts sub-cells)
+static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double mn[3], const double mx[3], uint32_t *occupied, int sx = 1) {
     const int64_t n = d.n;
     GridDev g{};
     g.h = h; g.inv_h = 1.0 / h;
@@ -85,7 +86,8 @@ static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double 
     g.nx = (int)std::floor((mx[0] - mn[0]) * g.inv_h) + 1;
     g.ny = (int)std::floor((mx[1] - mn[1]) * g.inv_h) + 1;
     g.nz = (int)std::floor((mx[2] - mn[2]) * g.inv_h) + 1;
-    const int64_t n_cells = (int64_t)g.nx * g.ny * g.nz;
+    g.sx = sx;
+    const int64_t n_cells = (int64_t)g.nx * sx * g.ny * g.nz;       // table entries
     g.n_pts = (uint32_t)n;
     if (ensure(c, c->d_keys, c->keys_cap, (size_t)n) || ensure(c, c->d_keys2, c->keys2_cap, (size_t)n) ||
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
@@ -106,7 +108,7 @@ static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double 
     g.cell_start = *d.cell_start;
     g.pts = *d.sorted;
     *d.grid = g;
-    *d.n_cells = n_cells;
+    *d.n_cells = n_cells / sx;
     return DCREG_OK;
 }
 
@@ -154,6 +156,15 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
         }
     }
     if (occupied_out) *occupied_out = occ;
+    // the cell edge is settled: cut x into sub-cells (same rows, same table loads, tighter candidate runs), as far as the
+    // table budget allows
+    int sx = c->opt_x_subdiv;
+    while (sx > 1 && (double)d.grid->nx * sx * d.grid->ny * d.grid->nz > max_cells) sx >>= 1;
+    if (sx > 1) {
+        uint32_t occ_sub = 0;
+        rc = build_grid_at(c, d, d.grid->h, mn, mx, &occ_sub, sx);
+        if (rc) return rc;
+    }
     return DCREG_OK;
 }
 
@@ -167,7 +178,7 @@ static int build_gap_field(dcreg_ctx *c, double radius_hint) {
     while (rings < 12 && (double)rings * g.h < (radius_hint > 0.0 ? radius_hint : 4.0 * g.h)) ++rings;
     if (rings < 2) return DCREG_OK;                           // one ring covers the radius: nothing to skip
     if (ensure(c, c->d_gap, c->gap_cap, (size_t)n_cells)) return DCREG_E_NOMEM;
-    hipLaunchKernelGGL(k_gap_init, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_cell_start, n_cells, c->d_gap);
+    hipLaunchKernelGGL(k_gap_init, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_cell_start, n_cells, g.sx, c->d_gap);
     for (int r = 1; r <= rings; ++r)
         hipLaunchKernelGGL(k_gap_dilate, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_gap, g.nx, g.ny, g.nz, r);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -616,6 +627,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     const std::string k(key);
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
+    else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort

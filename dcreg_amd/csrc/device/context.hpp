@@ -91,6 +91,7 @@ struct dcreg_ctx {
 
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
+    int opt_x_subdiv = 8;          // x sub-cells per grid cell (1, 2, 4, 8, 16)
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
     uint64_t launch_counter = 0;
     bool opt_spin = true;          // wait for results by spinning on pinned memory instead of hipStreamSynchronize

@@ -389,10 +389,12 @@ static __global__ void k_cell_keys(const float4 *__restrict__ p, int64_t n, Grid
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 c = p[i];
-    const int cx = clampi((int)floor(((double)c.x - g.ox) * g.inv_h), 0, g.nx - 1);
+    // x in sub-cells (GridDev::sx per cell); the sub-cell index over sx is the cell the searches take for this point
+    const int nxf = g.nx * g.sx;
+    const int cx = clampi((int)floor(((double)c.x - g.ox) * g.inv_h * (double)g.sx), 0, nxf - 1);
     const int cy = clampi((int)floor(((double)c.y - g.oy) * g.inv_h), 0, g.ny - 1);
     const int cz = clampi((int)floor(((double)c.z - g.oz) * g.inv_h), 0, g.nz - 1);
-    keys[i] = (uint32_t)(((int64_t)cz * g.ny + cy) * g.nx + cx);
+    keys[i] = (uint32_t)(((int64_t)cz * g.ny + cy) * nxf + cx);
     vals[i] = (uint32_t)i;
 }
 
@@ -461,9 +463,9 @@ static __global__ void k_cell_start(const uint32_t *__restrict__ keys, int64_t n
 
 // empty-space distance field of the target grid: gap[c] = 0 on occupied cells, then one dilation pass per ring.
 // In place: a pass only turns 255 into `ring`, and only looks for neighbours equal to ring - 1.
-static __global__ void k_gap_init(const uint32_t *__restrict__ cell_start, int64_t n_cells, uint8_t *__restrict__ gap) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_cells) gap[c] = cell_start[c + 1] > cell_start[c] ? 0 : 255;
+static __global__ void k_gap_init(const uint32_t *__restrict__ cell_start, int64_t n_cells, int sx, uint8_t *__restrict__ gap) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // cell; its sx sub-cells are consecutive table entries
+    if (c < n_cells) gap[c] = cell_start[(c + 1) * sx] > cell_start[c * sx] ? 0 : 255;
 }
 static __global__ void k_gap_dilate(uint8_t *gap, int nx, int ny, int nz, int ring) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

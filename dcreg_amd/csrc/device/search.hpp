@@ -49,8 +49,10 @@ struct GridDev {
     double ox, oy, oz;   // origin (min corner)
     double inv_h, h;
     int nx, ny, nz;
+    int sx;                       // x sub-cells per cell (>= 1): the point order and the table are (z, y, x-sub-cell) row-major, so a
+                                  // (y,z) row is still ONE contiguous run per x-interval, but the interval is cut sx times finer
     uint32_t n_pts;
-    const uint32_t *cell_start;   // [nx*ny*nz + 1]
+    const uint32_t *cell_start;   // [nx*sx*ny*nz + 1], entry ((z*ny + y)*nx + x)*sx + sub
     const float4 *pts;            // sorted target; at least 3 readable entries follow the last point (candidate loads come in fours)
     const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
     int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
@@ -226,6 +228,15 @@ template <class H>
 DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp);
 
 DCREG_DEVFN int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // lo <= hi at every call site
+// square root to 1 ulp (v_sqrt_f32) for reach computations that carry a 1e-5 relative safety margin anyway; sqrtf() expands to
+// a ~17-instruction correctly-rounded sequence on gfx950
+DCREG_DEVFN float sqrt_approx(float x) {
+#if DCREG_ON_DEVICE
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
@@ -302,7 +313,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         // bounded search: a query farther than max_ring cells from the grid has no neighbour inside the radius
         if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
     }
-    const double big = 1.0e9;
+    const double big = 6.0e7;     // cell coordinates stay below 2^26 in magnitude: sub-cell indices (x16) and ring arithmetic fit in 32 bits
     const double flx = floor(fmin(fmax(fx, -big), big)), fly = floor(fmin(fmax(fy, -big), big)), flz = floor(fmin(fmax(fz, -big), big));
     const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
     const int nx = g.nx, ny = g.ny, nz = g.nz;
@@ -313,21 +324,23 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 
     // ---- rings 0+1, phase A: the 9 (y,z) rows of the 3x3x3 block, each one contiguous x-run.  Straight-line code: all 18
     // table loads are unconditional and in flight together (a row that is outside the grid or out of reach loads entry 0
-    // twice and so yields an empty run), 32-bit cell arithmetic (the grid has at most 2^27 cells), and the reach tests
-    // compare SQUARED distances, shrunk so that a row / an end cell is never dropped on a distance it does not have
-    // (the float chain of dist2_nofma can come out below the exact value by a few ulp; these margins are 1e-5 .. 1e-4).
-    // Empty runs are dropped when the list is written, nearest rows come first.
+    // twice and so yields an empty run), 32-bit cell arithmetic (the table has at most 2^27 entries).  The x-interval of a
+    // row is the part of the three cells the ball of radius sqrt(bound) can reach, in SUB-CELLS (GridDev::sx per cell): the
+    // finer cut costs nothing in rows or table loads and spares the candidates of the sub-cells beyond the ball.  All reach
+    // tests are conservative (the float chain of dist2_nofma can come out below the exact value by a few ulp; the margins
+    // here are 1e-5 relative plus 1e-4 of a sub-cell).  Empty runs are dropped when the list is written, nearest rows first.
     const int tid = threadIdx.x & (kWave - 1);
     int nrun = 0;
     {
         const float hf = (float)g.h;
         const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
-        const float gxl = frx * hf, gxh = (1.f - frx) * hf;
         const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
         const float gy2[3] = {gyl * gyl * 0.99999f, 0.f, gyh * gyh * 0.99999f}, gz2[3] = {gzl * gzl * 0.99999f, 0.f, gzh * gzh * 0.99999f};
-        const float xl2 = gxl * gxl * 0.9999f, xh2 = gxh * gxh * 0.9999f;
-        const float lim_x = bound_f + 1e-12f * hf * hf;      // absolute slack: an end cell a hair away is always taken
-        const uint32_t unx = (uint32_t)nx, uny = (uint32_t)ny, sxy = unx * uny;
+        const int sx = g.sx, nxf = nx * sx;
+        const int cxs = cx * sx;                                   // first sub-cell of the query's cell (|cx| <= 6e7, sx <= 16: no overflow)
+        const float uf = frx * (float)sx;                          // query position inside its cell, in sub-cells
+        const float kx = (float)g.inv_h * (float)sx * 1.00001f;    // metres -> sub-cells, with the relative margin
+        const uint32_t unx = (uint32_t)nxf, uny = (uint32_t)ny, sxy = unx * uny;
         const uint32_t base_c = ((uint32_t)cz * uny + (uint32_t)cy) * unx;          // garbage when (cy, cz) is outside: not used then
         const uint32_t yoff[3] = {base_c - unx, base_c, base_c + unx};
         const bool yok[3] = {(uint32_t)(cy - 1) < uny, (uint32_t)cy < uny, (uint32_t)(cy + 1) < uny};
@@ -341,10 +354,11 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         for (int r = 0; r < 9; ++r) {
             const float g2 = gy2[DY[r] + 1] + gz2[DZ[r] + 1];
             g2s[r] = g2;
-            // x-cells of this row the ball of radius sqrt(bound) can reach (conservative): a tight bound (warm start)
-            // trims the three-cell run to one or two cells, or drops the row
-            const float rem = lim_x - g2;
-            const int x0 = clampi(cx - (xl2 <= rem ? 1 : 0), 0, nx), x1 = clampi(cx + 1 + (xh2 <= rem ? 1 : 0), 0, nx);   // [x0, x1)
+            // sub-cells of this row the ball can reach, clipped to the three cells of the block and to the grid: a tight bound
+            // (warm start) trims the run to a few sub-cells, or drops the row
+            const float rxf = fminf(sqrt_approx(fmaxf(bound_f - g2, 0.f)) * kx + 1e-4f, 1.0e6f);
+            const int lo = max((int)floorf(uf - rxf), -sx), hi = min((int)floorf(uf + rxf), 2 * sx - 1);
+            const int x0 = clampi(cxs + lo, 0, nxf), x1 = clampi(cxs + hi + 1, 0, nxf);   // [x0, x1)
             const bool ok = yok[DY[r] + 1] && zok[DZ[r] + 1] && (x1 > x0) && !(g2 > bound_f);
             const uint32_t row = yoff[DY[r] + 1] + (DZ[r] < 0 ? 0u - sxy : (DZ[r] > 0 ? sxy : 0u));
             rs[r] = g.cell_start[ok ? row + (uint32_t)x0 : 0u];
@@ -446,7 +460,6 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
     knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp, stamp);
 }
 
-#if !defined(DCREG_SHELLS_FACES)
 // Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
 // Ring kk = the surface of the cube of Chebyshev radius kk: its z faces and y faces are swept as (y,z) rows with the x-run of each
 // row trimmed to the cells the K-th-best ball can still reach (kd-tree style pruning on the grid); of the rows in between only the
@@ -458,7 +471,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //     row, and the (y,z) loops stop at the radius the ball still has at that x distance;
 //   * faces whose cell layer lies beyond the K-th best are not entered;
 //   * the loop bounds are uniform over the wave's lanes up to that radius, so the 64 queries stay in lock-step (a face walk with
-//     per-lane iteration order, empty-space culling per face and centre-out rows - below, -DDCREG_SHELLS_FACES - visited fewer rows
+//     per-lane iteration order, empty-space culling per face and centre-out rows visited fewer rows
 //     and was 25 % slower; batching the table loads of four rows, a flattened collect-then-scan walk and a 2x2x2 block occupancy
 //     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
 template <class H>
@@ -496,6 +509,10 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
     // inside that cell, in cells): single precision - every use carries a 1e-5 relative safety factor against 1e-7 of rounding
     const float frx = (float)(fx - (double)cx), fry = (float)(fy - (double)cy), frz = (float)(fz - (double)cz);
     const float inv_hf = (float)g.inv_h;
+    // x in sub-cells (GridDev::sx per cell): rows are trimmed to the sub-cell, the x faces are whole cells
+    const int sx = g.sx, nxf = nx * sx;
+    const int cxs = cx * sx;                           // |cx| <= 6e7 (knn_search), sx <= 16: no overflow
+    const float uf = frx * (float)sx, inv_hfs = inv_hf * (float)sx;
     auto slab = [&](int c, int cq, float fr) -> float {
         return c < cq ? ((float)(cq - c - 1) + fr) * hf : (c > cq ? ((float)(c - cq) - fr) * hf : 0.f);
     };
@@ -505,12 +522,13 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         DCREG_STAT(rows);
         const float w = hp.worst_d2();
         if (dyz > w) return;
-        // cells of the row the ball still reaches, relative to the query's cell (conservative: 1e-5 relative + 1e-4 of a cell)
-        const float xr_c = fminf((sqrtf(w - dyz) * 1.00001f) * inv_hf + 1e-4f, 1.0e6f);
-        const int dlo = (int)floorf(frx - xr_c), dhi = (int)floorf(frx + xr_c);         // cell offsets from cx
-        const int x0 = max(cx + max(dlo, -kk), 0), x1 = min(cx + min(dhi, kk), nx - 1) + 1;
+        // sub-cells of the row the ball still reaches, relative to the query's cell (conservative: 1e-5 relative + 1e-4 of a sub-cell)
+        const float xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
+        const int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);           // sub-cell offsets from cxs
+        const int kks = min(kk, 1 << 26) * sx;
+        const int x0 = max(cxs + max(dlo, -kks), 0), x1 = min(cxs + min(dhi, kks + sx - 1), nxf - 1) + 1;
         if (x1 <= x0) return;
-        const int64_t row = ((int64_t)z * ny + y) * nx;
+        const int64_t row = ((int64_t)z * ny + y) * nxf;
         DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + x1] - g.cell_start[row + x0] + 3u) / 4u);
         lookup_scan(row + x0, row + x1);
     };
@@ -538,7 +556,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             d2f[f] = gl * gl * 0.99999f;
             live[f] = layer >= 0 && layer < nq && !(d2f[f] > w_ring);
             // the cap the ball cuts out of the face reaches floor(rho / h) + 1 cells from the face cell under the query
-            const float rho = sqrtf(fmaxf(w_ring - d2f[f], 0.f)) * 1.00001f + 1e-6f * hf;
+            const float rho = sqrt_approx(fmaxf(w_ring - d2f[f], 0.f)) * 1.00001f + 1e-6f * hf;
             const double rho_c = (double)rho * g.inv_h;         // may be astronomically large (unbounded searches): compare before converting
             need[f] = rho_c >= (double)kk ? kk : min(kk, (int)rho_c + 1);
             const int xq = clampi(axis == 2 ? layer : cx, 0, nx - 1), yq = clampi(axis == 1 ? layer : cy, 0, ny - 1),
@@ -555,7 +573,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         // `fr` inside its cell: a row at offset +o is (o - fr) cells away, one at -o is (o - 1 + fr) cells away (conservative by
         // 1e-5 relative + 1e-4 of a cell); clipped to +-cap.  The loops below are bounded per lane; the wave runs to the widest.
         auto reach = [&](float r2, float fr, int cap, int &lo, int &hi) {
-            const float rc = fminf(sqrtf(fmaxf(r2, 0.f)) * 1.00001f * inv_hf + 1e-4f, 1.0e6f);
+            const float rc = fminf(sqrt_approx(fmaxf(r2, 0.f)) * 1.00001f * inv_hf + 1e-4f, 1.0e6f);
             lo = -min(cap, (int)floorf(rc + 1.f - fr));
             hi = min(cap, (int)floorf(rc + fr));
             if (r2 < 0.f) { lo = 1; hi = 0; }
@@ -614,148 +632,15 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
                     const float gy = slab(y, cy, fry);
                     const float dyz = (gy * gy + gz2) * 0.99999f;
                     const float w = hp.worst_d2();
-                    const int64_t row = ((int64_t)z * ny + y) * nx;
-                    if (gxa2 + dyz <= w) { DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + xa + 1] - g.cell_start[row + xa] + 3u) / 4u); lookup_scan(row + xa, row + xa + 1); }
-                    if (gxb2 + dyz <= hp.worst_d2()) { DCREG_TRACE(kk, dz, dy, 1, (g.cell_start[row + xb + 1] - g.cell_start[row + xb] + 3u) / 4u); lookup_scan(row + xb, row + xb + 1); }
+                    const int64_t row = ((int64_t)z * ny + y) * nxf, ra = row + (int64_t)xa * sx, rb = row + (int64_t)xb * sx;
+                    if (gxa2 + dyz <= w) { DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[ra + sx] - g.cell_start[ra] + 3u) / 4u); lookup_scan(ra, ra + sx); }
+                    if (gxb2 + dyz <= hp.worst_d2()) { DCREG_TRACE(kk, dz, dy, 1, (g.cell_start[rb + sx] - g.cell_start[rb] + 3u) / 4u); lookup_scan(rb, rb + sx); }
                 }
             }
         }
     }
 }
 
-#else
-// Experiment (rejected on measurement, see above).
-// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
-// (fx,fy,fz) = query position in cell units.  Ring kk is walked as its six FACES, not as (2kk+1)^2 rows:
-//   * a face whose cell layer lies beyond the current K-th best is dropped by arithmetic alone;
-//   * the empty-space field is read ONCE per remaining face, at the face cell under the query: if its nearest occupied
-//     cell is farther (Chebyshev) than the cap the K-th-best ball cuts out of the face, the whole cap is empty - a query
-//     hovering 6 cells off a wall asks 6 bytes per ring instead of walking ~250 empty cells;
-//   * the rows of a face are visited CENTRE-OUT (the row under the query first), so the heap holds near points before the
-//     far rows are tested, and each side stops at the first row the ball no longer reaches (distances grow monotonically);
-//   * every row's x-run is trimmed to the cells the K-th-best ball can still reach, as before.
-// Exact: a cell is skipped only when its minimal distance to the query exceeds the K-th best, or when the field proves it
-// empty.  Faces: +-z (rows y in [cy-kk, cy+kk]), +-y (rows z in (cz-kk, cz+kk)), +-x (single cells, y and z in the open range).
-// slab distance (metres, float) from the query (cell cq, cell coordinate f) to cell index c along one axis
-DCREG_DEVFN float slab_dist(int c, int cq, double f, float hf) {
-    return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
-}
-
-// centre-out offsets 0, +1, -1, +2, -2, ... up to +-omax; a side is closed when its row falls outside the grid on that side
-// or the caller reports that the ball no longer reaches it
-struct CentreOut {
-    int o, omax;
-    bool plus, up, dn;      // plus: the next offset to hand out is +o (else -o)
-    DCREG_DEVFN void init(int omax_) { o = 0; omax = omax_; plus = true; up = true; dn = true; }
-    // next signed offset, or false when both sides are exhausted
-    DCREG_DEVFN bool next(int &off) {
-        for (;;) {
-            if (o == 0) { o = 1; plus = true; off = 0; return true; }
-            if (o > omax || !(up || dn)) return false;
-            if (plus) { plus = false; if (up) { off = o; return true; } }
-            else { plus = true; const int oo = o; ++o; if (dn) { off = -oo; return true; } }
-        }
-    }
-    DCREG_DEVFN void close(int off) { if (off > 0) up = false; else if (off < 0) dn = false; else { /* centre row: sides stay open */ } }
-};
-
-template <class H>
-DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp, unsigned long long * /*stamp*/) {
-    const int nx = g.nx, ny = g.ny, nz = g.nz;
-    const float hf = (float)g.h;
-    // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
-    int k0 = 1;
-    if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
-        const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
-        k0 = max(1, f - 1);
-    }
-    // nearer side of each axis first
-    const bool zf = (fz - (double)cz) >= 0.5, yf = (fy - (double)cy) >= 0.5, xf = (fx - (double)cx) >= 0.5;
-    for (int k = k0; k < max_ring; ++k) {
-        // after ring k: every point within k*h (minus a rounding guard) has been seen
-        const double safe = (double)k * g.h * (1.0 - 1e-9);
-        const double safe2 = safe * safe * (1.0 - 1e-6);
-        if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
-        if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
-        const int kk = k + 1;                                   // scan shell kk
-        hp.n_shell = (uint32_t)kk;
-        // ONE loop body for the six faces (a single copy of the row scan in the instruction stream): face f = 2 * axis + side,
-        // axis 0 = z, 1 = y, 2 = x.  A face is a centre-out double loop over (z offset, y offset) around (zc, yc):
-        //   z face, layer zl : zc = zl, no z offsets;  yc = cy, y offsets up to kk;      x-cells [cx-kk, cx+kk]
-        //   y face, layer yl : zc = cz, z offsets up to kk-1;  yc = yl, no y offsets;    x-cells [cx-kk, cx+kk]
-        //   x face, layer xl : zc = cz, z offsets up to kk-1;  yc = cy, up to kk-1;      the single cell xl
-#pragma unroll 1
-        for (int f = 0; f < 6; ++f) {
-            const int axis = f >> 1;
-            const bool first = (f & 1) == 0;
-            const bool lean = axis == 0 ? zf : (axis == 1 ? yf : xf);
-            const int sgn = (first == lean) ? 1 : -1;
-            const int cq = axis == 0 ? cz : (axis == 1 ? cy : cx);
-            const int nq = axis == 0 ? nz : (axis == 1 ? ny : nx);
-            const double fq = axis == 0 ? fz : (axis == 1 ? fy : fx);
-            const int layer = cq + sgn * kk;
-            if (layer < 0 || layer >= nq) continue;
-            const float gl = slab_dist(layer, cq, fq, hf);
-            const float gl2 = gl * gl;
-            if (gl2 * 0.99999f > hp.worst_d2()) continue;       // the whole cell layer lies beyond the K-th best
-            DCREG_STAT(faces);
-            if (g.gap) {
-                // the cap the K-th-best ball cuts out of this face reaches floor(rho / h) + 1 cells from the face cell under the
-                // query; the field value there is the Chebyshev distance to the nearest occupied cell: nothing closer -> cap empty
-                const float rho = sqrtf(fmaxf(hp.worst_d2() - gl2 * 0.99999f, 0.f)) * 1.00001f + 1e-6f * hf;
-                const double rho_c = (double)rho * g.inv_h;     // may be astronomically large (unbounded searches): compare before converting
-                const int need = rho_c >= (double)kk ? kk : min(kk, (int)rho_c + 1);
-                const int xq = clampi(axis == 2 ? layer : cx, 0, nx - 1), yq = clampi(axis == 1 ? layer : cy, 0, ny - 1),
-                          zq = clampi(axis == 0 ? layer : cz, 0, nz - 1);
-                DCREG_STAT(table_loads);
-                const int gv = (int)g.gap[((int64_t)zq * ny + yq) * nx + xq];
-                const int free_r = gv == 255 ? g.gap_cap + 1 : gv;   // every cell closer (Chebyshev) than free_r to that cell is empty
-                if (need < free_r) { DCREG_STAT(face_skips); continue; }
-            }
-            const int zc = axis == 0 ? layer : cz, yc = axis == 1 ? layer : cy;
-            const int ozmax = axis == 0 ? 0 : kk - 1, oymax = axis == 0 ? kk : (axis == 1 ? 0 : kk - 1);
-            const int xa = axis == 2 ? layer : cx - kk, xb = axis == 2 ? layer : cx + kk;
-            const float gx2 = axis == 2 ? gl2 : 0.f;            // x faces: the cell's x distance is fixed
-            CentreOut oz;
-            oz.init(ozmax);
-            int dz;
-            while (oz.next(dz)) {
-                const int z = zc + dz;
-                if (z < 0) { if (dz < 0) oz.dn = false; continue; }
-                if (z >= nz) { if (dz > 0) oz.up = false; continue; }
-                const float gz = slab_dist(z, cz, fz, hf);
-                const float gz2 = gz * gz;
-                // offsets are taken around the query's own cell whenever there are several: distances grow monotonically per side
-                if ((gx2 + gz2) * 0.99999f > hp.worst_d2()) { oz.close(dz); continue; }
-                CentreOut oy;
-                oy.init(oymax);
-                int dy;
-                while (oy.next(dy)) {
-                    const int y = yc + dy;
-                    if (y < 0) { if (dy < 0) oy.dn = false; continue; }
-                    if (y >= ny) { if (dy > 0) oy.up = false; continue; }
-                    const float gy = slab_dist(y, cy, fy, hf);
-                    const float w = hp.worst_d2();
-                    DCREG_STAT(rows);
-                    if ((gx2 + gz2 + gy * gy) * 0.99999f > w) { oy.close(dy); continue; }
-                    // x-cells of this (y,z) row the ball still reaches (conservative), clipped to the ring and the grid
-                    const float dyz = (gz2 + gy * gy) * 0.99999f;
-                    const float xr = sqrtf(fmaxf(w - dyz, 0.f)) * 1.00001f + 1e-6f * hf;
-                    const double xr_c = (double)xr * g.inv_h;
-                    const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
-                    const int x0 = max(max(xa, xmin), 0), x1 = min(min(xb, xmax), nx - 1) + 1;
-                    if (x1 <= x0) continue;
-                    const int64_t r = ((int64_t)z * ny + y) * nx;
-                    DCREG_STAT(table_loads); DCREG_STAT(table_loads);
-                    scan_run<H>(g, g.cell_start[r + x0], g.cell_start[r + x1], qx, qy, qz, hp);
-                }
-            }
-        }
-    }
-}
-
-#endif  // DCREG_SHELLS_FACES
 
 // ---------------------------------------------------------------- exact K-NN of one query (fast path + fallback)
 // Runs the 32-bit-key search; if (and only if) a point outside the result ties with the K-th best distance,

@@ -124,7 +124,9 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  * set, default; results are identical either way), "gap_field" (1 = build the empty-space distance field at the next
  * dcreg_set_target, default; results are identical either way), "fast_plane_fit" (1 = the reduced-instruction plane fit,
  * default; 0 = the Eigen-shaped factorisation step for step; planes agree to a few ulp), "xcd_chunk" (query-block -> XCD
- * mapping: 0 = one contiguous run per XCD, c = runs of c blocks round-robin); experiment knobs: "lds_pad" (extra dynamic LDS
+ * mapping: 0 = one contiguous run per XCD, c = runs of c blocks round-robin), "x_subdiv" (1 / 2 / 4 / 8 / 16 = x sub-cells per grid cell
+ * at the next dcreg_set_target, default 8: candidate runs are trimmed to the sub-cell; results are identical either way);
+ * experiment knobs: "lds_pad" (extra dynamic LDS
  * bytes per block), "keep_source_order" (1 = the next dcreg_set_source keeps the caller's point order instead of the
  * Hilbert sort) */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);

@@ -22,7 +22,7 @@ res, logs = po.icp_run(tree, src, T0, "Ours", cfg)
 poses = [T0] + [np.array(L.T[:]).reshape(4, 4) for L in logs]
 print("oracle run %.1fs" % (time.time() - t0), flush=True)
 t0 = time.time()
-idx = emul.Index(tgt, 1.0)
+idx = emul.Index(tgt, 1.0, x_subdiv=int(os.environ.get("X_SUBDIV", "8")))
 S = emul.Source(src)
 print("index %.1fs: cell %.4f dims %s gap_cap %d" % (time.time() - t0, idx.cell, idx.dims, idx.gap_cap), flush=True)
 # warm state of the END of a run (bench: every run restarts from T0 with the state of the converged pose)

@@ -36,7 +36,7 @@ def lib():
     if _lib is None:
         L = C.CDLL(build())
         L.emu_index_build.restype = C.c_void_p
-        L.emu_index_build.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.emu_index_build.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         L.emu_index_free.argtypes = [C.c_void_p]
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
@@ -69,12 +69,12 @@ def plane_fit(Q, fast):
 class Index:
     """The device's grid index over a target cloud, built on the host."""
 
-    def __init__(self, xyz, radius, cell=0.0, cell_factor=2.0, gap_field=True):
+    def __init__(self, xyz, radius, cell=0.0, cell_factor=2.0, gap_field=True, x_subdiv=8):
         """gap_field: True / False = with / without the empty-space distance field (the block occupancy bitmap is built either
         way); -1 = neither structure."""
         self.xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         self.radius = radius
-        self.ptr = lib().emu_index_build(_ptr(self.xyz), len(self.xyz), float(radius), float(cell), float(cell_factor), int(gap_field))
+        self.ptr = lib().emu_index_build(_ptr(self.xyz), len(self.xyz), float(radius), float(cell), float(cell_factor), int(gap_field), int(x_subdiv))
         h, dims, nc, gc = C.c_double(), (C.c_int32 * 3)(), C.c_int64(), C.c_int32()
         lib().emu_index_info(self.ptr, C.byref(h), dims, C.byref(nc), C.byref(gc))
         self.cell, self.dims, self.n_cells, self.gap_cap = h.value, tuple(dims), nc.value, gc.value

@@ -40,16 +40,18 @@ static double cap_cell_for_budget(double h, const double mn[3], const double mx[
 }
 static inline int clampi_h(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, const double mn[3], const double mx[3]) {
+static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, const double mn[3], const double mx[3], int sx = 1) {
     GridDev g{};
     grid_dims(h, mn, mx, g);
-    const int64_t n_cells = (int64_t)g.nx * g.ny * g.nz;
+    g.sx = sx;
+    const int nxf = g.nx * sx;
+    const int64_t n_cells = (int64_t)nxf * g.ny * g.nz;       // table entries (x in sub-cells, as k_cell_keys)
     std::vector<uint32_t> keys((size_t)n), order((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
-        const int cx = clampi_h((int)std::floor(((double)xyz[3 * i] - g.ox) * g.inv_h), 0, g.nx - 1);
+        const int cx = clampi_h((int)std::floor(((double)xyz[3 * i] - g.ox) * g.inv_h * (double)sx), 0, nxf - 1);
         const int cy = clampi_h((int)std::floor(((double)xyz[3 * i + 1] - g.oy) * g.inv_h), 0, g.ny - 1);
         const int cz = clampi_h((int)std::floor(((double)xyz[3 * i + 2] - g.oz) * g.inv_h), 0, g.nz - 1);
-        keys[(size_t)i] = (uint32_t)(((int64_t)cz * g.ny + cy) * g.nx + cx);
+        keys[(size_t)i] = (uint32_t)(((int64_t)cz * g.ny + cy) * nxf + cx);
     }
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });   // radix sort is stable too
@@ -66,13 +68,13 @@ static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, con
         E.pts[(size_t)i] = float4{xyz[3 * o], xyz[3 * o + 1], xyz[3 * o + 2], __uint_as_float(o)};
     }
     g.n_pts = (uint32_t)n;
-    E.g = g; E.n_cells = n_cells; E.occupied = occ;
+    E.g = g; E.n_cells = n_cells / sx; E.occupied = occ;
     return occ;
 }
 
 extern "C" {
 
-void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double opt_cell, double cell_factor, int gap_field) {
+void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double opt_cell, double cell_factor, int gap_field, int x_subdiv) {
     EmuIndex *E = new EmuIndex();
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
     for (int64_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], (double)xyz[3 * i + a]); mx[a] = std::max(mx[a], (double)xyz[3 * i + a]); }
@@ -97,6 +99,12 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
             h1 = h2; m1 = m2;
         }
     }
+    {   // x sub-cells once the cell edge is settled, as context.hip build_index
+        int sx = 1;
+        while (sx < 16 && sx * 2 <= x_subdiv) sx *= 2;
+        while (sx > 1 && (double)E->g.nx * sx * E->g.ny * E->g.nz > max_cells) sx >>= 1;
+        if (sx > 1) build_at(*E, xyz, n, E->g.h, mn, mx, sx);
+    }
     GridDev &g = E->g;
     g.cell_start = E->cell_start.data();
     g.pts = E->pts.data();
@@ -107,7 +115,7 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
         if (rings >= 2) {
             const int nx = g.nx, ny = g.ny, nz = g.nz;
             E->gap.assign((size_t)E->n_cells, 255);
-            for (int64_t c = 0; c < E->n_cells; ++c) if (E->cell_start[(size_t)c + 1] > E->cell_start[(size_t)c]) E->gap[(size_t)c] = 0;
+            for (int64_t c = 0; c < E->n_cells; ++c) if (E->cell_start[(size_t)(c + 1) * g.sx] > E->cell_start[(size_t)c * g.sx]) E->gap[(size_t)c] = 0;
             for (int r = 1; r <= rings; ++r) {
                 std::vector<uint8_t> nxt = E->gap;
                 for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {

@@ -585,6 +585,34 @@ def test_empty_space_skip_is_exact(ctx):
     assert np.array_equal(got[0][1][0], got[1][1][0])
 
 
+def test_x_sub_cells_only_trim_the_candidate_runs(ctx, cyl):
+    """The "x_subdiv" option cuts every grid cell into sub-cells along x (finer trimming of the candidate runs, same rows):
+    k-NN results must stay exact for every value, and a linearisation bitwise the same (same neighbour sets, same sum order)."""
+    g = np.arange(0, 12, dtype=np.float32) * 0.25
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    tgt = np.concatenate([tgt, tgt[::9]])
+    rng = np.random.default_rng(6)
+    q = np.concatenate([tgt[:300] + 0.125, rng.uniform(-3, 6, (2000, 3)), [[100, 100, 100]], [[-250, 3, 1]]]).astype(np.float32)
+    oi, od = po.KdTree(tgt).knn(q, k=5)
+    tgt_c = cyl[0]
+    src_c = tgt_c[::2]
+    T0 = h.pose6d_matrix(0.3, -0.2, 0.1, h.deg2rad(2.0), h.deg2rad(-1.0), h.deg2rad(3.0))
+    sums = {}
+    try:
+        for sx in (1, 2, 4, 8, 16):
+            ctx.set_option("x_subdiv", sx)
+            ctx.set_target(tgt, 1.0)
+            gi, gd = ctx.knn(q, k=5, max_radius=0.0)
+            assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), sx
+            ctx.set_target(tgt_c, 1.0); ctx.set_source(src_c)
+            out = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(1.0, 1))
+            sums[sx] = (out["n_eff"], np.array(out["H_upper"]), np.array(out["g"]))
+    finally:
+        ctx.set_option("x_subdiv", 8)
+    for sx in (2, 4, 8, 16):
+        assert sums[sx][0] == sums[1][0] and np.array_equal(sums[sx][1], sums[1][1]) and np.array_equal(sums[sx][2], sums[1][2]), sx
+
+
 @pytest.mark.parametrize("method,n_iter", [("Ours", 1500), ("ME-SR", 300), ("ME-TSVD", 300), ("ME-TReg", 300), ("FCN-SR", 300)])
 def test_fig8_long_trace_through_the_hip_path(ctx, cyl, method, n_iter):
     """icp_iter.yaml (max_iterations 5000, vanishing thresholds): the committed per-iteration history of the reference,

@@ -80,8 +80,8 @@ def test_knn_with_ties_duplicates_and_outside_queries():
     rng = np.random.default_rng(5)
     q = np.concatenate([tgt[:300] + 0.125, rng.uniform(-3, 6, (1500, 3)), [[100, 100, 100]], tgt[:50]]).astype(np.float32)
     tree = po.KdTree(tgt)
-    for cell in (0.0, 0.3):                                                   # auto cell and cells of ~one lattice step
-        idx = emul.Index(tgt, 1.0, cell=cell)
+    for cell, sx in ((0.0, 4), (0.3, 4), (0.3, 1), (0.0, 2), (0.3, 16)):          # auto cell / cells of ~one lattice step; x sub-cells
+        idx = emul.Index(tgt, 1.0, cell=cell, x_subdiv=sx)
         for k in (1, 5):
             gi, gd = emul.knn(idx, q, k=k)
             oi, od = tree.knn(q, k=k)
@@ -99,8 +99,8 @@ def test_empty_space_between_clusters():
     tgt = np.concatenate([a, b]).astype(np.float32)
     q = np.concatenate([rng.uniform(2, 9, (1500, 3)) * np.array([1, 0.3, 0.3]), rng.uniform(-4, 14, (500, 3)), tgt[:100] + 0.01]).astype(np.float32)
     oi, od = po.KdTree(tgt).knn(q, k=5)
-    for gap in (True, False):
-        idx = emul.Index(tgt, 3.0, gap_field=gap)
+    for gap, sx in ((True, 4), (False, 4), (True, 1), (True, 8)):
+        idx = emul.Index(tgt, 3.0, gap_field=gap, x_subdiv=sx)
         assert idx.cell < 1.0 and (idx.gap_cap >= 2) == gap
         gi, gd = emul.knn(idx, q, k=5)
         assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
