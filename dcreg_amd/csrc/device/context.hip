@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -522,10 +524,27 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
 int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
                      dcreg_lin_out *outs, dcreg_lin_debug *dbg_host) {
     if (c && !outs) { c->fail("null argument"); return DCREG_E_INVALID; }
+    static const bool timing = std::getenv("DCREG_HOST_TIMING") != nullptr;     // diagnostic: where a blocking call's host time goes
+    using Clk = std::chrono::steady_clock;
+    const auto t0 = Clk::now();
     int rc = linearize_begin(c, 0, n_poses, R9, t3, nullptr, p, dbg_host);
     if (rc) return rc;
+    const auto t1 = Clk::now();
     rc = linearize_end(c, 0, outs);
     if (rc && c) c->slots[0].pending = false;
+    if (timing && c) {
+        static double s_begin = 0.0, s_end = 0.0, s_between = 0.0;
+        static long n = 0;
+        static Clk::time_point last;
+        const auto t2 = Clk::now();
+        if (n > 0) s_between += std::chrono::duration<double, std::micro>(t0 - last).count();
+        s_begin += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        s_end += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        last = t2;
+        if (++n % 100 == 0)
+            std::fprintf(stderr, "[dcreg host timing] %ld blocking linearisations: enqueue %.2f us, wait for the result %.2f us, caller between calls %.2f us (means)\n",
+                         n, s_begin / n, s_end / n, s_between / (n - 1));
+    }
     return rc;
 }
 
