@@ -115,6 +115,7 @@ EXPORTS = [
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
     "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_linearize_debug", "dcreg_knn",
+    "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
@@ -158,6 +159,9 @@ def load():
     L.dcreg_linearize_batch_begin_warm.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, C.POINTER(LinParams)]
     L.dcreg_linearize_batch_end.argtypes = [vp, C.c_int, C.POINTER(LinOut)]
     L.dcreg_reserve_warm_states.argtypes = [vp, C.c_int64]
+    L.dcreg_linearize_gated_begin.argtypes = [vp, C.c_int, C.POINTER(LinParams)]
+    L.dcreg_linearize_gate_open.argtypes = [vp, dp, dp]
+    L.dcreg_linearize_gate_abort.argtypes = [vp]
     L.dcreg_linearize_debug.argtypes = [vp, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut), C.POINTER(LinDebug)]
     L.dcreg_knn.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int, C.c_double, ip, fp]
     L.dcreg_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
@@ -416,6 +420,29 @@ class Context:
                                                              C.byref(params)), "dcreg_linearize_batch_begin_warm")
         self._check(self._L.dcreg_linearize_batch_end(self._h, slot, outs), "dcreg_linearize_batch_end")
         return [self._out_dict(o) for o in outs]
+
+    # pipelined single-pose launches (what dcreg_icp_run does between two iterations)
+    def linearize_begin(self, R, t, params=None, slot=0):
+        params = params or default_lin_params()
+        R = _f64(R).reshape(9); t = _f64(t).reshape(3)
+        self._check(self._L.dcreg_linearize_batch_begin(self._h, slot, 1, _dp(R), _dp(t), C.byref(params)), "dcreg_linearize_batch_begin")
+
+    def linearize_gated_begin(self, params=None, slot=0):
+        """queue a linearisation whose pose arrives later (gate_open) or never (gate_abort)"""
+        params = params or default_lin_params()
+        self._check(self._L.dcreg_linearize_gated_begin(self._h, slot, C.byref(params)), "dcreg_linearize_gated_begin")
+
+    def gate_open(self, R, t):
+        R = _f64(R).reshape(9); t = _f64(t).reshape(3)
+        self._check(self._L.dcreg_linearize_gate_open(self._h, _dp(R), _dp(t)), "dcreg_linearize_gate_open")
+
+    def gate_abort(self):
+        self._check(self._L.dcreg_linearize_gate_abort(self._h), "dcreg_linearize_gate_abort")
+
+    def linearize_end(self, slot=0):
+        out = (LinOut * 1)()
+        self._check(self._L.dcreg_linearize_batch_end(self._h, slot, out), "dcreg_linearize_batch_end")
+        return self._out_dict(out[0])
 
     def knn(self, q, k=5, max_radius=0.0):
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)

@@ -316,9 +316,16 @@ static void free_tmp(LinSlot &S) {
     S.tmp_dev.clear();
 }
 
+// gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
+// _gate_abort decide its fate)
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
-                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host) {
+                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host, bool gated = false) {
     if (!c) return DCREG_E_INVALID;
+    if (gated) {
+        static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+        R9 = eye; t3 = zero; n_poses = 1; state_ids = nullptr; dbg_host = nullptr;
+        if (c->gate_slot >= 0) { c->fail("a gated linearisation already waits for its pose"); return DCREG_E_STATE; }
+    }
     if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
     LinSlot &S = c->slots[slot];
     if (S.pending) { c->fail("slot %d still has a linearisation in flight", slot); return DCREG_E_STATE; }
@@ -369,6 +376,16 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
                 c->prev_stride = stride; c->prev_valid = true;
             }
             a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
+        }
+        if (gated) {
+            if (!c->h_gate) {
+                HIP_TRY(c, hipHostMalloc((void **)&c->h_gate, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent));
+                std::memset(c->h_gate, 0, sizeof(GateHost));
+                HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_gate_host, c->h_gate, 0));
+                HIP_TRY(c, hipMalloc((void **)&c->d_gate_pose, sizeof(PoseArg)));
+                HIP_TRY(c, hipMalloc((void **)&c->d_gate_abort, sizeof(uint32_t)));
+            }
+            d_poses = c->d_gate_pose;
         }
     } else {
         // batched poses: each may own one of the reserved warm-start states (dcreg_reserve_warm_states); -1 = search cold
@@ -423,9 +440,15 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
     const size_t lds = (size_t)c->opt_lds_pad;
+    const uint32_t *abort_flag = nullptr;
+    if (gated) {
+        const unsigned long long want = ++c->gate_seq;
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, c->d_gate_abort);
+        abort_flag = c->d_gate_abort;
+    }
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                            \
     hipLaunchKernelGGL((k_linearize<MODE, FUSED, FAST>), grid, dim3(kBlock), lds, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, \
-                       S.d_partials, nbx, fin, dd)
+                       S.d_partials, nbx, fin, dd, abort_flag)
     if (c->opt_fast_plane) {
         if (dbg_host) DCREG_LAUNCH_LIN(1, true, true);
         else if (fused) DCREG_LAUNCH_LIN(0, true, true);
@@ -438,7 +461,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
 #undef DCREG_LAUNCH_LIN
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
         const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { free_tmp(S); c->fail("k_linearize launch failed: %s", hipGetErrorString(le)); return DCREG_E_DEVICE; }
+        if (le != hipSuccess) {
+            free_tmp(S);
+            if (gated) __atomic_store_n(&c->h_gate->seq, (c->gate_seq << 1) | 1ull, __ATOMIC_RELEASE);   // the gate in the queue must not wait
+            c->fail("k_linearize launch failed: %s", hipGetErrorString(le));
+            return DCREG_E_DEVICE;
+        }
     }
     if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
     if (!fused || dbg_host) {
@@ -466,6 +494,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     }
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
+    if (gated) c->gate_slot = slot;
     return DCREG_OK;
 }
 
@@ -617,7 +646,11 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (!c) return;
     (void)dcreg_comm_destroy(c);
     (void)hipSetDevice(c->device);
+    (void)dcreg_linearize_gate_abort(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->h_gate) (void)hipHostFree(c->h_gate);
+    if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
+    if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
                     c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_prev_batch, c->d_gap};
@@ -700,6 +733,27 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
     return DCREG_OK;
 }
 int dcreg_linearize_batch_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) { return linearize_end(c, slot, outs); }
+int dcreg_linearize_gated_begin(dcreg_ctx *c, int slot, const dcreg_lin_params *p) {
+    return linearize_begin(c, slot, 1, nullptr, nullptr, nullptr, p, nullptr, true);
+}
+int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]) {
+    if (!c) return DCREG_E_INVALID;
+    if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
+    std::memcpy(c->h_gate->R, R, sizeof(c->h_gate->R)); std::memcpy(c->h_gate->t, t, sizeof(c->h_gate->t));
+    __atomic_store_n(&c->h_gate->seq, c->gate_seq << 1, __ATOMIC_RELEASE);
+    c->gate_slot = -1;
+    return DCREG_OK;
+}
+int dcreg_linearize_gate_abort(dcreg_ctx *c) {
+    if (!c) return DCREG_E_INVALID;
+    if (c->gate_slot < 0) return DCREG_OK;                                  // nothing queued
+    __atomic_store_n(&c->h_gate->seq, (c->gate_seq << 1) | 1ull, __ATOMIC_RELEASE);
+    LinSlot &S = c->slots[c->gate_slot];
+    S.pending = false;                 // no result will come; tickets_dirty stays set, so the next launch of the slot clears them
+    free_tmp(S);
+    c->gate_slot = -1;
+    return DCREG_OK;
+}
 int dcreg_linearize_debug(dcreg_ctx *c, const double R[9], const double t[3], const dcreg_lin_params *p, dcreg_lin_out *out, dcreg_lin_debug *dbg) {
     return launch_linearize(c, 1, R, t, p, out, dbg);
 }

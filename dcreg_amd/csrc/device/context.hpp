@@ -75,6 +75,12 @@ struct dcreg_ctx {
     char *sort_tmp = nullptr; size_t sort_tmp_cap = 0;
 
     // linearisation: per-slot buffers (see linearize_begin / linearize_end)
+    // gate of pipelined launches (kernels.hpp k_gate): pinned sequence number + pose, the device-resident pose it fills, abort word
+    dcreg::GateHost *h_gate = nullptr, *d_gate_host = nullptr;
+    dcreg::PoseArg *d_gate_pose = nullptr;
+    uint32_t *d_gate_abort = nullptr;
+    unsigned long long gate_seq = 0;       // number of the gated launch last queued
+    int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)
     static constexpr int kLinSlots = 2;
     LinSlot slots[kLinSlots];
 

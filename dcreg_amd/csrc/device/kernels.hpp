@@ -179,10 +179,43 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
     return tot;
 }
 
+// ---------------------------------------------------------------- the gate of a pipelined launch
+// An ICP loop alternates one linearisation and a 3 us host step, and every launch costs ~4 us of host time plus ~2 us until the
+// device starts: idle time for a device that has nothing else queued.  A GATED linearisation is queued while its predecessor still
+// runs, before its pose exists: k_gate (one wave) sits in the stream in front of it and polls a sequence number in pinned host
+// memory; when the host publishes the pose (two stores) the gate copies it into the device-resident PoseArg the linearisation
+// reads, and retires.  The host can also call the launch off (abort bit): the linearisation behind the gate then returns at once.
+// A gate that waits longer than ~5 s aborts by itself (wall clock, 100 MHz), so a vanished host cannot leave the queue spinning.
+struct GateHost { unsigned long long seq; double R[9]; double t[3]; };      // pinned, host-coherent; seq = (launch number << 1) | abort
+static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
+                                                   uint32_t *__restrict__ abort_flag) {
+    const int lane = threadIdx.x;
+    unsigned long long s = 0;
+    if (lane == 0) {
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            s = __hip_atomic_load(&hg->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((s >> 1) == want) break;
+            if (wall_clock64() - t0 > 500000000ull) { s = (want << 1) | 1ull; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)s), hi = __builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
+    s = ((unsigned long long)hi << 32) | lo;
+    if (lane < 12) {
+        const double *from = lane < 9 ? hg->R + lane : hg->t + (lane - 9);
+        const double v = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (lane < 9) dst->R[lane] = v; else dst->t[lane - 9] = v;
+    }
+    if (lane == 0) { dst->state = 0; dst->pad_ = 0; *abort_flag = (uint32_t)(s & 1ull); }
+}
+
 template <int MODE, bool FUSED, bool FAST>
 static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
-                                                       double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg) {
+                                                       double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg,
+                                                       const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
     __shared__ double red[8][kSlots];
     __shared__ double cnt[kBlock / 64][2];
     __shared__ int s_role;

@@ -105,12 +105,25 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
         return DCREG_OK;
     }
     int rc_all = DCREG_OK;
+    // One pair, no exchange: the launches are pipelined - while linearisation `it` runs, linearisation `it + 1` is queued behind
+    // a gate (dcreg_linearize_gated_begin); the host step then only publishes the pose.  slot = where linearisation `it` lives.
+    const bool piped = !reduce;
+    int slot = 0;
+    bool queued = false;                        // a gated launch waits for its pose
     for (int it = 0; it < cfg->max_iterations; ++it) {
         const auto t_iter = Clock::now();
         dcreg_lin_out lo;
         std::memset(&lo, 0, sizeof(lo));
         int rc = DCREG_OK;
-        if (!local_bad && !local_empty) rc = dcreg_linearize(ctx, R, t, &prm, &lo);
+        if (piped) {
+            if (it == 0) rc = dcreg_linearize_batch_begin(ctx, slot, 1, R, t, &prm);
+            if (rc != DCREG_OK) return rc;
+            queued = it + 1 < cfg->max_iterations && dcreg_linearize_gated_begin(ctx, slot ^ 1, &prm) == DCREG_OK;
+            rc = dcreg_linearize_batch_end(ctx, slot, &lo);
+            if (rc != DCREG_OK) { if (queued) dcreg_linearize_gate_abort(ctx); return rc; }
+        } else if (!local_bad && !local_empty) {
+            rc = dcreg_linearize(ctx, R, t, &prm, &lo);
+        }
         if (!reduce && rc != DCREG_OK) return rc;
         if (reduce) {   // point sharding: this rank linearised its slice; the sums of all slices, added in rank order
             double row[32];
@@ -133,6 +146,14 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
         StepOut so;
         const int st = host_step(lo, detection, handling, *cfg, R, t, so);
         if (st == 2) { res->iterations = it; res->converged = 0; res->status = 2; break; }
+        if (piped && st != 1 && it + 1 < cfg->max_iterations) {
+            // the pose of the next linearisation exists: let the device go before the bookkeeping below
+            if (queued) rc = dcreg_linearize_gate_open(ctx, R, t);                       // the queued launch starts now
+            else rc = dcreg_linearize_batch_begin(ctx, slot ^ 1, 1, R, t, &prm);         // (queueing ahead had failed)
+            queued = false;
+            if (rc != DCREG_OK) return rc;
+            slot ^= 1;
+        }
         std::memcpy(Hlast, so.H, sizeof(Hlast));
         if (log && it < log_capacity) {
             dcreg_iter_log &L = log[it];
@@ -152,6 +173,7 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
         res->iterations = it + 1;
         if (st == 1) { res->converged = 1; break; }
     }
+    if (queued) dcreg_linearize_gate_abort(ctx);     // left the loop early: the launch queued ahead is called off
     std::memcpy(res->R, R, sizeof(R)); std::memcpy(res->t, t, sizeof(t));
     covariance_of(res->converged != 0, Hlast, res->icp_cov);
     res->time_ms = ms_since(t_total);

@@ -146,6 +146,15 @@ int dcreg_linearize_batch(dcreg_ctx *, int n_poses, const double *R9, const doub
  * results of that slot (pinned-memory sequence numbers) and unpacks them.  Two slots (0, 1) with their own buffers: keep
  * one batch on the device while the host solves the other (dcreg_icp_run_trials does).  R9 / t3 are copied by _begin. */
 int dcreg_linearize_batch_begin(dcreg_ctx *, int slot, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *);
+/* pipelined single-pose launches (what dcreg_icp_run does between two iterations): _gated_begin queues a linearisation on `slot`
+ * whose pose is not known yet - a one-wave gate kernel in front of it waits for it - typically while the previous linearisation
+ * still runs; _gate_open publishes the pose (two stores, the device starts at once: no launch on the critical path); _gate_abort
+ * calls the queued linearisation off (it returns without touching results or warm state).  Exactly one of the two must follow every
+ * _gated_begin; results come through dcreg_linearize_batch_end(slot).  At most one gated launch waits at a time.  A gate nobody
+ * opens gives up after ~5 s. */
+int dcreg_linearize_gated_begin(dcreg_ctx *, int slot, const dcreg_lin_params *);
+int dcreg_linearize_gate_open(dcreg_ctx *, const double R[9], const double t[3]);
+int dcreg_linearize_gate_abort(dcreg_ctx *);
 int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
 /* Warm-start states for batched launches.  A single-pose linearisation bounds its search by the neighbour set its own
  * previous call found (kept inside the ctx); poses of a batch belong to different trajectories, so each needs a state of

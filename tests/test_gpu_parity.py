@@ -585,6 +585,47 @@ def test_empty_space_skip_is_exact(ctx):
     assert np.array_equal(got[0][1][0], got[1][1][0])
 
 
+def test_gated_launches_equal_blocking_ones(cyl):
+    """dcreg_linearize_gated_begin / _gate_open / _gate_abort (the launch pipeline of dcreg_icp_run): a linearisation queued behind
+    the gate before its pose exists gives bitwise the result of the blocking call; a launch that is called off leaves results and
+    warm state untouched; the protocol errors are reported, and a context can be destroyed with a gate still waiting."""
+    tgt = cyl[0]
+    src = tgt[::3]
+    prm = api.default_lin_params(1.0, 1)
+    poses = [h.pose6d_matrix(0.05 * k, -0.03 * k, 0.02, h.deg2rad(0.3 * k), 0.0, h.deg2rad(-0.2 * k)) for k in range(6)]
+    ref = api.Context(0)
+    ref.set_target(tgt, 1.0); ref.set_source(src)
+    want = [ref.linearize(T[:3, :3], T[:3, 3], prm) for T in poses]
+    c = api.Context(0)
+    c.set_target(tgt, 1.0); c.set_source(src)
+    slot = 0
+    c.linearize_begin(poses[0][:3, :3], poses[0][:3, 3], prm, slot=slot)
+    got = []
+    for k in range(len(poses)):
+        last = k + 1 == len(poses)
+        if not last:
+            c.linearize_gated_begin(prm, slot=slot ^ 1)             # queued while linearisation k is in flight
+            with pytest.raises(api.DcregError):
+                c.linearize_gated_begin(prm, slot=slot)             # only one gate at a time
+        got.append(c.linearize_end(slot=slot))
+        if not last:
+            c.gate_open(poses[k + 1][:3, :3], poses[k + 1][:3, 3])
+            slot ^= 1
+    for a, b in zip(got, want):
+        assert a["n_eff"] == b["n_eff"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
+    with pytest.raises(api.DcregError):
+        c.gate_open(poses[0][:3, :3], poses[0][:3, 3])              # nothing waits
+    # a launch that is called off: the next blocking call behaves as if it had never been queued
+    c.linearize_gated_begin(prm, slot=1)
+    c.gate_abort()
+    c.gate_abort()                                                  # idempotent
+    again = c.linearize(poses[-1][:3, :3], poses[-1][:3, 3], prm)
+    assert again["n_eff"] == want[-1]["n_eff"] and np.array_equal(again["H_upper"], want[-1]["H_upper"])
+    c.linearize_gated_begin(prm, slot=1)
+    c.close()                                                       # destroys the context with the gate still waiting
+    ref.close()
+
+
 def test_x_sub_cells_only_trim_the_candidate_runs(ctx, cyl):
     """The "x_subdiv" option cuts every grid cell into sub-cells along x (finer trimming of the candidate runs, same rows):
     k-NN results must stay exact for every value, and a linearisation bitwise the same (same neighbour sets, same sum order)."""
