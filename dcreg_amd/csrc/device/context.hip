@@ -316,6 +316,20 @@ static void free_tmp(LinSlot &S) {
     S.tmp_dev.clear();
 }
 
+// publish a gate record (kernels.hpp GateHost): pose words and checksum first, the number last
+static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double *R, const double *t) {
+    unsigned long long w[14];
+    w[0] = seq_word;
+    for (int k = 0; k < 12; ++k) w[1 + k] = c->h_gate->w[1 + k];            // abort: the pose words stay whatever they were
+    if (R) std::memcpy(&w[1], R, 9 * sizeof(double));
+    if (t) std::memcpy(&w[10], t, 3 * sizeof(double));
+    unsigned long long x = kGateSalt;
+    for (int k = 0; k < 13; ++k) x ^= w[k];
+    w[13] = x;
+    volatile unsigned long long *dst = c->h_gate->w;
+    for (int k = 1; k < 14; ++k) dst[k] = w[k];
+    __atomic_store_n(&c->h_gate->w[0], w[0], __ATOMIC_RELEASE);
+}
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
 // _gate_abort decide its fate)
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
@@ -463,7 +477,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             free_tmp(S);
-            if (gated) __atomic_store_n(&c->h_gate->seq, (c->gate_seq << 1) | 1ull, __ATOMIC_RELEASE);   // the gate in the queue must not wait
+            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);   // the gate in the queue must not wait
             c->fail("k_linearize launch failed: %s", hipGetErrorString(le));
             return DCREG_E_DEVICE;
         }
@@ -739,15 +753,14 @@ int dcreg_linearize_gated_begin(dcreg_ctx *c, int slot, const dcreg_lin_params *
 int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
-    std::memcpy(c->h_gate->R, R, sizeof(c->h_gate->R)); std::memcpy(c->h_gate->t, t, sizeof(c->h_gate->t));
-    __atomic_store_n(&c->h_gate->seq, c->gate_seq << 1, __ATOMIC_RELEASE);
+    gate_publish(c, c->gate_seq << 1, R, t);
     c->gate_slot = -1;
     return DCREG_OK;
 }
 int dcreg_linearize_gate_abort(dcreg_ctx *c) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0) return DCREG_OK;                                  // nothing queued
-    __atomic_store_n(&c->h_gate->seq, (c->gate_seq << 1) | 1ull, __ATOMIC_RELEASE);
+    gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);
     LinSlot &S = c->slots[c->gate_slot];
     S.pending = false;                 // no result will come; tickets_dirty stays set, so the next launch of the slot clears them
     free_tmp(S);

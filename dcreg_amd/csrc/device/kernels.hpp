@@ -182,32 +182,44 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // ---------------------------------------------------------------- the gate of a pipelined launch
 // An ICP loop alternates one linearisation and a 3 us host step, and every launch costs ~4 us of host time plus ~2 us until the
 // device starts: idle time for a device that has nothing else queued.  A GATED linearisation is queued while its predecessor still
-// runs, before its pose exists: k_gate (one wave) sits in the stream in front of it and polls a sequence number in pinned host
-// memory; when the host publishes the pose (two stores) the gate copies it into the device-resident PoseArg the linearisation
-// reads, and retires.  The host can also call the launch off (abort bit): the linearisation behind the gate then returns at once.
+// runs, before its pose exists: k_gate (one wave) sits in the stream in front of it and polls a small record in pinned host
+// memory; when the host publishes the pose there, the gate copies it into the device-resident PoseArg the linearisation reads,
+// and retires.  The host can also call the launch off (abort bit): the linearisation behind the gate then returns at once.
 // A gate that waits longer than ~5 s aborts by itself (wall clock, 100 MHz), so a vanished host cannot leave the queue spinning.
-struct GateHost { unsigned long long seq; double R[9]; double t[3]; };      // pinned, host-coherent; seq = (launch number << 1) | abort
+// The gate record: 16 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
+// patterns), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The gate reads all 16 words with ONE load per lane and accepts them only
+// if the number is the awaited one AND the checksum holds: the loads of one poll may be served in any order relative to the host's
+// stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip between "pose published" and "pose on
+// the device", whatever the read granularity of the link.
+struct alignas(128) GateHost { unsigned long long w[16]; };
+constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
 static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
                                                    uint32_t *__restrict__ abort_flag) {
     const int lane = threadIdx.x;
-    unsigned long long s = 0;
-    if (lane == 0) {
-        const unsigned long long t0 = wall_clock64();
-        for (;;) {
-            s = __hip_atomic_load(&hg->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((s >> 1) == want) break;
-            if (wall_clock64() - t0 > 500000000ull) { s = (want << 1) | 1ull; break; }
-            __builtin_amdgcn_s_sleep(4);
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long v = 0, seq = 0;
+    for (;;) {
+        v = lane < 16 ? __hip_atomic_load(&hg->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        // x = xor of words 0..12 and of word 13 (lanes >= 14 contribute 0): zero ^ salt when the record is whole
+        unsigned long long x = lane < 14 ? v : 0ull;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+            x ^= ((unsigned long long)hi << 32) | lo;
         }
+        const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        seq = ((unsigned long long)shi << 32) | slo;                        // lane 0's word
+        const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+        const bool whole = (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
+        if ((seq >> 1) == want && whole) break;
+        if (wall_clock64() - t0 > 500000000ull) { seq = (want << 1) | 1ull; break; }     // ~5 s at 100 MHz: nobody opens - give up
+        __builtin_amdgcn_s_sleep(2);
     }
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)s), hi = __builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
-    s = ((unsigned long long)hi << 32) | lo;
-    if (lane < 12) {
-        const double *from = lane < 9 ? hg->R + lane : hg->t + (lane - 9);
-        const double v = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-        if (lane < 9) dst->R[lane] = v; else dst->t[lane - 9] = v;
+    if (lane >= 1 && lane <= 12) {
+        const double d = __longlong_as_double((long long)v);
+        if (lane <= 9) dst->R[lane - 1] = d; else dst->t[lane - 10] = d;
     }
-    if (lane == 0) { dst->state = 0; dst->pad_ = 0; *abort_flag = (uint32_t)(s & 1ull); }
+    if (lane == 0) { dst->state = 0; dst->pad_ = 0; *abort_flag = (uint32_t)(seq & 1ull); }
 }
 
 template <int MODE, bool FUSED, bool FAST>
