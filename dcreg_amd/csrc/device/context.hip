@@ -451,7 +451,6 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
     // kernel timing: HIP events around every opt_time_kernels-th launch (each timed launch costs ~10 us of host time)
     const bool timed = slot == 0 && c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
-    if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const dim3 grid(nbx, (unsigned)n_poses);
     const size_t lds = (size_t)c->opt_lds_pad;
     const uint32_t *abort_flag = nullptr;
@@ -459,6 +458,14 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         const unsigned long long want = ++c->gate_seq;
         hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, c->d_gate_abort);
         abort_flag = c->d_gate_abort;
+    }
+    if (timed) {                           // after the gate: the events bracket k_linearize, not the wait for the pose
+        const hipError_t ee = hipEventRecord(c->ev0, c->stream);
+        if (ee != hipSuccess) {
+            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);
+            c->fail("hipEventRecord failed: %s", hipGetErrorString(ee));
+            return DCREG_E_DEVICE;
+        }
     }
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                            \
     hipLaunchKernelGGL((k_linearize<MODE, FUSED, FAST>), grid, dim3(kBlock), lds, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, \
@@ -482,7 +489,14 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             return DCREG_E_DEVICE;
         }
     }
-    if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));   // brackets k_linearize alone
+    if (timed) {                           // brackets k_linearize alone
+        const hipError_t ee = hipEventRecord(c->ev1, c->stream);
+        if (ee != hipSuccess) {
+            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);
+            c->fail("hipEventRecord failed: %s", hipGetErrorString(ee));
+            return DCREG_E_DEVICE;
+        }
+    }
     if (!fused || dbg_host) {
         if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
         const hipError_t le = hipGetLastError();

@@ -1,0 +1,10 @@
+"""Short view of bench.py JSON lines.  usage: print_bench.py file.json [...]"""
+import json, sys
+for f in sys.argv[1:]:
+    d = json.loads(open(f).read().strip().split("\n")[-1])
+    print(f, "value %.1f" % d["value"], "ms/step mean %.5f median %.5f min %.5f max %.5f" % (d["ms_per_step"], d["ms_per_step_median"], d["ms_per_step_min"], d["ms_per_step_max"]))
+    r, v = d["roofline"], d.get("roofline_valu_issue") or {}
+    print("  roofline: %.1f GB/s frac %.4f traffic %.3e kernel_us_avg %.2f | valu frac %s floor %s" % (r["achieved"], r["frac"], r["traffic"] or 0, r["kernel_us_avg"], v.get("frac"), v.get("floor_us")))
+    print("  concurrent", d.get("concurrent_pairs", {}).get("value"), "cpu", d.get("cpu_baseline", {}).get("value"))
+    for k, c in (d.get("configs") or {}).items():
+        print("   %-24s %.1f it/s, %.5f ms/step, kernel %.2f us, valu frac %s" % (k, c["value"], c["ms_per_step"], c["roofline"]["kernel_us_avg"], (c.get("roofline_valu_issue") or {}).get("frac")))
