@@ -335,10 +335,13 @@ static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
                            const dcreg_lin_params *p, dcreg_lin_debug *dbg_host, bool gated = false) {
     if (!c) return DCREG_E_INVALID;
+    // nothing may be queued behind a gate that still waits: it would wait with it
+    if (c->gate_slot >= 0) { c->fail("a gated linearisation still waits for its pose (dcreg_linearize_gate_open / _gate_abort first)"); return DCREG_E_STATE; }
     if (gated) {
         static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
         R9 = eye; t3 = zero; n_poses = 1; state_ids = nullptr; dbg_host = nullptr;
-        if (c->gate_slot >= 0) { c->fail("a gated linearisation already waits for its pose"); return DCREG_E_STATE; }
+        // results must arrive through the pinned flags: a stream synchronise would wait for the gate, i.e. for its own caller
+        if (!c->opt_spin) { c->fail("gated launches need the \"spin\" option (results through pinned flags)"); return DCREG_E_STATE; }
     }
     if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
     LinSlot &S = c->slots[slot];

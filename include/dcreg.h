@@ -150,7 +150,8 @@ int dcreg_linearize_batch_begin(dcreg_ctx *, int slot, int n_poses, const double
  * whose pose is not known yet - a one-wave gate kernel in front of it waits for it - typically while the previous linearisation
  * still runs; _gate_open publishes the pose (two stores, the device starts at once: no launch on the critical path); _gate_abort
  * calls the queued linearisation off (it returns without touching results or warm state).  Exactly one of the two must follow every
- * _gated_begin; results come through dcreg_linearize_batch_end(slot).  At most one gated launch waits at a time.  A gate nobody
+ * _gated_begin, before anything else is queued on the context (other launches are refused meanwhile); results come through
+ * dcreg_linearize_batch_end(slot).  Needs the default "spin" option (a stream synchronise would wait for the gate).  A gate nobody
  * opens gives up after ~5 s. */
 int dcreg_linearize_gated_begin(dcreg_ctx *, int slot, const dcreg_lin_params *);
 int dcreg_linearize_gate_open(dcreg_ctx *, const double R[9], const double t[3]);

@@ -607,6 +607,8 @@ def test_gated_launches_equal_blocking_ones(cyl):
             c.linearize_gated_begin(prm, slot=slot ^ 1)             # queued while linearisation k is in flight
             with pytest.raises(api.DcregError):
                 c.linearize_gated_begin(prm, slot=slot)             # only one gate at a time
+            with pytest.raises(api.DcregError):
+                c.linearize(poses[0][:3, :3], poses[0][:3, 3], prm) # nothing else may queue behind a waiting gate
         got.append(c.linearize_end(slot=slot))
         if not last:
             c.gate_open(poses[k + 1][:3, :3], poses[k + 1][:3, 3])
@@ -624,6 +626,21 @@ def test_gated_launches_equal_blocking_ones(cyl):
     c.linearize_gated_begin(prm, slot=1)
     c.close()                                                       # destroys the context with the gate still waiting
     ref.close()
+    # without the pinned-flag wait ("spin" 0) a stream synchronise would wait for the gate: the launch is refused and the engine
+    # falls back to blocking launches - same run, bit for bit
+    T0 = h.pose6d_matrix(0.3, -0.2, 0.1, h.deg2rad(2.0), h.deg2rad(-1.0), h.deg2rad(3.0))
+    cfg = api.default_config(search_radius=1.0, max_iterations=12)
+    runs = []
+    for spin in (1, 0):
+        e = api.Context(0)
+        e.set_option("spin", spin); e.set_target(tgt, 1.0); e.set_source(src)
+        if not spin:
+            with pytest.raises(api.DcregError):
+                e.linearize_gated_begin(prm, slot=1)
+        res, logs = e.icp_run(T0, "Ours", cfg)
+        runs.append((res.iterations, np.array(res.R[:]), np.array(res.t[:])))
+        e.close()
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
 
 
 def test_x_sub_cells_only_trim_the_candidate_runs(ctx, cyl):
