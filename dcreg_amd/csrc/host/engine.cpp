@@ -20,6 +20,8 @@
 
 namespace dcreg {
 bool invertSpd6(const double H[36], double inv[36]);
+bool analyzeStep(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res);   // solver.cpp
+void analyzeFinish(const double H[36], dcreg_analysis &res);
 }
 
 namespace {
@@ -35,16 +37,24 @@ inline dcreg_lin_params lin_params_of(const dcreg_config &cfg) {
 }
 
 // steps 6-9 of one iteration for one state; returns 0 continue, 1 converged, 2 abort (non-finite)
-struct StepOut { dcreg_analysis an; double dx[6]; double H[36]; };
-inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const dcreg_config &cfg, double R[9], double t[3], StepOut &so) {
+// defer = true: when nothing of the step depends on the full eigen-decomposition of H (a diagnostic of the log for "Ours"), it is
+// left to host_step_finish() - the caller lets the device start on the new pose in between
+struct StepOut { dcreg_analysis an; double dx[6]; double H[36]; bool evd_owed = false; };
+inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const dcreg_config &cfg, double R[9], double t[3], StepOut &so,
+                     bool defer = false) {
     dcreg_unpack_hessian(lo.H_upper, so.H);
-    dcreg_analyze_degeneracy(so.H, detection, handling, &cfg, &so.an);                 // :1922-1923
+    if (defer) so.evd_owed = dcreg::analyzeStep(so.H, detection, handling, cfg, so.an);
+    else dcreg_analyze_degeneracy(so.H, detection, handling, &cfg, &so.an);           // :1922-1923
     dcreg_solve_degenerate_system(so.H, lo.g, handling, &cfg, &so.an, so.dx);          // :1940
     for (double v : so.dx) if (!std::isfinite(v)) return 2;                            // :1942-1950
     dcreg::boxplus(R, t, so.dx, R, t);                                                 // :1953
     const double dr = std::sqrt(so.dx[0] * so.dx[0] + so.dx[1] * so.dx[1] + so.dx[2] * so.dx[2]);
     const double dt = std::sqrt(so.dx[3] * so.dx[3] + so.dx[4] * so.dx[4] + so.dx[5] * so.dx[5]);
     return (dr < cfg.CONVERGENCE_THRESH_ROT && dt < cfg.CONVERGENCE_THRESH_TRANS) ? 1 : 0;   // :1998
+}
+
+inline void host_step_finish(StepOut &so) {
+    if (so.evd_owed) { dcreg::analyzeFinish(so.H, so.an); so.evd_owed = false; }
 }
 
 // eigenvalue clamp of a symmetric 6x6 (:2020-2029): only when the smallest eigenvalue is <= 1e-12 (or `always`), to 1e-9
@@ -144,7 +154,7 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
             break;
         }
         StepOut so;
-        const int st = host_step(lo, detection, handling, *cfg, R, t, so);
+        const int st = host_step(lo, detection, handling, *cfg, R, t, so, piped);
         if (st == 2) { res->iterations = it; res->converged = 0; res->status = 2; break; }
         if (piped && st != 1 && it + 1 < cfg->max_iterations) {
             // the pose of the next linearisation exists: let the device go before the bookkeeping below
@@ -154,6 +164,7 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
             if (rc != DCREG_OK) return rc;
             slot ^= 1;
         }
+        host_step_finish(so);                                                 // the part of the analysis only the log reads
         std::memcpy(Hlast, so.H, sizeof(Hlast));
         if (log && it < log_capacity) {
             dcreg_iter_log &L = log[it];

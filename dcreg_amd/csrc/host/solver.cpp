@@ -101,18 +101,11 @@ static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis
     }
 }
 
-static void analyze(const Mat6 &H, int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res) {
+// full eigen-decomposition block of the analysis (dcreg.hpp:66-89): eigenvalues / eigenvectors / singular values / condition
+// numbers of H.  Only the FULL_EVD / SUB_CONDITION / FULL_SVD detections and the remapping / truncated-SVD handlings read them
+// back; for the others (Schur detection + PCG: "Ours") they are diagnostics of the iteration log.
+static bool fullEvdBlock(const Mat6 &H, dcreg_analysis &res) {
     const double nan = std::numeric_limits<double>::quiet_NaN();
-    std::memset(&res, 0, sizeof(res));
-    res.cond_schur_rot = res.cond_schur_trans = res.cond_diag_rot = res.cond_diag_trans = nan;
-    for (int i = 0; i < 3; ++i) {
-        res.lambda_schur_rot[i] = res.lambda_schur_trans[i] = res.lambda_sub_rot[i] = res.lambda_sub_trans[i] = nan;
-        res.rot_indices[i] = res.trans_indices[i] = i;
-    }
-    for (int i = 0; i < 6; ++i) res.P_preconditioner[i * 7] = 1.0;
-    for (int i = 0; i < 3; ++i) res.schur_V_rot[i * 4] = res.schur_V_trans[i * 4] = res.aligned_V_rot[i * 4] = res.aligned_V_trans[i * 4] = 1.0;
-
-    // dcreg.hpp:66-80
     Vec<6> ev; Mat6 V;
     const bool evdOk = symEig<6>(H, ev, V);
     if (evdOk) {
@@ -129,6 +122,30 @@ static void analyze(const Mat6 &H, int detection, int handling, const dcreg_conf
     std::sort(res.singular_values, res.singular_values + 6, [](double a, double b) { return a > b; });
     res.cond_full = res.singular_values[5] > 1e-12 ? res.singular_values[0] / res.singular_values[5]
                                                      : std::numeric_limits<double>::infinity();
+    return evdOk;
+}
+// can the step (mask, solve) of this detection / handling pair be taken before the full eigen-decomposition exists?
+static bool evdIsDiagnosticOnly(int detection, int handling) {
+    const bool det = detection == DCREG_NONE_DETE || detection == DCREG_SCHUR_CONDITION_NUMBER;
+    const bool hand = handling != DCREG_SOLUTION_REMAPPING && handling != DCREG_TRUNCATED_SVD;
+    return det && hand;
+}
+
+// defer_evd: leave the full eigen-decomposition block out when nothing of the step depends on it.  Returns true if it was left
+// out: analyzeFinish() then completes the record, bit for bit what the one-pass analysis writes.
+static bool analyze(const Mat6 &H, int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res, bool defer_evd = false) {
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    std::memset(&res, 0, sizeof(res));
+    res.cond_schur_rot = res.cond_schur_trans = res.cond_diag_rot = res.cond_diag_trans = nan;
+    for (int i = 0; i < 3; ++i) {
+        res.lambda_schur_rot[i] = res.lambda_schur_trans[i] = res.lambda_sub_rot[i] = res.lambda_sub_trans[i] = nan;
+        res.rot_indices[i] = res.trans_indices[i] = i;
+    }
+    for (int i = 0; i < 6; ++i) res.P_preconditioner[i * 7] = 1.0;
+    for (int i = 0; i < 3; ++i) res.schur_V_rot[i * 4] = res.schur_V_trans[i * 4] = res.aligned_V_rot[i * 4] = res.aligned_V_trans[i * 4] = 1.0;
+
+    const bool deferred = defer_evd && evdIsDiagnosticOnly(detection, handling);
+    const bool evdOk = deferred ? false : fullEvdBlock(H, res);      // dcreg.hpp:66-89
 
     if (detection == DCREG_SCHUR_CONDITION_NUMBER || handling == DCREG_PRECONDITIONED_CG || cfg.always_compute_schur)
         schurAnalysis(H, cfg, res);
@@ -173,6 +190,7 @@ static void analyze(const Mat6 &H, int detection, int handling, const dcreg_conf
         break;
     default: break;                        // NONE_DETE and everything else: not degenerate
     }
+    return deferred;
 }
 
 // preconditioned conjugate gradients on the 6x6 SPD system (dcreg.hpp:279-287 is a stub)
@@ -265,6 +283,12 @@ static Vec<6> solve(const Mat6 &H, const Vec<6> &g, int handling, const dcreg_co
 void analyzeDegeneracy(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res) {
     analyze(toMat6(H), detection, handling, cfg, res);
 }
+// the analysis in two parts, for a loop that wants the step out of the door first (engine.cpp): analyzeStep returns true if the
+// eigen-decomposition block is still owed, analyzeFinish pays it.  Together they write exactly what analyzeDegeneracy writes.
+bool analyzeStep(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res) {
+    return analyze(toMat6(H), detection, handling, cfg, res, true);
+}
+void analyzeFinish(const double H[36], dcreg_analysis &res) { fullEvdBlock(toMat6(H), res); }
 void solveDegenerateSystem(const double H[36], const double g[6], int handling, const dcreg_config &cfg,
                            dcreg_analysis &an, double x[6]) {
     Vec<6> gv; std::memcpy(gv.data(), g, sizeof(double) * 6);
