@@ -585,6 +585,37 @@ def test_empty_space_skip_is_exact(ctx):
     assert np.array_equal(got[0][1][0], got[1][1][0])
 
 
+def test_far_from_the_origin_and_very_dense_cells(ctx):
+    """Coordinates ~1e5 m from the origin (float spacing 8 mm: heavy quantisation, exact ties, cell arithmetic in double) and a cloud
+    whose 60 k points sit in a 2 cm cube (runs of tens of thousands of points per cell): exact k-NN and a linearisation vs the oracle."""
+    rng = np.random.default_rng(21)
+    base = h.scene_corridor(20000, seed=3)[:, :3]
+    far = (base.astype(np.float64) + np.array([1.0e5, -2.0e5, 3.0e4])).astype(np.float32)
+    q = np.concatenate([far[::7] + rng.normal(0, 0.05, far[::7].shape).astype(np.float32), far[:200]]).astype(np.float32)
+    tree = po.KdTree(far)
+    oi, od = tree.knn(q, k=5)
+    ctx.set_target(far, 1.0)
+    gi, gd = ctx.knn(q, k=5, max_radius=0.0)
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    src = far[::3]
+    ctx.set_source(src)
+    T = h.pose6d_matrix(0.02, -0.01, 0.01, h.deg2rad(1e-5), 0.0, h.deg2rad(-1e-5))      # tiny: the lever arm is 2e5 m
+    gpu = ctx.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(1.0, 1), debug=True)
+    ref = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(1.0, 1), debug=True)
+    assert gpu["n_eff"] == ref["n_eff"] and gpu["n_pt"] == ref["n_pt"] and np.array_equal(gpu["flag"], ref["flag"])
+    ok = ref["flag"] != 0
+    assert np.array_equal(gpu["nn_idx"][ok], ref["nn_idx"][ok])
+    dense = (rng.uniform(0, 0.02, (60000, 3)) + np.array([5.0, 5.0, 5.0])).astype(np.float32)
+    qd = np.concatenate([dense[::300] + 0.001, rng.uniform(4.5, 5.5, (300, 3)), [[5.0, 5.0, 5.0]]]).astype(np.float32)
+    oi, od = po.KdTree(dense).knn(qd, k=5)
+    ctx.set_target(dense, 1.0)
+    gi, gd = ctx.knn(qd, k=5, max_radius=0.0)
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    bi, bd = ctx.knn(qd, k=5, max_radius=0.3)
+    inside = od < np.float32(0.09)
+    assert np.array_equal(bi[inside], oi[inside])
+
+
 def test_gated_launches_equal_blocking_ones(cyl):
     """dcreg_linearize_gated_begin / _gate_open / _gate_abort (the launch pipeline of dcreg_icp_run): a linearisation queued behind
     the gate before its pose exists gives bitwise the result of the blocking call; a launch that is called off leaves results and

@@ -154,3 +154,27 @@ def test_ring_walk_cost_counters():
     S2 = emul.Source(src)
     out2 = emul.linearize(emul.Index(tgt, 1.0, gap_field=False), S2, T[:3, :3], T[:3, 3], wd=1, warm=False)
     assert out2["n_eff"] == out["n_eff"] and np.array_equal(out2["H_upper"], out["H_upper"]) and np.array_equal(out2["g"], out["g"])
+
+
+def test_far_from_the_origin_and_very_dense_cells():
+    """Coordinates ~1e5 m from the origin (float spacing 8 mm: heavy quantisation, many exact ties, cell arithmetic in double) and a
+    cloud whose 60 k points sit in a 2 cm cube (a few cells hold tens of thousands of points: runs far longer than any trimmed
+    x-interval): exact k-NN against the oracle, bounded and unbounded."""
+    rng = np.random.default_rng(21)
+    base = h.scene_corridor(20000, seed=3)[:, :3] if hasattr(h, "scene_corridor") else rng.uniform(0, 30, (20000, 3)).astype(np.float32)
+    far = (base.astype(np.float64) + np.array([1.0e5, -2.0e5, 3.0e4])).astype(np.float32)
+    q = np.concatenate([far[::7] + rng.normal(0, 0.05, far[::7].shape).astype(np.float32), far[:200]]).astype(np.float32)
+    oi, od = po.KdTree(far).knn(q, k=5)
+    for sx in (1, 8):
+        idx = emul.Index(far, 1.0, x_subdiv=sx)
+        gi, gd = emul.knn(idx, q, k=5)
+        assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    dense = (rng.uniform(0, 0.02, (60000, 3)) + np.array([5.0, 5.0, 5.0])).astype(np.float32)
+    qd = np.concatenate([dense[::300] + 0.001, rng.uniform(4.5, 5.5, (300, 3)), [[5.0, 5.0, 5.0]]]).astype(np.float32)
+    oi, od = po.KdTree(dense).knn(qd, k=5)
+    idx = emul.Index(dense, 1.0)
+    gi, gd = emul.knn(idx, qd, k=5)
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    bi, bd = emul.knn(idx, qd, k=5, max_radius=0.3)
+    inside = od < np.float32(0.09)
+    assert np.array_equal(bi[inside], oi[inside])
