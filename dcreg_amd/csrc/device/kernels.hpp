@@ -212,6 +212,8 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
         const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
         const bool whole = (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
         if ((seq >> 1) == want && whole) break;
+        // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this gate ever ran
+        if ((seq >> 1) > want && whole) { seq = (want << 1) | 1ull; break; }
         if (wall_clock64() - t0 > 500000000ull) { seq = (want << 1) | 1ull; break; }     // ~5 s at 100 MHz: nobody opens - give up
         __builtin_amdgcn_s_sleep(2);
     }

@@ -654,6 +654,15 @@ def test_gated_launches_equal_blocking_ones(cyl):
     c.gate_abort()                                                  # idempotent
     again = c.linearize(poses[-1][:3, :3], poses[-1][:3, 3], prm)
     assert again["n_eff"] == want[-1]["n_eff"] and np.array_equal(again["H_upper"], want[-1]["H_upper"])
+    # called off, and the next gated launch published at once: the first gate may only start after the record already carries the
+    # later number - it must read that as its own abort, not wait for a number that will never come
+    for _ in range(20):
+        c.linearize_gated_begin(prm, slot=1)
+        c.gate_abort()
+        c.linearize_gated_begin(prm, slot=1)
+        c.gate_open(poses[-1][:3, :3], poses[-1][:3, 3])
+        out = c.linearize_end(slot=1)
+        assert out["n_eff"] == want[-1]["n_eff"] and np.array_equal(out["H_upper"], want[-1]["H_upper"])
     c.linearize_gated_begin(prm, slot=1)
     c.close()                                                       # destroys the context with the gate still waiting
     ref.close()
