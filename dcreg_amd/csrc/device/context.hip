@@ -231,7 +231,7 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) { c->n_tgt = 0; return rc; }
     rc = build_gap_field(c, radius_hint);
     if (rc) { c->n_tgt = 0; return rc; }
-    c->prev_valid = false;   // positions refer to the old sort order
+    c->prev_valid = false;   // positions and distances refer to the old target
     c->n_warm_states = 0;
     return DCREG_OK;
 }
@@ -248,6 +248,11 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) return rc;
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
     const double inv_q = 2097151.0 / ext * 0.999999;
+    {   // farthest corner of the bounding box: no point is farther from the body-frame origin
+        double r2 = 0.0;
+        for (int k = 0; k < 3; ++k) { const double m = std::max(std::fabs(mn[k]), std::fabs(mx[k])); r2 += m * m; }
+        c->src_radius = std::sqrt(r2);
+    }
     if (ensure(c, c->d_mkeys, c->mkeys_cap, (size_t)n) || ensure(c, c->d_mkeys2, c->mkeys2_cap, (size_t)n) ||
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
         ensure(c, c->d_src, c->src_cap, (size_t)n))
@@ -316,18 +321,49 @@ static void free_tmp(LinSlot &S) {
     S.tmp_dev.clear();
 }
 
-// publish a gate record (kernels.hpp GateHost): pose words and checksum first, the number last
-static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double *R, const double *t) {
-    unsigned long long w[14];
+// pose change since the launch that last wrote the ctx's own warm state: dR, dt for the kernel, and whether no source point can
+// have moved farther than the small-move threshold (|dR|_F * largest |p| + |dt| bounds every point's move); then that launch's
+// pose becomes this one
+static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[9], float dt[3]) {
+    WarmPose &w = c->prev_pose;
+    double fro = 0.0, tr = 0.0;
+    for (int k = 0; k < 9; ++k) { const double d = w.valid ? R[k] - w.R[k] : 0.0; dR[k] = (float)d; fro += d * d; }
+    for (int k = 0; k < 3; ++k) { const double d = w.valid ? t[k] - w.t[k] : 0.0; dt[k] = (float)d; tr += d * d; }
+    const double max_move = std::sqrt(fro) * c->src_radius + std::sqrt(tr);
+    const bool small = w.valid && c->opt_small_move > 0.0 && max_move <= c->opt_small_move * c->grid.h;
+    std::memcpy(w.R, R, sizeof(w.R)); std::memcpy(w.t, t, sizeof(w.t));
+    w.valid = true;
+    c->last_move_small = small;
+    return small;
+}
+// after a launch that may not have run: the recorded pose no longer describes what the states hold
+static void drop_warm(dcreg_ctx *c) { c->prev_valid = false; c->prev_pose.valid = false; c->last_move_small = false; c->n_warm_states = 0; }
+// fresh warm-start states: no positions, infinite distances
+static int clear_states(dcreg_ctx *c, uint32_t *d, size_t stride, size_t n_states) {
+    HIP_TRY(c, hipMemsetAsync(d, 0xFF, sizeof(uint32_t) * 6 * stride * n_states, c->stream));
+    for (size_t k = 0; k < n_states; ++k)
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(d + (k * 6 + 5) * stride), 0x7F800000, stride, c->stream));
+    return DCREG_OK;
+}
+
+// publish a gate record (kernels.hpp GateHost): pose words and checksum first, the number last.  R == null: an abort, the pose words
+// stay whatever they were.
+static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double *R, const double *t, const float *dR, const float *dt) {
+    unsigned long long w[kGateWords];
     w[0] = seq_word;
-    for (int k = 0; k < 12; ++k) w[1 + k] = c->h_gate->w[1 + k];            // abort: the pose words stay whatever they were
-    if (R) std::memcpy(&w[1], R, 9 * sizeof(double));
-    if (t) std::memcpy(&w[10], t, 3 * sizeof(double));
+    for (int k = 1; k < kGateWords - 1; ++k) w[k] = c->h_gate->w[k];
+    if (R) {
+        std::memcpy(&w[1], R, 9 * sizeof(double));
+        std::memcpy(&w[10], t, 3 * sizeof(double));
+        float f[12];
+        std::memcpy(f, dR, 9 * sizeof(float)); std::memcpy(f + 9, dt, 3 * sizeof(float));
+        std::memcpy(&w[13], f, sizeof(f));
+    }
     unsigned long long x = kGateSalt;
-    for (int k = 0; k < 13; ++k) x ^= w[k];
-    w[13] = x;
+    for (int k = 0; k < kGateWords - 1; ++k) x ^= w[k];
+    w[kGateWords - 1] = x;
     volatile unsigned long long *dst = c->h_gate->w;
-    for (int k = 1; k < 14; ++k) dst[k] = w[k];
+    for (int k = 1; k < kGateWords; ++k) dst[k] = w[k];
     __atomic_store_n(&c->h_gate->w[0], w[0], __ATOMIC_RELEASE);
 }
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
@@ -382,17 +418,24 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
     PoseArg one{};
     const PoseArg *d_poses = nullptr;
+    bool small = false;                 // the small-move form of the warm bound (single-pose launches on the ctx's own state only)
     if (n_poses == 1 && !state_ids) {
         std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
         one.state = 0;
         if (c->opt_warm) {      // single pose: the ctx's own state
             if (!c->prev_valid) {
                 const size_t stride = ((size_t)n + 63) & ~(size_t)63;
-                if (ensure(c, c->d_prev, c->prev_cap, 5 * stride)) return DCREG_E_NOMEM;
-                HIP_TRY(c, hipMemsetAsync(c->d_prev, 0xFF, sizeof(uint32_t) * 5 * stride, c->stream));
+                if (ensure(c, c->d_prev, c->prev_cap, 6 * stride)) return DCREG_E_NOMEM;
+                rc = clear_states(c, c->d_prev, stride, 1);
+                if (rc) return rc;
                 c->prev_stride = stride; c->prev_valid = true;
+                c->prev_pose.valid = false; c->last_move_small = false;
             }
             a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
+            // which warm bound: a launch with a known pose decides on that pose; a gated one (its pose comes later, and with it
+            // dR / dt through the gate) on what the last launch saw - a wrong guess only costs time (search.hpp lin_search)
+            if (gated) small = c->last_move_small;
+            else small = pose_delta(c, one.R, one.t, one.dR, one.dt);
         }
         if (gated) {
             if (!c->h_gate) {
@@ -423,6 +466,8 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t));
             S.h_poses[i].state = (use_states && state_ids[i] >= 0) ? (uint32_t)state_ids[i] : kNoIdx;
             S.h_poses[i].pad_ = 0;
+            for (float &v : S.h_poses[i].dR) v = 0.f;
+            for (float &v : S.h_poses[i].dt) v = 0.f;
         }
         HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
         d_poses = S.d_poses;
@@ -447,7 +492,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
         if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 16 * ((n + 63) / 64 + 4), 0);
-        if (oom) { free_tmp(S); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
+        if (oom) { free_tmp(S); drop_warm(c); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
     FinArgs fin{S.d_tickets, S.d_out, seq};
@@ -465,29 +510,31 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (timed) {                           // after the gate: the events bracket k_linearize, not the wait for the pose
         const hipError_t ee = hipEventRecord(c->ev0, c->stream);
         if (ee != hipSuccess) {
-            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);
+            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);
+            drop_warm(c);
             c->fail("hipEventRecord failed: %s", hipGetErrorString(ee));
             return DCREG_E_DEVICE;
         }
     }
-#define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                            \
-    hipLaunchKernelGGL((k_linearize<MODE, FUSED, FAST>), grid, dim3(kBlock), lds, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, \
+#define DCREG_LAUNCH_LIN(MODE, FUSED, FAST, SMALL)                                                                                     \
+    hipLaunchKernelGGL((k_linearize<MODE, FUSED, FAST, SMALL>), grid, dim3(kBlock), lds, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, \
                        S.d_partials, nbx, fin, dd, abort_flag)
     if (c->opt_fast_plane) {
-        if (dbg_host) DCREG_LAUNCH_LIN(1, true, true);
-        else if (fused) DCREG_LAUNCH_LIN(0, true, true);
-        else DCREG_LAUNCH_LIN(0, false, true);
+        if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, true, true); else DCREG_LAUNCH_LIN(1, true, true, false); }
+        else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, true, true); else DCREG_LAUNCH_LIN(0, true, true, false); }
+        else DCREG_LAUNCH_LIN(0, false, true, false);
     } else {
-        if (dbg_host) DCREG_LAUNCH_LIN(1, true, false);
-        else if (fused) DCREG_LAUNCH_LIN(0, true, false);
-        else DCREG_LAUNCH_LIN(0, false, false);
+        if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, false, true); else DCREG_LAUNCH_LIN(1, true, false, false); }
+        else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, false, true); else DCREG_LAUNCH_LIN(0, true, false, false); }
+        else DCREG_LAUNCH_LIN(0, false, false, false);
     }
 #undef DCREG_LAUNCH_LIN
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             free_tmp(S);
-            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);   // the gate in the queue must not wait
+            drop_warm(c);
+            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);   // the gate in the queue must not wait
             c->fail("k_linearize launch failed: %s", hipGetErrorString(le));
             return DCREG_E_DEVICE;
         }
@@ -495,7 +542,8 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (timed) {                           // brackets k_linearize alone
         const hipError_t ee = hipEventRecord(c->ev1, c->stream);
         if (ee != hipSuccess) {
-            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);
+            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);
+            drop_warm(c);
             c->fail("hipEventRecord failed: %s", hipGetErrorString(ee));
             return DCREG_E_DEVICE;
         }
@@ -503,7 +551,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (!fused || dbg_host) {
         if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
         const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { free_tmp(S); c->fail("k_finalize launch failed: %s", hipGetErrorString(le)); return DCREG_E_DEVICE; }
+        if (le != hipSuccess) { free_tmp(S); drop_warm(c); c->fail("k_finalize launch failed: %s", hipGetErrorString(le)); return DCREG_E_DEVICE; }
     }
     if (dbg_host) {
         hipError_t ce = hipSuccess;
@@ -519,6 +567,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (ce != hipSuccess) {
             (void)hipStreamSynchronize(c->stream);
             free_tmp(S);
+            drop_warm(c);
             c->fail("copying the debug dump back failed: %s", hipGetErrorString(ce));
             return DCREG_E_DEVICE;
         }
@@ -710,6 +759,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     const std::string k(key);
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
+    else if (k == "small_move") c->opt_small_move = v >= 0.0 ? v : 0.0;
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
@@ -757,8 +807,8 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
     if (n_states == 0 || c->n_src <= 0) return DCREG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t stride = ((size_t)c->n_src + 63) & ~(size_t)63;
-    if (ensure(c, c->d_prev_batch, c->prev_batch_cap, 5 * stride * (size_t)n_states)) return DCREG_E_NOMEM;
-    HIP_TRY(c, hipMemsetAsync(c->d_prev_batch, 0xFF, sizeof(uint32_t) * 5 * stride * (size_t)n_states, c->stream));
+    if (ensure(c, c->d_prev_batch, c->prev_batch_cap, 6 * stride * (size_t)n_states)) return DCREG_E_NOMEM;
+    { const int rc = clear_states(c, c->d_prev_batch, stride, (size_t)n_states); if (rc) return rc; }
     c->prev_batch_stride = stride;
     c->n_warm_states = n_states;
     return DCREG_OK;
@@ -770,14 +820,17 @@ int dcreg_linearize_gated_begin(dcreg_ctx *c, int slot, const dcreg_lin_params *
 int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
-    gate_publish(c, c->gate_seq << 1, R, t);
+    float dR[9], dt[3];
+    if (c->opt_warm && c->prev_valid) (void)pose_delta(c, R, t, dR, dt);          // the queued launch reads and writes the ctx's own state
+    else { for (float &v : dR) v = 0.f; for (float &v : dt) v = 0.f; }
+    gate_publish(c, c->gate_seq << 1, R, t, dR, dt);
     c->gate_slot = -1;
     return DCREG_OK;
 }
 int dcreg_linearize_gate_abort(dcreg_ctx *c) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0) return DCREG_OK;                                  // nothing queued
-    gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr);
+    gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);
     LinSlot &S = c->slots[c->gate_slot];
     S.pending = false;                 // no result will come; tickets_dirty stays set, so the next launch of the slot clears them
     free_tmp(S);

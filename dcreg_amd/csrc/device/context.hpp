@@ -14,6 +14,9 @@ struct dcreg_lin_out;
 struct dcreg_lin_debug;
 
 // buffers and in-flight state of one linearisation slot
+// pose of the launch that last wrote a warm-start state (valid = false: the state is fresh)
+struct WarmPose { double R[9]; double t[3]; bool valid = false; };
+
 struct LinSlot {
     double *d_partials = nullptr; size_t partials_cap = 0;
     dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
@@ -57,11 +60,17 @@ struct dcreg_ctx {
     int64_t n_src = 0;
     float4 *d_src_raw = nullptr; size_t src_raw_cap = 0;
     float4 *d_src = nullptr; size_t src_cap = 0;           // Hilbert-sorted
-    // warm start: sorted-target positions of every source point's last exact neighbour set, [5][prev_stride]
+    // warm start: [6][prev_stride] - rows 0-4 the sorted-target positions of every source point's neighbour set as of its last
+    // gathering launch, row 5 the squared distance to the 5th neighbour found by its last launch (float bits) - and the pose of that
+    // last launch (LinArgs::prev, search.hpp lin_search)
     uint32_t *d_prev = nullptr; size_t prev_cap = 0;
     size_t prev_stride = 0;
     bool prev_valid = false;       // false -> cleared to "none" before the next single-pose linearisation
-    // batched launches: n_warm_states states of the same layout, [state][5][prev_batch_stride] (dcreg_reserve_warm_states)
+    WarmPose prev_pose;            // pose of the launch that last wrote the ctx's own state
+    bool last_move_small = false;  // was the last single-pose launch a small move?  (what a gated launch, queued before its pose
+                                   // exists, assumes about itself)
+    double src_radius = 0.0;       // largest distance of a source point from the body-frame origin (bounds a pose change's effect)
+    // batched launches: n_warm_states states of the same layout, [state][6][prev_batch_stride] (dcreg_reserve_warm_states)
     uint32_t *d_prev_batch = nullptr; size_t prev_batch_cap = 0;
     size_t prev_batch_stride = 0;
     int64_t n_warm_states = 0;
@@ -98,6 +107,8 @@ struct dcreg_ctx {
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
     int opt_x_subdiv = 8;          // x sub-cells per grid cell (1, 2, 4, 8, 16)
+    double opt_small_move = 0.05;  // fraction of a cell edge: a pose change that moves no source point farther takes the small-move
+                                   // warm bound (0 = never)
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
     uint64_t launch_counter = 0;
     bool opt_spin = true;          // wait for results by spinning on pinned memory instead of hipStreamSynchronize

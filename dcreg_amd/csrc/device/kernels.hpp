@@ -186,12 +186,13 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // memory; when the host publishes the pose there, the gate copies it into the device-resident PoseArg the linearisation reads,
 // and retires.  The host can also call the launch off (abort bit): the linearisation behind the gate then returns at once.
 // A gate that waits longer than ~5 s aborts by itself (wall clock, 100 MHz), so a vanished host cannot leave the queue spinning.
-// The gate record: 16 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
-// patterns), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The gate reads all 16 words with ONE load per lane and accepts them only
-// if the number is the awaited one AND the checksum holds: the loads of one poll may be served in any order relative to the host's
-// stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip between "pose published" and "pose on
-// the device", whatever the read granularity of the link.
-struct alignas(128) GateHost { unsigned long long w[16]; };
+// The gate record: 20 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
+// patterns), w[13..18] = dR, dt (12 floats, PoseArg), w[19] = kGateSalt ^ w[0] ^ ... ^ w[18].  The gate reads all words with ONE load
+// per lane and accepts them only if the number is the awaited one AND the checksum holds: the loads of one poll may be served in
+// any order relative to the host's stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip
+// between "pose published" and "pose on the device", whatever the read granularity of the link.
+constexpr int kGateWords = 20;
+struct alignas(128) GateHost { unsigned long long w[32]; };
 constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
 static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
                                                    uint32_t *__restrict__ abort_flag) {
@@ -199,11 +200,11 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
     const unsigned long long t0 = wall_clock64();
     unsigned long long v = 0, seq = 0;
     for (;;) {
-        v = lane < 16 ? __hip_atomic_load(&hg->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-        // x = xor of words 0..12 and of word 13 (lanes >= 14 contribute 0): zero ^ salt when the record is whole
-        unsigned long long x = lane < 14 ? v : 0ull;
+        v = lane < kGateWords ? __hip_atomic_load(&hg->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        // x = xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
+        unsigned long long x = v;
 #pragma unroll
-        for (int m = 1; m < 16; m <<= 1) {
+        for (int m = 1; m < 32; m <<= 1) {
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
             x ^= ((unsigned long long)hi << 32) | lo;
         }
@@ -221,10 +222,15 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
         const double d = __longlong_as_double((long long)v);
         if (lane <= 9) dst->R[lane - 1] = d; else dst->t[lane - 10] = d;
     }
+    if (lane >= 13 && lane <= 18) {                      // two floats per word: dR[0..8], dt[0..2]
+        float *f = &dst->dR[0];                          // dR and dt are adjacent in PoseArg
+        const int k = 2 * (lane - 13);
+        f[k] = __uint_as_float((uint32_t)v); f[k + 1] = __uint_as_float((uint32_t)(v >> 32));
+    }
     if (lane == 0) { dst->state = 0; dst->pad_ = 0; *abort_flag = (uint32_t)(seq & 1ull); }
 }
 
-template <int MODE, bool FUSED, bool FAST>
+template <int MODE, bool FUSED, bool FAST, bool SMALL>
 static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                        PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                        double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg,
@@ -256,9 +262,9 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
     unsigned long long sst[7] = {0, 0, 0, 0, 0, 0, 0};   // search sub-phase stamps; [3..6] ring-walk cycle / count sums (search.hpp)
     if (MODE == 1) clk[1] = clock64();
     // batched launches: every pose owns a warm-start state of its own, selected by the pose's state slot
-    uint32_t *prev = a.prev ? a.prev + (size_t)P.state * 5u * a.prev_stride : nullptr;
+    uint32_t *prev = a.prev ? a.prev + (size_t)P.state * 6u * a.prev_stride : nullptr;
     if (poses && P.state == kNoIdx) prev = nullptr;
-    lin_search(g, runs[wave], P, a, prev, have_q, s4, i, q, nn, MODE == 1 ? sst : nullptr);
+    lin_search<SMALL>(g, runs[wave], P, a, prev, have_q, s4, i, q, nn, MODE == 1 ? sst : nullptr);
     if (MODE == 1) clk[2] = clock64();
 
     // ---- plane fit, gates, row (search.hpp)

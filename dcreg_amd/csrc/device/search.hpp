@@ -15,6 +15,7 @@
 // Arithmetic: k-NN distances float32, non-fused, summed x,y,z in that order (what FLANN's L2 functor does
 // and what the oracle does); everything after the neighbour set is fp64, like the reference.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #if defined(DCREG_HOST_EMUL)
 #include "host_emul_shim.hpp"
@@ -60,9 +61,13 @@ struct GridDev {
 
 struct PoseArg {
     double R[9]; double t[3];
+    float dR[9]; float dt[3];   // this pose minus the pose of the launch that last wrote its warm-start state (zeros for a fresh state):
+                                // |dR p + dt| bounds how far source point p has moved since (small-move launches, lin_search)
     uint32_t state;      // batched launches: which warm-start state this pose reads and updates (kNoIdx = search cold); single pose: 0
     uint32_t pad_;
 };
+
+static_assert(offsetof(PoseArg, dt) == offsetof(PoseArg, dR) + 9 * sizeof(float), "dR and dt are read as 12 consecutive floats");
 
 struct LinArgs {
     double radius_sq;             // R^2 in double (gate :1726)
@@ -70,8 +75,9 @@ struct LinArgs {
     double max_thick_sq, min_norm, w_slope, w_min;
     int use_wd;
     int max_ring;                 // rings needed to cover the radius
-    uint32_t *prev;               // [5][prev_stride] sorted-target positions of each query's last neighbour set, or null
-    uint32_t prev_stride;
+    uint32_t *prev;               // [state][6][prev_stride]: rows 0-4 = sorted-target positions of a query's neighbour set as of its last
+    uint32_t prev_stride;         //   gathering launch (kNoIdx = none), row 5 = bits of the squared distance to the 5th neighbour found by
+                                  //   its last launch of either kind (+inf = none); or null
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
@@ -988,46 +994,71 @@ DCREG_DEVFN void plane_fit_qr_fast(const double (&qx)[5], const double (&qy)[5],
 
 // ---------------------------------------------------------------- one source point: search, then row
 // Steps 1-2 of an iteration for one query (icp_test_runner.cpp:1716-1726): pose transform (double -> float store), warm
-// bound from the previous neighbour set, exact 5-NN.  `i` = position of the query in the sorted source (index into the
-// warm-start state), `prev` = base of this pose's state ([5][prev_stride]) or null.
+// bound, exact 5-NN.  `i` = position of the query in the sorted source (index into the warm-start state), `prev` = base of
+// this pose's state ([6][prev_stride]) or null.
 struct PointQuery {
     float qx, qy, qz;     // transformed query, float (utils.hpp:630-636)
     bool reach;           // the query is close enough to the grid for a neighbour inside the radius to exist
 };
 
+// SMALL = false: the warm bound is the largest distance from the new query position to the 5 points its last gathering launch
+//   found (any pose): 5 position loads, 5 point gathers (issued ahead of the pose transform and the cell-table loads), tight
+//   whatever the motion.
+// SMALL = true (the host launches this form when the pose has all but stopped moving - every iteration of a converged
+//   trajectory): the last launch found the 5 neighbours within sqrt(d2_old); the query has moved by |dR p + dt| since, so they lie
+//   within sqrt(d2_old) + |move| of it now (triangle inequality).  One float of state instead of ten dependent loads and five
+//   distances - two memory latencies off the front of every wave - and as tight as the gather when the move is tiny.  Valid for
+//   ANY move (only looser), so a wrong guess of the host costs time, never a neighbour.
+template <bool SMALL>
 DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, const LinArgs &a, uint32_t *prev, bool have_q,
                             const float4 &s4, uint32_t i, PointQuery &q, KnnResult<5> &nn, unsigned long long *sst = nullptr) {
-    // warm start: the K-th neighbour distance is at most the largest distance to ANY K distinct target points, so
-    // the neighbour set of the previous linearisation (any pose) bounds this search; the result is the same exact
-    // set, found after visiting only the cells that ball touches.  The position loads and the point gathers are
-    // issued here, ahead of the pose transform and the cell-table loads, so their latency overlaps with those.
-    uint32_t pp[5];
-    float4 pv[5];
+    // warm start: the K-th neighbour distance is at most the largest distance to ANY K distinct target points, so what an earlier
+    // search of this query (same source point, same target) found bounds this search; the result is the same exact set, found
+    // after visiting only the cells that ball touches.
+    const bool warm_any = prev && have_q;
+    float bound = a.radius_sq_f;
+    if (SMALL) {
+        const float w_old = warm_any ? __uint_as_float(prev[(size_t)5 * a.prev_stride + i]) : __builtin_inff();
+        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
+        const float mx = P.dR[0] * s4.x + P.dR[1] * s4.y + P.dR[2] * s4.z + P.dt[0];
+        const float my = P.dR[3] * s4.x + P.dR[4] * s4.y + P.dR[5] * s4.z + P.dt[1];
+        const float mz = P.dR[6] * s4.x + P.dR[7] * s4.y + P.dR[8] * s4.z + P.dt[2];
+        // conservative: 1e-5 relative on both lengths (the float chains round at ~1e-7), the float store of the two query
+        // positions (half an ulp per coordinate each), and a floor that keeps the bound a normal float
+        const float move = sqrt_approx(mx * mx + my * my + mz * mz) * 1.00001f + 4e-7f * (fabsf(q.qx) + fabsf(q.qy) + fabsf(q.qz)) + 1e-15f;
+        const float b = sqrt_approx(w_old) * 1.00001f + move;          // +inf stays +inf
+        bound = fminf(bound, b * b * 1.00001f);
+    } else {
+        uint32_t pp[5];
+        float4 pv[5];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) pp[j] = (prev && have_q) ? prev[(size_t)j * a.prev_stride + i] : kNoIdx;
-    const bool warm = pp[4] != kNoIdx;
+        for (int j = 0; j < 5; ++j) pp[j] = warm_any ? prev[(size_t)j * a.prev_stride + i] : kNoIdx;
+        const bool warm = pp[4] != kNoIdx;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) pv[j] = warm ? g.pts[pp[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
+        for (int j = 0; j < 5; ++j) pv[j] = warm ? g.pts[pp[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
+        if (warm) {
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) m = fmaxf(m, dist2_nofma(q.qx, q.qy, q.qz, pv[j]));
+            // inclusive bound for a strict '<' heap: next float above m (m >= 0, finite)
+            const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
+            bound = fminf(bound, incl);
+        }
+    }
     const double fx = ((double)q.qx - g.ox) * g.inv_h, fy = ((double)q.qy - g.oy) * g.inv_h, fz = ((double)q.qz - g.oz) * g.inv_h;
     const double lim = (double)a.max_ring + 1.0;
     // a query farther than max_ring cells from the grid has no neighbour inside the radius
     q.reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
     nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
-    float bound = a.radius_sq_f;
-    if (warm) {
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) m = fmaxf(m, dist2_nofma(q.qx, q.qy, q.qz, pv[j]));
-        // inclusive bound for a strict '<' heap: next float above m (m >= 0, finite)
-        const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
-        bound = fminf(bound, incl);
-    }
     if (q.reach) knn_exact<5>(g, runs, q.qx, q.qy, q.qz, bound, a.max_ring, nn, sst);
-    if (prev && have_q) {
+    if (warm_any) {
         const bool keep = q.reach && nn.full;
+        if (!SMALL) {       // (a small-move launch leaves the positions of the last gathering launch: older, still valid)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) prev[(size_t)j * a.prev_stride + i] = keep ? nn.pos[j] : kNoIdx;
+            for (int j = 0; j < 5; ++j) prev[(size_t)j * a.prev_stride + i] = keep ? nn.pos[j] : kNoIdx;
+        }
+        prev[(size_t)5 * a.prev_stride + i] = keep ? __float_as_uint(nn.d2[4]) : 0x7F800000u;
     }
 }
 

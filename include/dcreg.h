@@ -125,7 +125,10 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  * dcreg_set_target, default; results are identical either way), "fast_plane_fit" (1 = the reduced-instruction plane fit,
  * default; 0 = the Eigen-shaped factorisation step for step; planes agree to a few ulp), "xcd_chunk" (query-block -> XCD
  * mapping: 0 = one contiguous run per XCD, c = runs of c blocks round-robin), "x_subdiv" (1 / 2 / 4 / 8 / 16 = x sub-cells per grid cell
- * at the next dcreg_set_target, default 8: candidate runs are trimmed to the sub-cell; results are identical either way);
+ * at the next dcreg_set_target, default 8: candidate runs are trimmed to the sub-cell; results are identical either way),
+ * "small_move" (fraction of a cell edge, default 0.05, 0 = never: a single-pose launch whose pose change moves no source point
+ * farther than that bounds each search by the old 5th-neighbour distance plus the point's move instead of gathering the old
+ * neighbours; results are identical either way);
  * experiment knobs: "lds_pad" (extra dynamic LDS
  * bytes per block), "keep_source_order" (1 = the next dcreg_set_source keeps the caller's point order instead of the
  * Hilbert sort) */

@@ -41,7 +41,7 @@ def lib():
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
-                                    C.c_void_p, C.c_int64] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64]
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_double] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64]
         L.emu_plane_fit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         _lib = L
@@ -103,21 +103,25 @@ class Source:
         self.sorted = np.ascontiguousarray(xyz[self.order])
         self.n = len(xyz)
         self.stride = (self.n + 63) & ~63
-        self.prev = None
+        self.reset_warm()
 
     def reset_warm(self):
-        self.prev = None
+        """state = neighbour positions (last gathering launch) + squared 5th-neighbour distance, pose and index of the last launch"""
+        self.prev, self.prev_pose, self.prev_index = None, None, None
 
 
-def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0):
+def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0, small_move=0.05):
     """One linearisation through the device functions on the host -> dict like Context.linearize (+ "stats" [n, 8] in
     processing order: candidates, outermost shell, table loads, rows, runs, trips, faces, face skips)."""
     radius = index.radius if radius is None else radius
     prm = LinParams(radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, int(wd), int(fast))
     n = source.n
-    if warm and source.prev is None:
-        source.prev = np.full(5 * source.stride, 0xFFFFFFFF, np.uint32)
+    if warm and (source.prev is None or source.prev_index is not index):      # a new target voids the stored distances
+        st = np.full((6, source.stride), 0xFFFFFFFF, np.uint32)
+        st[5] = 0x7F800000
+        source.prev, source.prev_pose, source.prev_index = st.reshape(-1), None, index
     prev = source.prev if warm else None
+    prev_pose = source.prev_pose if warm else None
     out = np.zeros(32)
     keep = {}
     if debug:
@@ -127,9 +131,11 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
     tr = np.zeros((n, trace_cap), np.uint32) if trace_cap else None
     R = np.ascontiguousarray(R, np.float64).reshape(9)
     t = np.ascontiguousarray(t, np.float64).reshape(3)
-    lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(prev), source.stride,
+    lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(prev), source.stride, _ptr(prev_pose), float(small_move),
                         _ptr(out), _ptr(keep.get("nn_idx")), _ptr(keep.get("nn_d2")), _ptr(keep.get("flag")), _ptr(keep.get("normal")),
                         _ptr(keep.get("r")), _ptr(keep.get("s")), _ptr(st), _ptr(tr), int(trace_cap))
+    if warm:
+        source.prev_pose = np.concatenate([R, t])
     res = {"H_upper": out[:21].copy(), "g": out[21:27].copy(), "sum_r2": out[27], "sum_b2": out[28], "n_eff": int(round(out[29])),
            "n_pt": int(round(out[30]))}
     res.update(keep)

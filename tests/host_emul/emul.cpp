@@ -185,11 +185,11 @@ struct EmuLinParams {
 };
 
 // One linearisation of `n` queries (src_xyz in the order given; order[i] = original index written into the per-point
-// outputs, or null for identity).  prev: [5][prev_stride] warm-start state, read and updated (null = cold).
+// outputs, or null for identity).  prev: [6][prev_stride] warm-start state, read and updated (null = cold).
 // out32: 21 H + 6 g + sum r^2 + sum b^2 + n_eff + n_pt.  Per-point outputs may be null.  stats: [n][8] counters
 // {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}.
 int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_t n, const double R[9], const double t[3],
-                  const EmuLinParams *p, uint32_t *prev, int64_t prev_stride, double *out32, int32_t *nn_idx, float *nn_d2,
+                  const EmuLinParams *p, uint32_t *prev, int64_t prev_stride, const double *prev_pose12, double small_move_frac, double *out32, int32_t *nn_idx, float *nn_d2,
                   uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats, uint32_t *trace, int64_t trace_cap_per_query) {
     EmuIndex *E = (EmuIndex *)idx;
     const GridDev &g = E->g;
@@ -206,6 +206,16 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     a.prev = prev; a.prev_stride = (uint32_t)prev_stride; a.euler = 0;
     PoseArg P{};
     std::memcpy(P.R, R, sizeof(P.R)); std::memcpy(P.t, t, sizeof(P.t));
+    bool small = false;
+    {   // prev_pose12 = R (9) and t (3) of the launch that last wrote the state, or null for a fresh state (context.hip pose_delta)
+        double fro = 0.0, tr = 0.0, mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (int k = 0; k < 9; ++k) { const double d = prev_pose12 ? R[k] - prev_pose12[k] : 0.0; P.dR[k] = (float)d; fro += d * d; }
+        for (int k = 0; k < 3; ++k) { const double d = prev_pose12 ? t[k] - prev_pose12[9 + k] : 0.0; P.dt[k] = (float)d; tr += d * d; }
+        for (int64_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], (double)src_xyz[3 * i + c]); mx[c] = std::max(mx[c], (double)src_xyz[3 * i + c]); }
+        double r2 = 0.0;
+        for (int c = 0; c < 3; ++c) { const double m = std::max(std::fabs(mn[c]), std::fabs(mx[c])); r2 += m * m; }
+        small = prev && prev_pose12 && small_move_frac > 0.0 && std::sqrt(fro) * std::sqrt(r2) + std::sqrt(tr) <= small_move_frac * g.h;
+    }
     static thread_local RunList runs;
     double tot[31];
     for (double &v : tot) v = 0.0;
@@ -217,7 +227,8 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         KnnResult<5> nn;
         emu_stats = EmuStats{};
         if (trace) { emu_trace.buf = trace + (size_t)i * (size_t)trace_cap_per_query; emu_trace.cap = (uint32_t)trace_cap_per_query - 1; emu_trace.n = 0; }
-        lin_search(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
+        if (small) lin_search<true>(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
+        else lin_search<false>(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
         if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
         double row[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
         const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, row, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, row, nrm, rr, ss);

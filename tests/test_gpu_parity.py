@@ -585,6 +585,35 @@ def test_empty_space_skip_is_exact(ctx):
     assert np.array_equal(got[0][1][0], got[1][1][0])
 
 
+def test_both_warm_bounds_give_the_same_runs(cyl):
+    """"small_move" picks, per launch, how the warm bound is obtained (gather of the old neighbours / old 5th-neighbour distance plus
+    the point's move).  Both are exact for any motion: runs with the small-move form never taken, taken by the default rule and
+    ALWAYS taken (also across big jumps, where it is merely loose) are bitwise the same, blocking and pipelined."""
+    tgt = cyl[0]
+    src = tgt[::2]
+    T0 = h.pose6d_matrix(0.3, -0.2, 0.1, h.deg2rad(2.0), h.deg2rad(-1.0), h.deg2rad(3.0))
+    cfg = api.default_config(search_radius=1.0, max_iterations=25, CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0)
+    prm = api.default_lin_params(1.0, 1)
+    walk = [T0, T0 @ h.pose6d_matrix(1e-5, 0.0, 2e-5, 1e-7, 0.0, -1e-7), T0 @ h.pose6d_matrix(0.5, 0.5, -0.2, 0.0, h.deg2rad(4.0), 0.0), T0,
+            T0 @ h.pose6d_matrix(300.0, 0.0, 0.0, 0.0, 0.0, 0.0), T0]
+    got = {}
+    for frac in (0.0, 0.05, 1e9):
+        c = api.Context(0)
+        c.set_option("small_move", frac); c.set_target(tgt, 1.0); c.set_source(src)
+        lin = [c.linearize(T[:3, :3], T[:3, 3], prm) for T in walk]
+        res, logs = c.icp_run(T0, "Ours", cfg)                      # pipelined engine, state carried over from the walk
+        res2, _ = c.icp_run(T0, "Ours", cfg)                        # and once more from the converged state
+        got[frac] = (lin, res.iterations, np.array(res.R[:]), np.array(res.t[:]), np.array(res2.R[:]), np.array(res2.t[:]),
+                     [np.array(L.H_upper[:]) for L in logs])
+        c.close()
+    for frac in (0.05, 1e9):
+        a, b = got[frac], got[0.0]
+        for x, y in zip(a[0], b[0]):
+            assert x["n_eff"] == y["n_eff"] and np.array_equal(x["H_upper"], y["H_upper"]) and np.array_equal(x["g"], y["g"])
+        assert a[1] == b[1] and all(np.array_equal(a[k], b[k]) for k in (2, 3, 4, 5))
+        assert all(np.array_equal(x, y) for x, y in zip(a[6], b[6]))
+
+
 def test_far_from_the_origin_and_very_dense_cells(ctx):
     """Coordinates ~1e5 m from the origin (float spacing 8 mm: heavy quantisation, exact ties, cell arithmetic in double) and a cloud
     whose 60 k points sit in a 2 cm cube (runs of tens of thousands of points per cell): exact k-NN and a linearisation vs the oracle."""

@@ -65,6 +65,18 @@ def test_synthetic_scenes_and_pose_sequences(name):
         ref = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(radius, k % 2), debug=True)
         e = emul.linearize(idx, S, T[:3, :3], T[:3, 3], radius=radius, wd=k % 2, fast=True, debug=True)
         assert_same(e, ref)
+    # the two ways to the warm bound (gather of the old neighbours / old 5th distance plus the point's move) are both exact for
+    # ANY motion: never, by the default threshold, and always taking the small-move bound give the same sums along a walk that
+    # mixes tiny steps, jumps and a trip far outside the grid
+    walk = [poses[1], poses[1] @ h.pose6d_matrix(1e-4, -2e-4, 1e-4, 1e-6, -2e-6, 1e-6), poses[1] @ h.pose6d_matrix(2e-3, 1e-3, -1e-3, 1e-5, 2e-5, -1e-5),
+            poses[2], poses[2] @ h.pose6d_matrix(0.02, 0.0, 0.01, 0.0, 1e-4, 0.0), poses[4], poses[3], poses[0], poses[0]]
+    runs = {}
+    for frac in (0.0, 0.05, 1e9):
+        Sw = emul.Source(src)
+        runs[frac] = [emul.linearize(idx, Sw, T[:3, :3], T[:3, 3], radius=radius, wd=1, small_move=frac) for T in walk]
+    for frac in (0.05, 1e9):
+        for x, y in zip(runs[frac], runs[0.0]):
+            assert x["n_eff"] == y["n_eff"] and np.array_equal(x["H_upper"], y["H_upper"]) and np.array_equal(x["g"], y["g"])
     # the warm bound and the empty-space field only prune: cold / no-field searches give bitwise the same sums
     T = poses[1]
     a = emul.linearize(idx, S, T[:3, :3], T[:3, 3], radius=radius, wd=1)
