@@ -324,8 +324,7 @@ static void free_tmp(LinSlot &S) {
 // pose change since the launch that last wrote the ctx's own warm state: dR, dt for the kernel, and whether no source point can
 // have moved farther than the small-move threshold (|dR|_F * largest |p| + |dt| bounds every point's move); then that launch's
 // pose becomes this one
-static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[9], float dt[3]) {
-    WarmPose &w = c->prev_pose;
+static bool pose_delta_of(const dcreg_ctx *c, WarmPose &w, const double *R, const double *t, float dR[9], float dt[3]) {
     double fro = 0.0, tr = 0.0;
     for (int k = 0; k < 9; ++k) { const double d = w.valid ? R[k] - w.R[k] : 0.0; dR[k] = (float)d; fro += d * d; }
     for (int k = 0; k < 3; ++k) { const double d = w.valid ? t[k] - w.t[k] : 0.0; dt[k] = (float)d; tr += d * d; }
@@ -333,16 +332,17 @@ static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[
     const bool small = w.valid && c->opt_small_move > 0.0 && max_move <= c->opt_small_move * c->grid.h;
     std::memcpy(w.R, R, sizeof(w.R)); std::memcpy(w.t, t, sizeof(w.t));
     w.valid = true;
-    c->last_move_small = small;
     return small;
+}
+static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[9], float dt[3]) {   // the ctx's own state
+    return c->last_move_small = pose_delta_of(c, c->prev_pose, R, t, dR, dt);
 }
 // after a launch that may not have run: the recorded pose no longer describes what the states hold
 static void drop_warm(dcreg_ctx *c) { c->prev_valid = false; c->prev_pose.valid = false; c->last_move_small = false; c->n_warm_states = 0; }
-// fresh warm-start states: no positions, infinite distances
+// fresh warm-start states, ONE fill for all of them: positions kNoIdx, distances the NaN 0xFFFFFFFF - the small-move bound of a NaN
+// is a NaN and fminf(radius^2, NaN) = radius^2, i.e. "none", like the +inf a search without a full neighbour set writes
 static int clear_states(dcreg_ctx *c, uint32_t *d, size_t stride, size_t n_states) {
     HIP_TRY(c, hipMemsetAsync(d, 0xFF, sizeof(uint32_t) * 6 * stride * n_states, c->stream));
-    for (size_t k = 0; k < n_states; ++k)
-        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(d + (k * 6 + 5) * stride), 0x7F800000, stride, c->stream));
     return DCREG_OK;
 }
 
@@ -462,13 +462,19 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         }
         if (ensure(c, S.d_poses, S.poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
         S.h_poses.resize((size_t)n_poses);      // stays alive until end(): source of the asynchronous copy
+        bool all_small = true;
         for (int i = 0; i < n_poses; ++i) {
             std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t));
             S.h_poses[i].state = (use_states && state_ids[i] >= 0) ? (uint32_t)state_ids[i] : kNoIdx;
             S.h_poses[i].pad_ = 0;
             for (float &v : S.h_poses[i].dR) v = 0.f;
             for (float &v : S.h_poses[i].dt) v = 0.f;
+            // the small-move form is one kernel for the whole batch: taken when EVERY pose that owns a state has all but stopped
+            if (S.h_poses[i].state != kNoIdx)
+                all_small = pose_delta_of(c, c->batch_pose[(size_t)state_ids[i]], S.h_poses[i].R, S.h_poses[i].t, S.h_poses[i].dR, S.h_poses[i].dt) && all_small;
+            else all_small = false;
         }
+        small = use_states && all_small;
         HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
         d_poses = S.d_poses;
         if (use_states) { a.prev = c->d_prev_batch; a.prev_stride = (uint32_t)c->prev_batch_stride; }
@@ -522,11 +528,11 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (c->opt_fast_plane) {
         if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, true, true); else DCREG_LAUNCH_LIN(1, true, true, false); }
         else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, true, true); else DCREG_LAUNCH_LIN(0, true, true, false); }
-        else DCREG_LAUNCH_LIN(0, false, true, false);
+        else { if (small) DCREG_LAUNCH_LIN(0, false, true, true); else DCREG_LAUNCH_LIN(0, false, true, false); }
     } else {
         if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, false, true); else DCREG_LAUNCH_LIN(1, true, false, false); }
         else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, false, true); else DCREG_LAUNCH_LIN(0, true, false, false); }
-        else DCREG_LAUNCH_LIN(0, false, false, false);
+        else { if (small) DCREG_LAUNCH_LIN(0, false, false, true); else DCREG_LAUNCH_LIN(0, false, false, false); }
     }
 #undef DCREG_LAUNCH_LIN
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
@@ -809,6 +815,7 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
     const size_t stride = ((size_t)c->n_src + 63) & ~(size_t)63;
     if (ensure(c, c->d_prev_batch, c->prev_batch_cap, 6 * stride * (size_t)n_states)) return DCREG_E_NOMEM;
     { const int rc = clear_states(c, c->d_prev_batch, stride, (size_t)n_states); if (rc) return rc; }
+    c->batch_pose.assign((size_t)n_states, WarmPose{});
     c->prev_batch_stride = stride;
     c->n_warm_states = n_states;
     return DCREG_OK;

@@ -73,6 +73,7 @@ struct dcreg_ctx {
     // batched launches: n_warm_states states of the same layout, [state][6][prev_batch_stride] (dcreg_reserve_warm_states)
     uint32_t *d_prev_batch = nullptr; size_t prev_batch_cap = 0;
     size_t prev_batch_stride = 0;
+    std::vector<WarmPose> batch_pose;   // per reserved state: pose of the launch that last wrote it
     int64_t n_warm_states = 0;
 
     // build scratch

@@ -77,7 +77,7 @@ struct LinArgs {
     int max_ring;                 // rings needed to cover the radius
     uint32_t *prev;               // [state][6][prev_stride]: rows 0-4 = sorted-target positions of a query's neighbour set as of its last
     uint32_t prev_stride;         //   gathering launch (kNoIdx = none), row 5 = bits of the squared distance to the 5th neighbour found by
-                                  //   its last launch of either kind (+inf = none); or null
+                                  //   its last launch of either kind (+inf, or the NaN 0xFFFFFFFF of a fresh state = none); or null
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
@@ -1026,7 +1026,7 @@ DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, c
         // conservative: 1e-5 relative on both lengths (the float chains round at ~1e-7), the float store of the two query
         // positions (half an ulp per coordinate each), and a floor that keeps the bound a normal float
         const float move = sqrt_approx(mx * mx + my * my + mz * mz) * 1.00001f + 4e-7f * (fabsf(q.qx) + fabsf(q.qy) + fabsf(q.qz)) + 1e-15f;
-        const float b = sqrt_approx(w_old) * 1.00001f + move;          // +inf stays +inf
+        const float b = sqrt_approx(w_old) * 1.00001f + move;          // +inf stays +inf, NaN (fresh state) stays NaN: no bound below
         bound = fminf(bound, b * b * 1.00001f);
     } else {
         uint32_t pp[5];

@@ -117,8 +117,7 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
     prm = LinParams(radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, int(wd), int(fast))
     n = source.n
     if warm and (source.prev is None or source.prev_index is not index):      # a new target voids the stored distances
-        st = np.full((6, source.stride), 0xFFFFFFFF, np.uint32)
-        st[5] = 0x7F800000
+        st = np.full((6, source.stride), 0xFFFFFFFF, np.uint32)      # as context.hip clear_states: row 5 starts as a NaN = "none"
         source.prev, source.prev_pose, source.prev_index = st.reshape(-1), None, index
     prev = source.prev if warm else None
     prev_pose = source.prev_pose if warm else None
