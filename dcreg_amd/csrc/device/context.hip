@@ -324,7 +324,8 @@ static void free_tmp(LinSlot &S) {
 // pose change since the launch that last wrote the ctx's own warm state: dR, dt for the kernel, and whether no source point can
 // have moved farther than the small-move threshold (|dR|_F * largest |p| + |dt| bounds every point's move); then that launch's
 // pose becomes this one
-static bool pose_delta_of(const dcreg_ctx *c, WarmPose &w, const double *R, const double *t, float dR[9], float dt[3]) {
+static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[9], float dt[3]) {
+    WarmPose &w = c->prev_pose;
     double fro = 0.0, tr = 0.0;
     for (int k = 0; k < 9; ++k) { const double d = w.valid ? R[k] - w.R[k] : 0.0; dR[k] = (float)d; fro += d * d; }
     for (int k = 0; k < 3; ++k) { const double d = w.valid ? t[k] - w.t[k] : 0.0; dt[k] = (float)d; tr += d * d; }
@@ -332,10 +333,8 @@ static bool pose_delta_of(const dcreg_ctx *c, WarmPose &w, const double *R, cons
     const bool small = w.valid && c->opt_small_move > 0.0 && max_move <= c->opt_small_move * c->grid.h;
     std::memcpy(w.R, R, sizeof(w.R)); std::memcpy(w.t, t, sizeof(w.t));
     w.valid = true;
+    c->last_move_small = small;
     return small;
-}
-static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[9], float dt[3]) {   // the ctx's own state
-    return c->last_move_small = pose_delta_of(c, c->prev_pose, R, t, dR, dt);
 }
 // after a launch that may not have run: the recorded pose no longer describes what the states hold
 static void drop_warm(dcreg_ctx *c) { c->prev_valid = false; c->prev_pose.valid = false; c->last_move_small = false; c->n_warm_states = 0; }
@@ -415,6 +414,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     }
     const int64_t n = c->n_src;
     a.prev = nullptr; a.prev_stride = 0;
+    a.delta = PoseDelta{}; a.delta_dev = nullptr;
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
     PoseArg one{};
     const PoseArg *d_poses = nullptr;
@@ -435,7 +435,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             // which warm bound: a launch with a known pose decides on that pose; a gated one (its pose comes later, and with it
             // dR / dt through the gate) on what the last launch saw - a wrong guess only costs time (search.hpp lin_search)
             if (gated) small = c->last_move_small;
-            else small = pose_delta(c, one.R, one.t, one.dR, one.dt);
+            else small = pose_delta(c, one.R, one.t, a.delta.dR, a.delta.dt);
         }
         if (gated) {
             if (!c->h_gate) {
@@ -443,9 +443,11 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
                 std::memset(c->h_gate, 0, sizeof(GateHost));
                 HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_gate_host, c->h_gate, 0));
                 HIP_TRY(c, hipMalloc((void **)&c->d_gate_pose, sizeof(PoseArg)));
+                HIP_TRY(c, hipMalloc((void **)&c->d_gate_delta, sizeof(PoseDelta)));
                 HIP_TRY(c, hipMalloc((void **)&c->d_gate_abort, sizeof(uint32_t)));
             }
             d_poses = c->d_gate_pose;
+            a.delta_dev = c->d_gate_delta;
         }
     } else {
         // batched poses: each may own one of the reserved warm-start states (dcreg_reserve_warm_states); -1 = search cold
@@ -461,21 +463,19 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             }
         }
         if (ensure(c, S.d_poses, S.poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
-        S.h_poses.resize((size_t)n_poses);      // stays alive until end(): source of the asynchronous copy
-        bool all_small = true;
+        if ((size_t)n_poses > S.h_poses_cap) {      // stays alive until end(): source of the asynchronous copy
+            if (S.h_poses) (void)hipHostFree(S.h_poses);
+            S.h_poses = nullptr; S.h_poses_cap = 0;
+            const size_t cap = std::max<size_t>((size_t)n_poses, 256);
+            HIP_TRY(c, hipHostMalloc((void **)&S.h_poses, cap * sizeof(PoseArg), hipHostMallocDefault));
+            S.h_poses_cap = cap;
+        }
         for (int i = 0; i < n_poses; ++i) {
             std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t));
             S.h_poses[i].state = (use_states && state_ids[i] >= 0) ? (uint32_t)state_ids[i] : kNoIdx;
             S.h_poses[i].pad_ = 0;
-            for (float &v : S.h_poses[i].dR) v = 0.f;
-            for (float &v : S.h_poses[i].dt) v = 0.f;
-            // the small-move form is one kernel for the whole batch: taken when EVERY pose that owns a state has all but stopped
-            if (S.h_poses[i].state != kNoIdx)
-                all_small = pose_delta_of(c, c->batch_pose[(size_t)state_ids[i]], S.h_poses[i].R, S.h_poses[i].t, S.h_poses[i].dR, S.h_poses[i].dt) && all_small;
-            else all_small = false;
         }
-        small = use_states && all_small;
-        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses.data(), sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
         d_poses = S.d_poses;
         if (use_states) { a.prev = c->d_prev_batch; a.prev_stride = (uint32_t)c->prev_batch_stride; }
     }
@@ -510,7 +510,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const uint32_t *abort_flag = nullptr;
     if (gated) {
         const unsigned long long want = ++c->gate_seq;
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, c->d_gate_abort);
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, c->d_gate_delta, c->d_gate_abort);
         abort_flag = c->d_gate_abort;
     }
     if (timed) {                           // after the gate: the events bracket k_linearize, not the wait for the pose
@@ -528,11 +528,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (c->opt_fast_plane) {
         if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, true, true); else DCREG_LAUNCH_LIN(1, true, true, false); }
         else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, true, true); else DCREG_LAUNCH_LIN(0, true, true, false); }
-        else { if (small) DCREG_LAUNCH_LIN(0, false, true, true); else DCREG_LAUNCH_LIN(0, false, true, false); }
+        else DCREG_LAUNCH_LIN(0, false, true, false);     // batched launches always gather (measured: the small-move form buys
+                                                          // nothing on the sparse fixture and its per-pose bookkeeping costs host time)
     } else {
         if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, false, true); else DCREG_LAUNCH_LIN(1, true, false, false); }
         else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, false, true); else DCREG_LAUNCH_LIN(0, true, false, false); }
-        else { if (small) DCREG_LAUNCH_LIN(0, false, false, true); else DCREG_LAUNCH_LIN(0, false, false, false); }
+        else DCREG_LAUNCH_LIN(0, false, false, false);
     }
 #undef DCREG_LAUNCH_LIN
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
@@ -736,6 +737,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->h_gate) (void)hipHostFree(c->h_gate);
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
+    if (c->d_gate_delta) (void)hipFree(c->d_gate_delta);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
@@ -745,6 +747,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
         for (void *b : S.tmp_dev) (void)hipFree(b);
         if (S.h_out) (void)hipHostFree(S.h_out);
+        if (S.h_poses) (void)hipHostFree(S.h_poses);
     }
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -815,7 +818,6 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
     const size_t stride = ((size_t)c->n_src + 63) & ~(size_t)63;
     if (ensure(c, c->d_prev_batch, c->prev_batch_cap, 6 * stride * (size_t)n_states)) return DCREG_E_NOMEM;
     { const int rc = clear_states(c, c->d_prev_batch, stride, (size_t)n_states); if (rc) return rc; }
-    c->batch_pose.assign((size_t)n_states, WarmPose{});
     c->prev_batch_stride = stride;
     c->n_warm_states = n_states;
     return DCREG_OK;

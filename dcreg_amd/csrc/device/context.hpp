@@ -20,7 +20,9 @@ struct WarmPose { double R[9]; double t[3]; bool valid = false; };
 struct LinSlot {
     double *d_partials = nullptr; size_t partials_cap = 0;
     dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
-    std::vector<dcreg::PoseArg> h_poses;
+    dcreg::PoseArg *h_poses = nullptr; size_t h_poses_cap = 0;     // PINNED staging of the batched poses: the H2D copy is a plain DMA
+                                                                   // (a pageable source is staged by the runtime; beyond 16 KB that
+                                                                   // cost 14 us per launch)
     double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped result rows
     unsigned int *d_tickets = nullptr; size_t tickets_cap = 0;
     bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
@@ -73,7 +75,6 @@ struct dcreg_ctx {
     // batched launches: n_warm_states states of the same layout, [state][6][prev_batch_stride] (dcreg_reserve_warm_states)
     uint32_t *d_prev_batch = nullptr; size_t prev_batch_cap = 0;
     size_t prev_batch_stride = 0;
-    std::vector<WarmPose> batch_pose;   // per reserved state: pose of the launch that last wrote it
     int64_t n_warm_states = 0;
 
     // build scratch
@@ -88,6 +89,7 @@ struct dcreg_ctx {
     // gate of pipelined launches (kernels.hpp k_gate): pinned sequence number + pose, the device-resident pose it fills, abort word
     dcreg::GateHost *h_gate = nullptr, *d_gate_host = nullptr;
     dcreg::PoseArg *d_gate_pose = nullptr;
+    dcreg::PoseDelta *d_gate_delta = nullptr;
     uint32_t *d_gate_abort = nullptr;
     unsigned long long gate_seq = 0;       // number of the gated launch last queued
     int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)

@@ -187,7 +187,7 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // and retires.  The host can also call the launch off (abort bit): the linearisation behind the gate then returns at once.
 // A gate that waits longer than ~5 s aborts by itself (wall clock, 100 MHz), so a vanished host cannot leave the queue spinning.
 // The gate record: 20 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
-// patterns), w[13..18] = dR, dt (12 floats, PoseArg), w[19] = kGateSalt ^ w[0] ^ ... ^ w[18].  The gate reads all words with ONE load
+// patterns), w[13..18] = dR, dt (12 floats, PoseDelta), w[19] = kGateSalt ^ w[0] ^ ... ^ w[18].  The gate reads all words with ONE load
 // per lane and accepts them only if the number is the awaited one AND the checksum holds: the loads of one poll may be served in
 // any order relative to the host's stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip
 // between "pose published" and "pose on the device", whatever the read granularity of the link.
@@ -195,7 +195,7 @@ constexpr int kGateWords = 20;
 struct alignas(128) GateHost { unsigned long long w[32]; };
 constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
 static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
-                                                   uint32_t *__restrict__ abort_flag) {
+                                                   PoseDelta *__restrict__ ddst, uint32_t *__restrict__ abort_flag) {
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
     unsigned long long v = 0, seq = 0;
@@ -223,7 +223,7 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
         if (lane <= 9) dst->R[lane - 1] = d; else dst->t[lane - 10] = d;
     }
     if (lane >= 13 && lane <= 18) {                      // two floats per word: dR[0..8], dt[0..2]
-        float *f = &dst->dR[0];                          // dR and dt are adjacent in PoseArg
+        float *f = &ddst->dR[0];                         // dR and dt are adjacent in PoseDelta
         const int k = 2 * (lane - 13);
         f[k] = __uint_as_float((uint32_t)v); f[k + 1] = __uint_as_float((uint32_t)(v >> 32));
     }

@@ -61,13 +61,15 @@ struct GridDev {
 
 struct PoseArg {
     double R[9]; double t[3];
-    float dR[9]; float dt[3];   // this pose minus the pose of the launch that last wrote its warm-start state (zeros for a fresh state):
-                                // |dR p + dt| bounds how far source point p has moved since (small-move launches, lin_search)
     uint32_t state;      // batched launches: which warm-start state this pose reads and updates (kNoIdx = search cold); single pose: 0
     uint32_t pad_;
 };
+// the pose of a single-pose launch minus the pose of the launch that last wrote the warm-start state (zeros for a fresh state):
+// |dR p + dt| bounds how far source point p has moved since (small-move launches, lin_search).  Kept out of PoseArg: the batched
+// launches copy an array of PoseArg to the device per launch, and that copy is on the device's critical path.
+struct PoseDelta { float dR[9]; float dt[3]; };
 
-static_assert(offsetof(PoseArg, dt) == offsetof(PoseArg, dR) + 9 * sizeof(float), "dR and dt are read as 12 consecutive floats");
+static_assert(offsetof(PoseDelta, dt) == offsetof(PoseDelta, dR) + 9 * sizeof(float), "dR and dt are read as 12 consecutive floats");
 
 struct LinArgs {
     double radius_sq;             // R^2 in double (gate :1726)
@@ -75,6 +77,8 @@ struct LinArgs {
     double max_thick_sq, min_norm, w_slope, w_min;
     int use_wd;
     int max_ring;                 // rings needed to cover the radius
+    PoseDelta delta;              // small-move launches with a pose known at launch time
+    const PoseDelta *delta_dev;   // ... or, for a launch queued behind the gate, where the gate puts it (null: use `delta`)
     uint32_t *prev;               // [state][6][prev_stride]: rows 0-4 = sorted-target positions of a query's neighbour set as of its last
     uint32_t prev_stride;         //   gathering launch (kNoIdx = none), row 5 = bits of the squared distance to the 5th neighbour found by
                                   //   its last launch of either kind (+inf, or the NaN 0xFFFFFFFF of a fresh state = none); or null
@@ -1020,9 +1024,10 @@ DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, c
     if (SMALL) {
         const float w_old = warm_any ? __uint_as_float(prev[(size_t)5 * a.prev_stride + i]) : __builtin_inff();
         body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
-        const float mx = P.dR[0] * s4.x + P.dR[1] * s4.y + P.dR[2] * s4.z + P.dt[0];
-        const float my = P.dR[3] * s4.x + P.dR[4] * s4.y + P.dR[5] * s4.z + P.dt[1];
-        const float mz = P.dR[6] * s4.x + P.dR[7] * s4.y + P.dR[8] * s4.z + P.dt[2];
+        const PoseDelta &D = a.delta_dev ? *a.delta_dev : a.delta;
+        const float mx = D.dR[0] * s4.x + D.dR[1] * s4.y + D.dR[2] * s4.z + D.dt[0];
+        const float my = D.dR[3] * s4.x + D.dR[4] * s4.y + D.dR[5] * s4.z + D.dt[1];
+        const float mz = D.dR[6] * s4.x + D.dR[7] * s4.y + D.dR[8] * s4.z + D.dt[2];
         // conservative: 1e-5 relative on both lengths (the float chains round at ~1e-7), the float store of the two query
         // positions (half an ulp per coordinate each), and a floor that keeps the bound a normal float
         const float move = sqrt_approx(mx * mx + my * my + mz * mz) * 1.00001f + 4e-7f * (fabsf(q.qx) + fabsf(q.qy) + fabsf(q.qz)) + 1e-15f;

@@ -11,6 +11,8 @@ def one(pattern):
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()[:60]
 
+ALL_LIN = "dcreg::k_linearize (all instantiations)"
+
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
       "Command: `python bench.py --steps 50 --warmup 50 --repeats 4 --no-cpu-baseline --no-configs --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
@@ -30,6 +32,8 @@ if kt:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(kt)):
         agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if "k_linearize" in r["Kernel_Name"]:        # the launches of a run use several instantiations (warm-bound form): one row for all
+            agg[ALL_LIN].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     md += ["## Kernel trace (ns)", "", "| kernel | calls | avg | min | max | total |", "|---|---|---|---|---|---|"]
     ks = {}
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
@@ -51,6 +55,8 @@ def counters(sub):
     if f:
         for r in csv.DictReader(open(f)):
             res[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "k_linearize" in r["Kernel_Name"]:
+                res[ALL_LIN][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return res
 pm = {}
 for sub in ("fetch", "write", "sq1", "sq2", "tcc"):
@@ -65,7 +71,7 @@ if pm:
         md.append("**%s**" % k)
         md.append("")
         md += ["| counter | value |", "|---|---|"] + ["| %s | %.4g |" % (a, b) for a, b in sorted(v.items())] + [""]
-    lin = next((v for k, v in pm.items() if "k_linearize" in k), None)
+    lin = pm.get(ALL_LIN) or next((v for k, v in pm.items() if "k_linearize" in k), None)     # mean over ALL launches of the run
     if lin and "FETCH_SIZE" in lin:
         fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
         raw = (fetch_kb + write_kb) * 1024.0

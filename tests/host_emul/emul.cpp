@@ -209,8 +209,8 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     bool small = false;
     {   // prev_pose12 = R (9) and t (3) of the launch that last wrote the state, or null for a fresh state (context.hip pose_delta)
         double fro = 0.0, tr = 0.0, mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-        for (int k = 0; k < 9; ++k) { const double d = prev_pose12 ? R[k] - prev_pose12[k] : 0.0; P.dR[k] = (float)d; fro += d * d; }
-        for (int k = 0; k < 3; ++k) { const double d = prev_pose12 ? t[k] - prev_pose12[9 + k] : 0.0; P.dt[k] = (float)d; tr += d * d; }
+        for (int k = 0; k < 9; ++k) { const double d = prev_pose12 ? R[k] - prev_pose12[k] : 0.0; a.delta.dR[k] = (float)d; fro += d * d; }
+        for (int k = 0; k < 3; ++k) { const double d = prev_pose12 ? t[k] - prev_pose12[9 + k] : 0.0; a.delta.dt[k] = (float)d; tr += d * d; }
         for (int64_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], (double)src_xyz[3 * i + c]); mx[c] = std::max(mx[c], (double)src_xyz[3 * i + c]); }
         double r2 = 0.0;
         for (int c = 0; c < 3; ++c) { const double m = std::max(std::fabs(mn[c]), std::fabs(mx[c])); r2 += m * m; }
