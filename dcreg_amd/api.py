@@ -44,8 +44,12 @@ class LinOut(C.Structure):
 class LinDebug(C.Structure):
     _fields_ = [("nn_idx", C.POINTER(C.c_int32)), ("nn_d2", C.POINTER(C.c_float)),
                 ("flag", C.POINTER(C.c_uint8)), ("normal", C.POINTER(C.c_double)),
-                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double)), ("stats", C.POINTER(C.c_uint32)),
-                ("clocks", C.POINTER(C.c_uint64))]
+                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double)), ("stats", C.POINTER(C.c_uint32))]
+
+
+class LaunchStats(C.Structure):
+    _fields_ = [("poses_searched", C.c_int64), ("poses_certified", C.c_int64), ("last_queries_listed", C.c_int64),
+                ("last_blocks_listed", C.c_int64)]
 
 
 class IndexInfo(C.Structure):
@@ -105,16 +109,17 @@ class TrialResult(C.Structure):
 
 _STRUCTS = {"dcreg_lin_params": LinParams, "dcreg_lin_out": LinOut, "dcreg_lin_debug": LinDebug,
             "dcreg_index_info": IndexInfo, "dcreg_config": Config, "dcreg_analysis": Analysis,
-            "dcreg_iter_log": IterLog, "dcreg_icp_result": IcpResult, "dcreg_trial_result": TrialResult}
+            "dcreg_iter_log": IterLog, "dcreg_icp_result": IcpResult, "dcreg_trial_result": TrialResult,
+            "dcreg_launch_stats": LaunchStats}
 
-# every symbol include/dcreg.h declares
+# every symbol include/dcreg.h and include/dcreg_debug.h declare
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_void_p)      # dcreg_reduce_fn
 
 EXPORTS = [
     "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
-    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_linearize_debug", "dcreg_knn",
+    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
@@ -159,6 +164,8 @@ def load():
     L.dcreg_linearize_batch_begin_warm.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, C.POINTER(LinParams)]
     L.dcreg_linearize_batch_end.argtypes = [vp, C.c_int, C.POINTER(LinOut)]
     L.dcreg_reserve_warm_states.argtypes = [vp, C.c_int64]
+    L.dcreg_reset_warm_state.argtypes = [vp, C.c_int64]
+    L.dcreg_launch_stats_get.argtypes = [vp, C.POINTER(LaunchStats), C.c_int]
     L.dcreg_linearize_gated_begin.argtypes = [vp, C.c_int, C.POINTER(LinParams)]
     L.dcreg_linearize_gate_open.argtypes = [vp, dp, dp]
     L.dcreg_linearize_gate_abort.argtypes = [vp]
@@ -383,10 +390,10 @@ class Context:
         n = self.index_info().n_source
         keep = {"nn_idx": np.full((n, 5), -1, np.int32), "nn_d2": np.full((n, 5), np.inf, np.float32),
                 "flag": np.zeros(n, np.uint8), "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n),
-                "stats": np.zeros(n, np.uint32), "clocks": np.zeros(((n + 63) // 64 + 4, 16), np.uint64)}
+                "stats": np.zeros(n, np.uint32)}
         dbg = LinDebug(keep["nn_idx"].ctypes.data_as(C.POINTER(C.c_int32)), keep["nn_d2"].ctypes.data_as(C.POINTER(C.c_float)),
                        keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8)), _dp(keep["normal"]), _dp(keep["r"]), _dp(keep["s"]),
-                       keep["stats"].ctypes.data_as(C.POINTER(C.c_uint32)), keep["clocks"].ctypes.data_as(C.POINTER(C.c_uint64)))
+                       keep["stats"].ctypes.data_as(C.POINTER(C.c_uint32)))
         self._check(self._L.dcreg_linearize_debug(self._h, _dp(R), _dp(t), C.byref(params), C.byref(out), C.byref(dbg)), "dcreg_linearize_debug")
         d = self._out_dict(out)
         d.update(keep)
@@ -407,6 +414,15 @@ class Context:
 
     def reserve_warm_states(self, n_states):
         self._check(self._L.dcreg_reserve_warm_states(self._h, int(n_states)), "dcreg_reserve_warm_states")
+
+    def reset_warm_state(self, state_id):
+        self._check(self._L.dcreg_reset_warm_state(self._h, int(state_id)), "dcreg_reset_warm_state")
+
+    def launch_stats(self, reset=False):
+        """dcreg_launch_stats_get (dcreg_debug.h): how the linearisations since the last reset were carried out"""
+        st = LaunchStats()
+        self._check(self._L.dcreg_launch_stats_get(self._h, C.byref(st), int(reset)), "dcreg_launch_stats_get")
+        return {k: int(getattr(st, k)) for k, _ in LaunchStats._fields_}
 
     def linearize_batch_warm(self, Rs, ts, state_ids, params=None, slot=0):
         """dcreg_linearize_batch_begin_warm + _end: pose i reads and updates warm-start state state_ids[i] (-1 = cold)."""

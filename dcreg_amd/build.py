@@ -23,7 +23,7 @@ SOURCES = [
     "host/engine.cpp",
 ]
 HEADERS = ["device/kernels.hpp", "device/search.hpp", "device/context.hpp", "host/linalg.hpp", "host/se3.hpp",
-           "../../include/dcreg.h"]
+           "../../include/dcreg_debug.h", "../../include/dcreg.h"]
 
 
 def _hipcc():

@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
-#include "../../../include/dcreg.h"
+#include "../../../include/dcreg_debug.h"
 #include "context.hpp"
 #include "kernels.hpp"
 
@@ -42,6 +42,7 @@ static int ensure(dcreg_ctx *c, T *&ptr, size_t &cap, size_t need) {
 }
 
 static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+static void drop_warm(dcreg_ctx *c);
 
 // ------------------------------------------------------------------------------------------ index build
 static int sort_pairs_u32(dcreg_ctx *c, uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n, int bits) {
@@ -227,12 +228,13 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) return rc;
     c->n_tgt = n;
     c->radius_hint = radius_hint;
-    rc = build_index(c, target_dst(c), radius_hint, &c->occupied_cells);
+    // the cells are sized for the SEARCH radius (make_lin_args): one ring must cover it
+    rc = build_index(c, target_dst(c), radius_hint * (1.0 + c->opt_cert_margin), &c->occupied_cells);
     if (rc) { c->n_tgt = 0; return rc; }
-    rc = build_gap_field(c, radius_hint);
+    rc = build_gap_field(c, radius_hint * (1.0 + c->opt_cert_margin));
     if (rc) { c->n_tgt = 0; return rc; }
-    c->prev_valid = false;   // positions and distances refer to the old target
-    c->n_warm_states = 0;
+    drop_warm(c);            // positions and certificates refer to the old target
+    c->n_batch_states = 0;
     return DCREG_OK;
 }
 
@@ -269,8 +271,8 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
     c->aux_valid = false;
-    c->prev_valid = false;
-    c->n_warm_states = 0;
+    drop_warm(c);
+    c->n_batch_states = 0;
     return DCREG_OK;
 }
 
@@ -279,11 +281,18 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     if (!p || !(p->search_radius > 0.0)) { c->fail("invalid linearisation parameters"); return DCREG_E_INVALID; }
     if (p->k != 5 && p->k != 0) { c->fail("only k = 5 is supported (icp_test_runner.cpp:1722)"); return DCREG_E_INVALID; }
     a.radius_sq = p->search_radius * p->search_radius;
-    float rf = (float)a.radius_sq;
-    if ((double)rf < a.radius_sq) rf = std::nextafterf(rf, INFINITY);
-    a.radius_sq_f = std::nextafterf(rf, INFINITY);   // candidates with d2 < this may pass the double gate
+    {   // searches cover a little more than the gate radius (certificates of "5th neighbour beyond R" spend the difference)
+        const double rs = p->search_radius * (1.0 + c->opt_cert_margin), r2 = rs * rs;
+        float rf = (float)r2;
+        if ((double)rf < r2) rf = std::nextafterf(rf, INFINITY);
+        a.radius_sq_f = std::nextafterf(rf, INFINITY);   // candidates with d2 < this are kept
+        float ro = (float)(p->search_radius * (1.0 + 1e-5));
+        if ((double)ro < p->search_radius * (1.0 + 1e-5)) ro = std::nextafterf(ro, INFINITY);
+        a.cert_r_out = ro;
+    }
     a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm;
     a.w_slope = p->weight_slope; a.w_min = p->weight_min; a.use_wd = p->use_weight_derivative;
+    a.warm = c->opt_warm ? 1 : 0;
     int k = 1;
     while (k < 100000) {
         const double safe = (double)k * c->grid.h * (1.0 - 1e-9);
@@ -321,42 +330,35 @@ static void free_tmp(LinSlot &S) {
     S.tmp_dev.clear();
 }
 
-// pose change since the launch that last wrote the ctx's own warm state: dR, dt for the kernel, and whether no source point can
-// have moved farther than the small-move threshold (|dR|_F * largest |p| + |dt| bounds every point's move); then that launch's
-// pose becomes this one
-static bool pose_delta(dcreg_ctx *c, const double *R, const double *t, float dR[9], float dt[3]) {
+// bound on how far any source point has moved since the launch that last touched the ctx's own state (|dR|_F * largest |p| + |dt|);
+// then that launch's pose becomes this one
+static double pose_move(dcreg_ctx *c, const double *R, const double *t) {
     WarmPose &w = c->prev_pose;
     double fro = 0.0, tr = 0.0;
-    for (int k = 0; k < 9; ++k) { const double d = w.valid ? R[k] - w.R[k] : 0.0; dR[k] = (float)d; fro += d * d; }
-    for (int k = 0; k < 3; ++k) { const double d = w.valid ? t[k] - w.t[k] : 0.0; dt[k] = (float)d; tr += d * d; }
-    const double max_move = std::sqrt(fro) * c->src_radius + std::sqrt(tr);
-    const bool small = w.valid && c->opt_small_move > 0.0 && max_move <= c->opt_small_move * c->grid.h;
+    for (int k = 0; k < 9; ++k) { const double d = w.valid ? R[k] - w.R[k] : 0.0; fro += d * d; }
+    for (int k = 0; k < 3; ++k) { const double d = w.valid ? t[k] - w.t[k] : 0.0; tr += d * d; }
+    const double max_move = w.valid ? std::sqrt(fro) * c->src_radius + std::sqrt(tr) : 1e300;
     std::memcpy(w.R, R, sizeof(w.R)); std::memcpy(w.t, t, sizeof(w.t));
     w.valid = true;
-    c->last_move_small = small;
-    return small;
+    c->last_max_move = max_move;
+    return max_move;
 }
-// after a launch that may not have run: the recorded pose no longer describes what the states hold
-static void drop_warm(dcreg_ctx *c) { c->prev_valid = false; c->prev_pose.valid = false; c->last_move_small = false; c->n_warm_states = 0; }
-// fresh warm-start states, ONE fill for all of them: positions kNoIdx, distances the NaN 0xFFFFFFFF - the small-move bound of a NaN
-// is a NaN and fminf(radius^2, NaN) = radius^2, i.e. "none", like the +inf a search without a full neighbour set writes
-static int clear_states(dcreg_ctx *c, uint32_t *d, size_t stride, size_t n_states) {
-    HIP_TRY(c, hipMemsetAsync(d, 0xFF, sizeof(uint32_t) * 6 * stride * n_states, c->stream));
-    return DCREG_OK;
+// after a launch that may not have run: what the states hold is unknown
+static void drop_warm(dcreg_ctx *c) {
+    c->state_valid = false; c->prev_pose.valid = false; c->last_max_move = 1e300;
+    std::fill(c->batch_state_valid.begin(), c->batch_state_valid.end(), (uint8_t)0);
 }
+static bool certifies(const dcreg_ctx *c, double max_move) { return c->opt_cert_move > 0.0 && max_move <= c->opt_cert_move * c->grid.h; }
 
 // publish a gate record (kernels.hpp GateHost): pose words and checksum first, the number last.  R == null: an abort, the pose words
 // stay whatever they were.
-static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double *R, const double *t, const float *dR, const float *dt) {
+static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double *R, const double *t) {
     unsigned long long w[kGateWords];
     w[0] = seq_word;
     for (int k = 1; k < kGateWords - 1; ++k) w[k] = c->h_gate->w[k];
     if (R) {
         std::memcpy(&w[1], R, 9 * sizeof(double));
         std::memcpy(&w[10], t, 3 * sizeof(double));
-        float f[12];
-        std::memcpy(f, dR, 9 * sizeof(float)); std::memcpy(f + 9, dt, 3 * sizeof(float));
-        std::memcpy(&w[13], f, sizeof(f));
     }
     unsigned long long x = kGateSalt;
     for (int k = 0; k < kGateWords - 1; ++k) x ^= w[k];
@@ -365,6 +367,34 @@ static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double
     for (int k = 1; k < kGateWords; ++k) dst[k] = w[k];
     __atomic_store_n(&c->h_gate->w[0], w[0], __ATOMIC_RELEASE);
 }
+static void gate_call_off(dcreg_ctx *c) { gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr); }
+
+// work lists of certifying launches: room for every query / block of the launch on any one of the lists' shares
+static int ensure_lists(dcreg_ctx *c, uint32_t nbx, int n_poses, ListArgs &wl) {
+    if (!c->d_list_count) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_list_count, sizeof(uint32_t) * 2 * 2 * kWorkLists));
+        HIP_TRY(c, hipMemsetAsync(c->d_list_count, 0, sizeof(uint32_t) * 2 * 2 * kWorkLists, c->stream));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_list_counts, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        c->h_list_counts[0] = c->h_list_counts[1] = 0;
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_list_counts_host, c->h_list_counts, 0));
+    }
+    const size_t b_cap = ((size_t)nbx + kWorkLists - 1) / kWorkLists * (size_t)n_poses, q_cap = b_cap * kBlock;
+    if (b_cap >= ((size_t)1 << 31) / kBlock) { c->fail("too many queries in one launch for the work lists"); return DCREG_E_INVALID; }
+    if (ensure(c, c->d_q_entries, c->q_entries_cap, q_cap * kWorkLists) || ensure(c, c->d_b_entries, c->b_entries_cap, b_cap * kWorkLists)) return DCREG_E_NOMEM;
+    wl.count = c->d_list_count; wl.q_entries = c->d_q_entries; wl.b_entries = c->d_b_entries;
+    wl.q_cap = (uint32_t)q_cap; wl.b_cap = (uint32_t)b_cap;
+    wl.host_counts = c->d_list_counts_host;
+    return DCREG_OK;
+}
+// grid of a list kernel: persistent blocks, sized by what the last certifying launch had on its lists (the loops inside take whatever
+// there is); a multiple of the number of lists
+static unsigned list_grid(size_t hint_items, size_t max_items, size_t per_block) {
+    const size_t want = std::min(max_items, std::max<size_t>(2 * hint_items, 64 * per_block));
+    size_t blocks = (want + per_block - 1) / per_block;
+    blocks = std::min<size_t>(std::max<size_t>(blocks, kWorkLists), 8192);
+    return (unsigned)((blocks + kWorkLists - 1) / kWorkLists * kWorkLists);
+}
+
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
 // _gate_abort decide its fate)
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
@@ -391,7 +421,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
     const uint32_t nbx = blocks_for(c->n_src, kBlock);
     if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
-    // one pose: the kernel finishes the reduction itself (chunk rows -> pinned memory); many poses: k_finalize
+    // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
     const bool fused = (n_poses == 1);
     const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
     const size_t n_rows = fused ? (size_t)n_chunks : (size_t)n_poses;      // result rows the host waits for
@@ -413,71 +443,104 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         S.out_cap = cap;
     }
     const int64_t n = c->n_src;
-    a.prev = nullptr; a.prev_stride = 0;
-    a.delta = PoseDelta{}; a.delta_dev = nullptr;
+    a.state = nullptr; a.state_stride = 0;
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
     PoseArg one{};
+    one.state = kNoIdx; one.fresh = 1;
     const PoseArg *d_poses = nullptr;
-    bool small = false;                 // the small-move form of the warm bound (single-pose launches on the ctx's own state only)
+    // The launch plan.  n_cert poses are linearised by charging certificates (k_rows, then the two list kernels), n_full by
+    // searching everything (k_full); d_ids_* = which poses, for batched launches that mix both.
+    int n_cert = 0, n_full = n_poses;
+    const uint32_t *d_ids_cert = nullptr, *d_ids_full = nullptr;
+    bool uses_state = false;
+    const bool state_was_valid = c->state_valid;
     if (n_poses == 1 && !state_ids) {
         std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
-        one.state = 0;
         if (c->opt_warm) {      // single pose: the ctx's own state
-            if (!c->prev_valid) {
-                const size_t stride = ((size_t)n + 63) & ~(size_t)63;
-                if (ensure(c, c->d_prev, c->prev_cap, 6 * stride)) return DCREG_E_NOMEM;
-                rc = clear_states(c, c->d_prev, stride, 1);
-                if (rc) return rc;
-                c->prev_stride = stride; c->prev_valid = true;
-                c->prev_pose.valid = false; c->last_move_small = false;
+            const size_t stride = ((size_t)n + 63) & ~(size_t)63;
+            if (!c->state_valid || c->state_stride != stride) {
+                if (ensure(c, c->d_state, c->state_cap, kStateRows * stride)) return DCREG_E_NOMEM;
+                c->state_stride = stride; c->state_valid = false;
+                c->prev_pose.valid = false; c->last_max_move = 1e300;
             }
-            a.prev = c->d_prev; a.prev_stride = (uint32_t)c->prev_stride;
-            // which warm bound: a launch with a known pose decides on that pose; a gated one (its pose comes later, and with it
-            // dR / dt through the gate) on what the last launch saw - a wrong guess only costs time (search.hpp lin_search)
-            if (gated) small = c->last_move_small;
-            else small = pose_delta(c, one.R, one.t, a.delta.dR, a.delta.dt);
+            uses_state = true;
+            one.state = 0; one.fresh = c->state_valid ? 0u : 1u;
+            a.state = c->d_state; a.state_stride = (uint32_t)c->state_stride;
+            // which plan: a launch with a known pose decides on that pose; a gated one (its pose comes later) on what the last launch
+            // saw - a wrong guess only costs time
+            double max_move = c->last_max_move;
+            if (!gated) max_move = pose_move(c, one.R, one.t);
+            if (c->state_valid && !dbg_host && certifies(c, max_move)) { n_cert = 1; n_full = 0; }
         }
         if (gated) {
-            if (!c->h_gate) {
-                HIP_TRY(c, hipHostMalloc((void **)&c->h_gate, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent));
-                std::memset(c->h_gate, 0, sizeof(GateHost));
-                HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_gate_host, c->h_gate, 0));
-                HIP_TRY(c, hipMalloc((void **)&c->d_gate_pose, sizeof(PoseArg)));
-                HIP_TRY(c, hipMalloc((void **)&c->d_gate_delta, sizeof(PoseDelta)));
-                HIP_TRY(c, hipMalloc((void **)&c->d_gate_abort, sizeof(uint32_t)));
+            if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
+                GateHost *hg = nullptr; PoseArg *dp = nullptr; uint32_t *da = nullptr;
+                bool ok = hipHostMalloc((void **)&hg, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+                ok = ok && hipMalloc((void **)&dp, sizeof(PoseArg)) == hipSuccess && hipMalloc((void **)&da, sizeof(uint32_t)) == hipSuccess;
+                void *dgh = nullptr;
+                ok = ok && hipHostGetDevicePointer(&dgh, hg, 0) == hipSuccess;
+                if (!ok) {
+                    if (hg) (void)hipHostFree(hg);
+                    if (dp) (void)hipFree(dp);
+                    if (da) (void)hipFree(da);
+                    c->state_valid = state_was_valid;
+                    c->fail("allocating the launch gate failed");
+                    return DCREG_E_NOMEM;
+                }
+                std::memset(hg, 0, sizeof(GateHost));
+                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_pose = dp; c->d_gate_abort = da;
             }
             d_poses = c->d_gate_pose;
-            a.delta_dev = c->d_gate_delta;
         }
     } else {
-        // batched poses: each may own one of the reserved warm-start states (dcreg_reserve_warm_states); -1 = search cold
-        const bool use_states = state_ids && c->opt_warm && c->n_warm_states > 0;
+        // batched poses: each may own one of the reserved states (dcreg_reserve_warm_states); -1 = search cold, keep nothing
+        const bool use_states = state_ids && c->opt_warm && c->n_batch_states > 0;
         if (state_ids && c->opt_warm) {
-            std::vector<uint8_t> seen((size_t)std::max<int64_t>(c->n_warm_states, 1), 0);
+            std::vector<uint8_t> seen((size_t)std::max<int64_t>(c->n_batch_states, 1), 0);
             for (int i = 0; i < n_poses; ++i) {
                 const int32_t sid = state_ids[i];
                 if (sid < 0) continue;
-                if ((int64_t)sid >= c->n_warm_states) { c->fail("warm state %d was not reserved (dcreg_reserve_warm_states: %lld)", sid, (long long)c->n_warm_states); return DCREG_E_INVALID; }
+                if ((int64_t)sid >= c->n_batch_states) { c->fail("warm state %d was not reserved (dcreg_reserve_warm_states: %lld)", sid, (long long)c->n_batch_states); return DCREG_E_INVALID; }
                 if (seen[(size_t)sid]) { c->fail("warm state %d is used by two poses of one launch", sid); return DCREG_E_INVALID; }
                 seen[(size_t)sid] = 1;
             }
         }
-        if (ensure(c, S.d_poses, S.poses_cap, (size_t)n_poses)) return DCREG_E_NOMEM;
-        if ((size_t)n_poses > S.h_poses_cap) {      // stays alive until end(): source of the asynchronous copy
+        const size_t bytes = (size_t)n_poses * (sizeof(PoseArg) + sizeof(uint32_t));
+        if (bytes > S.poses_cap) {      // the pinned block stays alive until end(): source of the asynchronous copy
             if (S.h_poses) (void)hipHostFree(S.h_poses);
-            S.h_poses = nullptr; S.h_poses_cap = 0;
-            const size_t cap = std::max<size_t>((size_t)n_poses, 256);
-            HIP_TRY(c, hipHostMalloc((void **)&S.h_poses, cap * sizeof(PoseArg), hipHostMallocDefault));
-            S.h_poses_cap = cap;
+            if (S.d_poses) (void)hipFree(S.d_poses);
+            S.h_poses = nullptr; S.d_poses = nullptr; S.poses_cap = 0;
+            const size_t cap = std::max<size_t>(bytes, 256 * (sizeof(PoseArg) + sizeof(uint32_t)));
+            HIP_TRY(c, hipHostMalloc((void **)&S.h_poses, cap, hipHostMallocDefault));
+            if (hipMalloc((void **)&S.d_poses, cap) != hipSuccess) { c->fail("hipMalloc(%zu B) failed", cap); return DCREG_E_NOMEM; }
+            S.poses_cap = cap;
         }
+        PoseArg *hp = (PoseArg *)S.h_poses;
+        uint32_t *hid = (uint32_t *)(S.h_poses + (size_t)n_poses * sizeof(PoseArg));
+        // pose ids: the certifying poses first (front to back), the searching ones last (back to front)
+        n_cert = 0; n_full = 0;
         for (int i = 0; i < n_poses; ++i) {
-            std::memcpy(S.h_poses[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(S.h_poses[i].t, t3 + 3 * i, sizeof(one.t));
-            S.h_poses[i].state = (use_states && state_ids[i] >= 0) ? (uint32_t)state_ids[i] : kNoIdx;
-            S.h_poses[i].pad_ = 0;
+            std::memcpy(hp[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(hp[i].t, t3 + 3 * i, sizeof(one.t));
+            const bool has = use_states && state_ids[i] >= 0;
+            hp[i].state = has ? (uint32_t)state_ids[i] : kNoIdx;
+            const bool valid = has && c->batch_state_valid[(size_t)state_ids[i]] != 0;
+            hp[i].fresh = valid ? 0u : 1u;
+            // a state that holds certificates is charged (k_rows); anything else is searched in full (k_full)
+            if (valid && c->opt_cert_move > 0.0) hid[n_cert++] = (uint32_t)i; else hid[n_poses - 1 - n_full++] = (uint32_t)i;
+            if (has) c->batch_state_valid[(size_t)state_ids[i]] = 1;
         }
-        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, sizeof(PoseArg) * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
-        d_poses = S.d_poses;
-        if (use_states) { a.prev = c->d_prev_batch; a.prev_stride = (uint32_t)c->prev_batch_stride; }
+        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->stream));
+        d_poses = (const PoseArg *)S.d_poses;
+        const uint32_t *d_ids = (const uint32_t *)(S.d_poses + (size_t)n_poses * sizeof(PoseArg));
+        d_ids_cert = d_ids; d_ids_full = d_ids + (n_poses - n_full);
+        if (use_states) { a.state = c->d_state_batch; a.state_stride = (uint32_t)c->state_batch_stride; }
+    }
+    ListArgs wl{};
+    if (n_cert > 0) {
+        rc = ensure_lists(c, nbx, n_cert, wl);
+        if (rc) { c->state_valid = state_was_valid; if (!fused) drop_warm(c); return rc; }
+        c->list_parity ^= 1u;
+        wl.parity = c->list_parity;
     }
     DebugDev dd{};
     free_tmp(S);
@@ -497,68 +560,68 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (dbg_host->r) dd.r = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
-        if (dbg_host->clocks) dd.clocks = (unsigned long long *)alloc(sizeof(uint64_t) * 16 * ((n + 63) / 64 + 4), 0);
         if (oom) { free_tmp(S); drop_warm(c); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
     FinArgs fin{S.d_tickets, S.d_out, seq};
     if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
-    // kernel timing: HIP events around every opt_time_kernels-th launch (each timed launch costs ~10 us of host time)
+    // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
     const bool timed = slot == 0 && c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
-    const dim3 grid(nbx, (unsigned)n_poses);
-    const size_t lds = (size_t)c->opt_lds_pad;
     const uint32_t *abort_flag = nullptr;
+    // a launch that was queued and must not run after all (errors below): call the gate off, forget what the states were about to hold
+    auto bail = [&](const char *what, hipError_t e) {
+        free_tmp(S);
+        if (gated) gate_call_off(c);
+        drop_warm(c);
+        c->fail("%s failed: %s", what, hipGetErrorString(e));
+        return DCREG_E_DEVICE;
+    };
     if (gated) {
         const unsigned long long want = ++c->gate_seq;
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, c->d_gate_delta, c->d_gate_abort);
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, one.fresh, c->d_gate_abort);
         abort_flag = c->d_gate_abort;
     }
-    if (timed) {                           // after the gate: the events bracket k_linearize, not the wait for the pose
+    if (timed) {                           // after the gate: the events bracket the linearisation, not the wait for the pose
         const hipError_t ee = hipEventRecord(c->ev0, c->stream);
-        if (ee != hipSuccess) {
-            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);
-            drop_warm(c);
-            c->fail("hipEventRecord failed: %s", hipGetErrorString(ee));
-            return DCREG_E_DEVICE;
-        }
+        if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
-#define DCREG_LAUNCH_LIN(MODE, FUSED, FAST, SMALL)                                                                                     \
-    hipLaunchKernelGGL((k_linearize<MODE, FUSED, FAST, SMALL>), grid, dim3(kBlock), lds, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, \
-                       S.d_partials, nbx, fin, dd, abort_flag)
-    if (c->opt_fast_plane) {
-        if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, true, true); else DCREG_LAUNCH_LIN(1, true, true, false); }
-        else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, true, true); else DCREG_LAUNCH_LIN(0, true, true, false); }
-        else DCREG_LAUNCH_LIN(0, false, true, false);     // batched launches always gather (measured: the small-move form buys
-                                                          // nothing on the sparse fixture and its per-pose bookkeeping costs host time)
-    } else {
-        if (dbg_host) { if (small) DCREG_LAUNCH_LIN(1, true, false, true); else DCREG_LAUNCH_LIN(1, true, false, false); }
-        else if (fused) { if (small) DCREG_LAUNCH_LIN(0, true, false, true); else DCREG_LAUNCH_LIN(0, true, false, false); }
-        else DCREG_LAUNCH_LIN(0, false, false, false);
+    const bool fast = c->opt_fast_plane;
+    if (n_cert > 0) {
+        const dim3 grid(nbx, (unsigned)n_cert);
+        const size_t max_q = (size_t)n_cert * (size_t)n, max_b = (size_t)n_cert * nbx;
+        const unsigned gq = list_grid((size_t)c->h_list_counts[0], max_q, kBlock), gb = list_grid((size_t)c->h_list_counts[1], max_b, 1);
+#define DCREG_LAUNCH_ROWS(FUSED, FAST, LISTED, GRID)                                                                                      \
+    hipLaunchKernelGGL((k_rows<FUSED, FAST, LISTED>), GRID, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses,    \
+                       d_ids_cert, a, S.d_partials, nbx, fin, wl, abort_flag)
+        if (fused) { if (fast) DCREG_LAUNCH_ROWS(true, true, false, grid); else DCREG_LAUNCH_ROWS(true, false, false, grid); }
+        else { if (fast) DCREG_LAUNCH_ROWS(false, true, false, grid); else DCREG_LAUNCH_ROWS(false, false, false, grid); }
+        hipLaunchKernelGGL(k_search_list, dim3(gq), dim3(kBlock), 0, c->stream, c->d_src, c->grid, one, d_poses, a, wl, abort_flag);
+        if (fused) { if (fast) DCREG_LAUNCH_ROWS(true, true, true, dim3(gb)); else DCREG_LAUNCH_ROWS(true, false, true, dim3(gb)); }
+        else { if (fast) DCREG_LAUNCH_ROWS(false, true, true, dim3(gb)); else DCREG_LAUNCH_ROWS(false, false, true, dim3(gb)); }
+#undef DCREG_LAUNCH_ROWS
     }
-#undef DCREG_LAUNCH_LIN
+    if (n_full > 0) {
+        const dim3 grid(nbx, (unsigned)n_full);
+#define DCREG_LAUNCH_FULL(MODE, FUSED, FAST)                                                                                               \
+    hipLaunchKernelGGL((k_full<MODE, FUSED, FAST>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses,       \
+                       d_ids_full, a, S.d_partials, nbx, fin, dd, abort_flag)
+        if (dbg_host) { if (fast) DCREG_LAUNCH_FULL(1, true, true); else DCREG_LAUNCH_FULL(1, true, false); }
+        else if (fused) { if (fast) DCREG_LAUNCH_FULL(0, true, true); else DCREG_LAUNCH_FULL(0, true, false); }
+        else { if (fast) DCREG_LAUNCH_FULL(0, false, true); else DCREG_LAUNCH_FULL(0, false, false); }
+#undef DCREG_LAUNCH_FULL
+    }
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
         const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) {
-            free_tmp(S);
-            drop_warm(c);
-            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);   // the gate in the queue must not wait
-            c->fail("k_linearize launch failed: %s", hipGetErrorString(le));
-            return DCREG_E_DEVICE;
-        }
+        if (le != hipSuccess) return bail("linearisation kernel launch", le);
     }
-    if (timed) {                           // brackets k_linearize alone
-        const hipError_t ee = hipEventRecord(c->ev1, c->stream);
-        if (ee != hipSuccess) {
-            if (gated) gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);
-            drop_warm(c);
-            c->fail("hipEventRecord failed: %s", hipGetErrorString(ee));
-            return DCREG_E_DEVICE;
-        }
-    }
-    if (!fused || dbg_host) {
-        if (!fused) hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
+    if (!fused) {
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
         const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { free_tmp(S); drop_warm(c); c->fail("k_finalize launch failed: %s", hipGetErrorString(le)); return DCREG_E_DEVICE; }
+        if (le != hipSuccess) return bail("k_finalize launch", le);
+    }
+    if (timed) {                           // brackets the linearisation's kernels
+        const hipError_t ee = hipEventRecord(c->ev1, c->stream);
+        if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     if (dbg_host) {
         hipError_t ce = hipSuccess;
@@ -570,18 +633,45 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         back(dbg_host->r, dd.r, sizeof(double) * n);
         back(dbg_host->s, dd.s, sizeof(double) * n);
         back(dbg_host->stats, dd.stats, sizeof(uint32_t) * n);
-        back(dbg_host->clocks, dd.clocks, sizeof(uint64_t) * 16 * ((n + 63) / 64));
         if (ce != hipSuccess) {
             (void)hipStreamSynchronize(c->stream);
-            free_tmp(S);
-            drop_warm(c);
-            c->fail("copying the debug dump back failed: %s", hipGetErrorString(ce));
-            return DCREG_E_DEVICE;
+            return bail("copying the debug dump back", ce);
         }
     }
+    c->n_poses_searched += n_full; c->n_poses_certified += n_cert;
+    if (uses_state) c->state_valid = true;          // once this launch has run, the state holds a search of the current clouds
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
-    S.seq = seq; S.sync = dbg_host != nullptr;
-    if (gated) c->gate_slot = slot;
+    S.seq = seq; S.sync = dbg_host != nullptr; S.certifying = n_cert > 0;
+    if (gated) {
+        c->gate_slot = slot;
+        c->gate_uses_state = uses_state; c->gate_certifying = n_cert > 0; c->gate_state_was_valid = state_was_valid;
+    }
+    return DCREG_OK;
+}
+
+// wait for the result rows of a launch.  Hot path: spin on the sequence numbers the kernels publish into pinned host memory.  A
+// launch may be slow but healthy (a GPU shared with other processes, huge clouds), and while it is awaited a gate for the NEXT launch
+// may already sit in the stream: a stream synchronise would then wait for that gate, i.e. for this very thread.  So the wait is
+// bounded by wall-clock time (far below the gate's own patience); only when it runs out is the stream drained - after calling the
+// waiting gate off - to surface a device fault instead of hanging.
+static int wait_rows(dcreg_ctx *c, LinSlot &S) {
+    using Clk = std::chrono::steady_clock;
+    Clk::time_point t0;
+    bool clocked = false;
+    for (size_t i = 0; i < S.n_rows; ++i) {
+        volatile unsigned long long *flag = (volatile unsigned long long *)(S.h_out + i * kSlots + 31);
+        uint64_t spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) {
+            __builtin_ia32_pause();
+            if ((++spins & ((1ull << 20) - 1)) != 0) continue;
+            if (!clocked) { t0 = Clk::now(); clocked = true; continue; }
+            if (std::chrono::duration<double>(Clk::now() - t0).count() < c->opt_wait_seconds) continue;
+            if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);      // nothing may wait behind us while we drain the stream
+            const hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->fail("device fault while waiting for a linearisation: %s", hipGetErrorString(e)); return DCREG_E_DEVICE; }
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
+        }
+    }
     return DCREG_OK;
 }
 
@@ -592,26 +682,17 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
     if (!S.pending) { c->fail("slot %d has no linearisation in flight", slot); return DCREG_E_STATE; }
     if (!outs) { c->fail("null argument"); return DCREG_E_INVALID; }
     S.pending = false;
+    int rc = DCREG_OK;
     if (S.sync || !c->opt_spin) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->fail("hipStreamSynchronize failed: %s", hipGetErrorString(e)); rc = DCREG_E_DEVICE; }
+        if (rc == DCREG_OK && S.sync) { const hipError_t e2 = hipGetLastError(); if (e2 != hipSuccess) { c->fail("%s", hipGetErrorString(e2)); rc = DCREG_E_DEVICE; } }
     } else {
-        // hot path: spin on the sequence numbers the kernels publish into pinned host memory
-        for (size_t i = 0; i < S.n_rows; ++i) {
-            volatile unsigned long long *flag = (volatile unsigned long long *)(S.h_out + i * kSlots + 31);
-            uint64_t spins = 0;
-            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) {
-                __builtin_ia32_pause();
-                if (++spins > (1ull << 26)) {   // ~seconds: surface a device fault instead of hanging
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
-                    break;
-                }
-            }
-        }
+        rc = wait_rows(c, S);
     }
-    S.tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
     free_tmp(S);
-    if (S.sync) HIP_TRY(c, hipGetLastError());
+    if (rc != DCREG_OK) { drop_warm(c); return rc; }       // what the launch left in the states is unknown
+    S.tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
     if (S.timed) {
         float ms = 0.f;
         hipError_t te = hipEventElapsedTime(&ms, c->ev0, c->ev1);
@@ -737,12 +818,13 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->h_gate) (void)hipHostFree(c->h_gate);
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
-    if (c->d_gate_delta) (void)hipFree(c->d_gate_delta);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_prev, c->d_prev_batch, c->d_gap};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_list_count, c->d_q_entries,
+                    c->d_b_entries, c->d_gap};
     for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->h_list_counts) (void)hipHostFree(c->h_list_counts);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
         for (void *b : S.tmp_dev) (void)hipFree(b);
@@ -768,16 +850,20 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     const std::string k(key);
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
-    else if (k == "small_move") c->opt_small_move = v >= 0.0 ? v : 0.0;
+    else if (k == "cert_move" || k == "small_move") c->opt_cert_move = v >= 0.0 ? v : 0.0;
+    else if (k == "cert_margin") { c->opt_cert_margin = v >= 1e-4 ? std::min(v, 1.0) : 1e-4; drop_warm(c); }    // the cells follow at the next dcreg_set_target
+    else if (k == "wait_seconds") c->opt_wait_seconds = v > 0.0 ? v : 30.0;
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
-    else if (k == "warm_start") { c->opt_warm = v != 0.0; c->prev_valid = false; }
+    else if (k == "warm_start") {
+        if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it before changing \"warm_start\""); return DCREG_E_STATE; }
+        c->opt_warm = v != 0.0; drop_warm(c);
+    }
     else if (k == "xcd_chunk") c->opt_xcd_chunk = (int)v;   // 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks round-robin
     else if (k == "fast_plane_fit") c->opt_fast_plane = v != 0.0;   // 1 (default) = plane_fit_qr_fast, 0 = the Eigen-shaped plane_fit_qr
-    else if (k == "lds_pad") c->opt_lds_pad = (int)v;   // extra dynamic LDS per block (occupancy experiments)
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;
 }
@@ -812,14 +898,22 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
     if (!c) return DCREG_E_INVALID;
     if (n_states < 0) { c->fail("negative state count"); return DCREG_E_INVALID; }
     for (const LinSlot &S : c->slots) if (S.pending) { c->fail("a linearisation is still in flight"); return DCREG_E_STATE; }
-    c->n_warm_states = 0;
+    c->n_batch_states = 0;
+    c->batch_state_valid.clear();
     if (n_states == 0 || c->n_src <= 0) return DCREG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t stride = ((size_t)c->n_src + 63) & ~(size_t)63;
-    if (ensure(c, c->d_prev_batch, c->prev_batch_cap, 6 * stride * (size_t)n_states)) return DCREG_E_NOMEM;
-    { const int rc = clear_states(c, c->d_prev_batch, stride, (size_t)n_states); if (rc) return rc; }
-    c->prev_batch_stride = stride;
-    c->n_warm_states = n_states;
+    // nothing is cleared: a state is "fresh" (host-side flag) until its first launch has filled it
+    if (ensure(c, c->d_state_batch, c->state_batch_cap, kStateRows * stride * (size_t)n_states)) return DCREG_E_NOMEM;
+    c->state_batch_stride = stride;
+    c->n_batch_states = n_states;
+    c->batch_state_valid.assign((size_t)n_states, 0);
+    return DCREG_OK;
+}
+int dcreg_reset_warm_state(dcreg_ctx *c, int64_t state_id) {
+    if (!c) return DCREG_E_INVALID;
+    if (state_id < 0 || state_id >= c->n_batch_states) { c->fail("warm state %lld was not reserved", (long long)state_id); return DCREG_E_INVALID; }
+    c->batch_state_valid[(size_t)state_id] = 0;
     return DCREG_OK;
 }
 int dcreg_linearize_batch_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) { return linearize_end(c, slot, outs); }
@@ -829,20 +923,21 @@ int dcreg_linearize_gated_begin(dcreg_ctx *c, int slot, const dcreg_lin_params *
 int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
-    float dR[9], dt[3];
-    if (c->opt_warm && c->prev_valid) (void)pose_delta(c, R, t, dR, dt);          // the queued launch reads and writes the ctx's own state
-    else { for (float &v : dR) v = 0.f; for (float &v : dt) v = 0.f; }
-    gate_publish(c, c->gate_seq << 1, R, t, dR, dt);
+    if (c->gate_uses_state) (void)pose_move(c, R, t);             // the queued launch reads and writes the ctx's own state
+    gate_publish(c, c->gate_seq << 1, R, t);
     c->gate_slot = -1;
     return DCREG_OK;
 }
 int dcreg_linearize_gate_abort(dcreg_ctx *c) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0) return DCREG_OK;                                  // nothing queued
-    gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr, nullptr, nullptr);
+    gate_call_off(c);
     LinSlot &S = c->slots[c->gate_slot];
     S.pending = false;                 // no result will come; tickets_dirty stays set, so the next launch of the slot clears them
     free_tmp(S);
+    // the kernels behind the gate return without touching anything: the state, its pose and the list counters are as before
+    if (c->gate_uses_state) c->state_valid = c->gate_state_was_valid;
+    if (c->gate_certifying) c->list_parity ^= 1u;
     c->gate_slot = -1;
     return DCREG_OK;
 }
@@ -873,6 +968,15 @@ int dcreg_index_info_get(const dcreg_ctx *c, dcreg_index_info *info) {
     info->origin[0] = c->grid.ox; info->origin[1] = c->grid.oy; info->origin[2] = c->grid.oz;
     info->dims[0] = c->grid.nx; info->dims[1] = c->grid.ny; info->dims[2] = c->grid.nz;
     info->n_cells = c->n_cells; info->n_target = c->n_tgt; info->n_source = c->n_src; info->max_ring = c->last_max_ring;
+    return DCREG_OK;
+}
+
+int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
+    if (!c || !st) return DCREG_E_INVALID;
+    st->poses_searched = c->n_poses_searched; st->poses_certified = c->n_poses_certified;
+    st->last_queries_listed = c->h_list_counts ? (int64_t)__atomic_load_n(&c->h_list_counts[0], __ATOMIC_ACQUIRE) : 0;
+    st->last_blocks_listed = c->h_list_counts ? (int64_t)__atomic_load_n(&c->h_list_counts[1], __ATOMIC_ACQUIRE) : 0;
+    if (reset) { c->n_poses_searched = 0; c->n_poses_certified = 0; }
     return DCREG_OK;
 }
 

@@ -19,15 +19,15 @@ struct WarmPose { double R[9]; double t[3]; bool valid = false; };
 
 struct LinSlot {
     double *d_partials = nullptr; size_t partials_cap = 0;
-    dcreg::PoseArg *d_poses = nullptr; size_t poses_cap = 0;
-    dcreg::PoseArg *h_poses = nullptr; size_t h_poses_cap = 0;     // PINNED staging of the batched poses: the H2D copy is a plain DMA
-                                                                   // (a pageable source is staged by the runtime; beyond 16 KB that
-                                                                   // cost 14 us per launch)
+    // batched poses: ONE pinned staging block [PoseArg x n | pose ids x n] and its device copy (one plain DMA per launch; a pageable
+    // source is staged by the runtime, and beyond 16 KB that cost 14 us per launch)
+    unsigned char *h_poses = nullptr, *d_poses = nullptr; size_t poses_cap = 0;      // bytes
     double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped result rows
     unsigned int *d_tickets = nullptr; size_t tickets_cap = 0;
     bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
     std::vector<void *> tmp_dev;   // debug dump buffers of the launch in flight
     bool pending = false, fused = false, timed = false, sync = false;
+    bool certifying = false;       // the launch in flight charges certificates (k_rows + lists) rather than searching everything
     int n_poses = 0;
     uint32_t n_chunks = 0;
     size_t n_rows = 0;
@@ -62,20 +62,25 @@ struct dcreg_ctx {
     int64_t n_src = 0;
     float4 *d_src_raw = nullptr; size_t src_raw_cap = 0;
     float4 *d_src = nullptr; size_t src_cap = 0;           // Hilbert-sorted
-    // warm start: [6][prev_stride] - rows 0-4 the sorted-target positions of every source point's neighbour set as of its last
-    // gathering launch, row 5 the squared distance to the 5th neighbour found by its last launch (float bits) - and the pose of that
-    // last launch (LinArgs::prev, search.hpp lin_search)
-    uint32_t *d_prev = nullptr; size_t prev_cap = 0;
-    size_t prev_stride = 0;
-    bool prev_valid = false;       // false -> cleared to "none" before the next single-pose linearisation
-    WarmPose prev_pose;            // pose of the launch that last wrote the ctx's own state
-    bool last_move_small = false;  // was the last single-pose launch a small move?  (what a gated launch, queued before its pose
-                                   // exists, assumes about itself)
+    // neighbour state of the ctx's own single-pose launches (search.hpp kStateRows): [kStateRows][state_stride]
+    uint32_t *d_state = nullptr; size_t state_cap = 0;
+    size_t state_stride = 0;
+    bool state_valid = false;      // the state holds the results of a search of the current clouds
+    WarmPose prev_pose;            // pose of the launch that last touched the ctx's own state
+    double last_max_move = 1e300;  // bound on any source point's move at the last single-pose launch (what a gated launch, queued
+                                   // before its pose exists, assumes about itself)
     double src_radius = 0.0;       // largest distance of a source point from the body-frame origin (bounds a pose change's effect)
-    // batched launches: n_warm_states states of the same layout, [state][6][prev_batch_stride] (dcreg_reserve_warm_states)
-    uint32_t *d_prev_batch = nullptr; size_t prev_batch_cap = 0;
-    size_t prev_batch_stride = 0;
-    int64_t n_warm_states = 0;
+    // batched launches: n_batch_states states of the same layout, [state][kStateRows][state_batch_stride] (dcreg_reserve_warm_states),
+    // and whether each holds anything yet
+    uint32_t *d_state_batch = nullptr; size_t state_batch_cap = 0;
+    size_t state_batch_stride = 0;
+    int64_t n_batch_states = 0;
+    std::vector<uint8_t> batch_state_valid;
+    // work lists of certifying launches (kernels.hpp ListArgs)
+    uint32_t *d_list_count = nullptr;
+    uint2 *d_q_entries = nullptr, *d_b_entries = nullptr; size_t q_entries_cap = 0, b_entries_cap = 0;
+    uint32_t list_parity = 0;
+    unsigned long long *h_list_counts = nullptr, *d_list_counts_host = nullptr;    // pinned [2]: queries / blocks of the last certifying launch
 
     // build scratch
     float *d_stage = nullptr; size_t stage_cap = 0;
@@ -89,10 +94,12 @@ struct dcreg_ctx {
     // gate of pipelined launches (kernels.hpp k_gate): pinned sequence number + pose, the device-resident pose it fills, abort word
     dcreg::GateHost *h_gate = nullptr, *d_gate_host = nullptr;
     dcreg::PoseArg *d_gate_pose = nullptr;
-    dcreg::PoseDelta *d_gate_delta = nullptr;
     uint32_t *d_gate_abort = nullptr;
     unsigned long long gate_seq = 0;       // number of the gated launch last queued
     int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)
+    bool gate_uses_state = false;          // what the queued launch was built with: it reads / writes the ctx's own state,
+    bool gate_certifying = false;          //   it tests certificates (k_rows + work lists: the list parity was advanced for it),
+    bool gate_state_was_valid = false;     //   and what state_valid was before it was queued (restored if it is called off)
     static constexpr int kLinSlots = 2;
     LinSlot slots[kLinSlots];
 
@@ -110,20 +117,22 @@ struct dcreg_ctx {
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
     int opt_x_subdiv = 8;          // x sub-cells per grid cell (1, 2, 4, 8, 16)
-    double opt_small_move = 0.05;  // fraction of a cell edge: a pose change that moves no source point farther takes the small-move
-                                   // warm bound (0 = never)
+    double opt_cert_move = 0.5;    // fraction of a cell edge: a pose change that moves no source point farther is linearised by testing
+                                   // certificates (k_rows + work lists) instead of searching every query (0 = never)
+    double opt_cert_margin = 0.05; // searches cover R (1 + margin): what "5th neighbour beyond R" certificates can spend
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
     uint64_t launch_counter = 0;
+    double opt_wait_seconds = 30.0; // how long a result is awaited before the stream is drained to look for a device fault
     bool opt_spin = true;          // wait for results by spinning on pinned memory instead of hipStreamSynchronize
     bool need_set_device = true;
     unsigned long long seq = 0;
-    int opt_lds_pad = 0;
     int opt_xcd_chunk = 16;        // query-block -> XCD mapping (kernels.hpp xcd_remap): runs of 16 blocks round-robin (measured: C4 -13 %)
     bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
     bool opt_keep_source_order = false;   // experiments only
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
+    int64_t n_poses_searched = 0, n_poses_certified = 0;    // dcreg_launch_stats
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
 

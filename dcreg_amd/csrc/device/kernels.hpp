@@ -120,20 +120,34 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t c
     return (k / chunk) * span + xcd * chunk + (k % chunk);
 }
 
-// ---------------------------------------------------------------- the fused linearisation kernel
-// MODE 0: reduction only.  MODE 1: also dump per-point results (parity tests).
+// ---------------------------------------------------------------- the linearisation kernels
+// One linearisation (steps 1-5 of an iteration, icp_test_runner.cpp:1714-1915) of a pose is either ONE launch
+//   k_full          every block: 6-NN search of every query (bounded by its old neighbours when the state has some), certificate,
+//                   state update, then rows + reduction.  The first launch on a state, launches after a large pose change, poses
+//                   without a state, debug dumps;
+// or, when the pose's state holds certificates (search.hpp kStateRows) and the pose has moved little, up to three:
+//   k_rows<false>   every block: test each query's certificate at its new position.  A block whose queries all still hold one
+//                   needs NO search: it gathers the five known neighbours per query, re-sorts them at the new pose and builds rows +
+//                   reduction.  Otherwise the queries out of budget go, compacted, on the query list, the block on the block list;
+//   k_search_list   dense waves over the query list: 6-NN search, certificate, state update;
+//   k_rows<true>    the listed blocks: rows + reduction for all their 256 queries from the (partly refreshed) state.
+// Every block partial is therefore produced by the same row code from the same exact neighbour sets in the same lane order, whichever
+// kernel runs it, and the chunk / pose sums take the partials in index order: the sums do not depend on which queries were searched.
+// On a converged trajectory the lists are empty, the host has its result after the first kernel and the other two retire in the
+// shadow of the host step.
+// MODE 0: reduction only.  MODE 1 (k_full): also dump per-point results (parity tests).
 struct DebugDev {
     int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
     uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16
-    unsigned long long *clocks;   // per wave: 8 shader-clock stamps (phase breakdown), may be null
 };
 
 // Single-pose launches finish inside the kernel (no second launch): blocks are grouped in chunks of kChunk consecutive
 // partial rows; the last block to finish in a chunk (ticket counter) sums that chunk's rows in a fixed order and writes
 // the chunk row, stamped with the launch's sequence number, straight into pinned host-coherent memory.  The host spins on
-// the stamps and adds the few chunk rows in index order.  WHO sums is timing dependent, WHAT is summed in which order is
-// not: the result is deterministic.  Batched launches (many poses, few blocks each) use k_finalize instead: a ticket
-// per block costs more there than the second launch (measured, profiles/r01_search_ablation.md addendum 5).
+// the stamps and adds the few chunk rows in index order.  WHO sums is timing dependent - it may be a block of the last kernel of
+// the launch -, WHAT is summed in which order is not: the result is deterministic.  Batched launches (many poses, few blocks
+// each) use k_finalize instead: a ticket per block costs more there than the extra launch (measured, profiles/r01_search_ablation.md
+// addendum 5).
 constexpr int kChunk = 64;
 struct FinArgs {
     unsigned int *tickets;         // [n_chunks], zero between launches (the last arrival resets its ticket)
@@ -141,6 +155,21 @@ struct FinArgs {
     unsigned long long seq;
 };
 
+// the work lists of a certifying launch: queries to search and blocks to redo, each kept as eight lists (one per XCD's worth of
+// blocks: an append is an atomic on a counter, and one word takes ~88 of them per microsecond; a block appends once per list), double
+// buffered by launch parity - the launch of parity p appends to count[p] and clears count[1 - p] for its successor, so nothing has to
+// be reset between launches
+constexpr int kWorkLists = 8;
+struct ListArgs {
+    uint32_t *count;               // [2][2][kWorkLists]: parity, kind (0 queries, 1 blocks), list
+    uint2 *q_entries;              // [kWorkLists][q_cap]: {pose, query}
+    uint2 *b_entries;              // [kWorkLists][b_cap]: {pose, query block}
+    uint32_t q_cap, b_cap;
+    uint32_t parity;
+    unsigned long long *host_counts;   // pinned [2]: queries searched / blocks redone by the launch, for the host's next grid sizes (may be null)
+    __device__ uint32_t *qcount(uint32_t l) const { return count + (parity * 2u + 0u) * kWorkLists + l; }
+    __device__ uint32_t *bcount(uint32_t l) const { return count + (parity * 2u + 1u) * kWorkLists + l; }
+};
 // Cross-block traffic of the tree uses agent-scope (sc1, write-through / L2-coherent) relaxed atomics plus an explicit
 // s_waitcnt instead of __threadfence(): a release fence on gfx950 is a full L2 write-back (buffer_wbl2), measured at
 // +10 us per launch when every block executes one.
@@ -184,18 +213,20 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // device starts: idle time for a device that has nothing else queued.  A GATED linearisation is queued while its predecessor still
 // runs, before its pose exists: k_gate (one wave) sits in the stream in front of it and polls a small record in pinned host
 // memory; when the host publishes the pose there, the gate copies it into the device-resident PoseArg the linearisation reads,
-// and retires.  The host can also call the launch off (abort bit): the linearisation behind the gate then returns at once.
-// A gate that waits longer than ~5 s aborts by itself (wall clock, 100 MHz), so a vanished host cannot leave the queue spinning.
-// The gate record: 20 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
-// patterns), w[13..18] = dR, dt (12 floats, PoseDelta), w[19] = kGateSalt ^ w[0] ^ ... ^ w[18].  The gate reads all words with ONE load
+// and retires.  The host can also call the launch off (abort bit): the kernels behind the gate then return at once.
+// A gate that waits longer than kGateTimeoutTicks (wall clock, 100 MHz; far longer than the host ever waits for a result) aborts by
+// itself, so a vanished host cannot leave the queue spinning.
+// The gate record: 14 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
+// patterns of doubles), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The gate reads all words with ONE load
 // per lane and accepts them only if the number is the awaited one AND the checksum holds: the loads of one poll may be served in
 // any order relative to the host's stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip
 // between "pose published" and "pose on the device", whatever the read granularity of the link.
-constexpr int kGateWords = 20;
+constexpr int kGateWords = 14;
+constexpr unsigned long long kGateTimeoutTicks = 12000000000ull;     // 120 s
 struct alignas(128) GateHost { unsigned long long w[32]; };
 constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
 static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
-                                                   PoseDelta *__restrict__ ddst, uint32_t *__restrict__ abort_flag) {
+                                                   uint32_t fresh, uint32_t *__restrict__ abort_flag) {
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
     unsigned long long v = 0, seq = 0;
@@ -215,97 +246,34 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
         if ((seq >> 1) == want && whole) break;
         // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this gate ever ran
         if ((seq >> 1) > want && whole) { seq = (want << 1) | 1ull; break; }
-        if (wall_clock64() - t0 > 500000000ull) { seq = (want << 1) | 1ull; break; }     // ~5 s at 100 MHz: nobody opens - give up
+        if (wall_clock64() - t0 > kGateTimeoutTicks) { seq = (want << 1) | 1ull; break; }     // nobody opens - give up
         __builtin_amdgcn_s_sleep(2);
     }
     if (lane >= 1 && lane <= 12) {
         const double d = __longlong_as_double((long long)v);
         if (lane <= 9) dst->R[lane - 1] = d; else dst->t[lane - 10] = d;
     }
-    if (lane >= 13 && lane <= 18) {                      // two floats per word: dR[0..8], dt[0..2]
-        float *f = &ddst->dR[0];                         // dR and dt are adjacent in PoseDelta
-        const int k = 2 * (lane - 13);
-        f[k] = __uint_as_float((uint32_t)v); f[k + 1] = __uint_as_float((uint32_t)(v >> 32));
-    }
-    if (lane == 0) { dst->state = 0; dst->pad_ = 0; *abort_flag = (uint32_t)(seq & 1ull); }
+    if (lane == 0) { dst->state = 0; dst->fresh = fresh; *abort_flag = (uint32_t)(seq & 1ull); }
 }
 
-template <int MODE, bool FUSED, bool FAST, bool SMALL>
-static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
-                                                       PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
-                                                       double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin, DebugDev dbg,
-                                                       const uint32_t *__restrict__ abort_flag) {
-    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
-    __shared__ double red[8][kSlots];
-    __shared__ double cnt[kBlock / 64][2];
-    __shared__ int s_role;
-    __shared__ RunList runs[kBlock / kWave];
-    const uint32_t pose_id = blockIdx.y;
-    const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
-    const uint32_t i = vb * kBlock + threadIdx.x;
+// ---- the common tail of a block: the wave's rows -> its Gram matrix and counts in LDS (the wave's LDS staging area must be free) ...
+__device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t flag, double *stage, double (*red)[kSlots], double (*cnt)[2]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PoseArg P;
-    if (poses) P = poses[pose_id]; else P = pose1;
-
-    double row[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) row[k] = 0.0;
-    uint8_t flag = 0;
-    unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
-    if (MODE == 1) clk[0] = clock64();
-
-    // ---- query, warm bound, exact 5-NN (search.hpp)
-    const bool have_q = i < n_src;
-    const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    PointQuery q;
-    KnnResult<5> nn;
-    unsigned long long sst[7] = {0, 0, 0, 0, 0, 0, 0};   // search sub-phase stamps; [3..6] ring-walk cycle / count sums (search.hpp)
-    if (MODE == 1) clk[1] = clock64();
-    // batched launches: every pose owns a warm-start state of its own, selected by the pose's state slot
-    uint32_t *prev = a.prev ? a.prev + (size_t)P.state * 6u * a.prev_stride : nullptr;
-    if (poses && P.state == kNoIdx) prev = nullptr;
-    lin_search<SMALL>(g, runs[wave], P, a, prev, have_q, s4, i, q, nn, MODE == 1 ? sst : nullptr);
-    if (MODE == 1) clk[2] = clock64();
-
-    // ---- plane fit, gates, row (search.hpp)
-    if (have_q) {
-        double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
-        flag = lin_row<FAST>(P, a, s4, q, nn, row, nrm, r_pt, s_pt);
-        if (MODE == 1) {
-            const uint32_t oi = __float_as_uint(s4.w);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const bool ok = q.reach && nn.idx[j] != kNoIdx;
-                if (dbg.nn_idx) dbg.nn_idx[5 * (size_t)oi + j] = ok ? (int32_t)nn.idx[j] : -1;
-                if (dbg.nn_d2) dbg.nn_d2[5 * (size_t)oi + j] = ok ? nn.d2[j] : __builtin_inff();
-            }
-            if (flag == 1 || flag == 4) {
-                if (dbg.normal) { dbg.normal[3 * (size_t)oi] = nrm[0]; dbg.normal[3 * (size_t)oi + 1] = nrm[1]; dbg.normal[3 * (size_t)oi + 2] = nrm[2]; }
-                if (dbg.r) dbg.r[oi] = r_pt;
-                if (dbg.s) dbg.s[oi] = s_pt;
-            }
-            if (dbg.flag) dbg.flag[oi] = flag;
-            if (dbg.stats) dbg.stats[oi] = (nn.n_eval & 0xFFFFu) | ((nn.n_shell & 0x7FFFu) << 16);
-        }
+    double u0, u1;
+    wave_gram_mfma(row, stage, lane, u0, u1);
+    double *gm = &red[0][0] + wave * 64;            // the wave's Gram matrix, M[a][b] at a * 8 + b
+    if ((lane & 15) < 8) {
+        gm[(lane >> 4) * 8 + (lane & 7)] = u0;
+        gm[32 + (lane >> 4) * 8 + (lane & 7)] = u1;
     }
-
-    if (MODE == 1) clk[3] = clock64();
-    // wave reduction on the matrix cores (the wave's RunList is free now: it stages the rows) -> the wave's 8x8 Gram
-    // matrix and its two counts in LDS -> block partial (fixed order, no float atomics)
-    {
-        double u0, u1;
-        wave_gram_mfma(row, runs[wave].stage, lane, u0, u1);
-        double *gm = &red[0][0] + wave * 64;            // the wave's Gram matrix, M[a][b] at a * 8 + b
-        if ((lane & 15) < 8) {
-            gm[(lane >> 4) * 8 + (lane & 7)] = u0;
-            gm[32 + (lane >> 4) * 8 + (lane & 7)] = u1;
-        }
-        const unsigned long long eff = __builtin_amdgcn_ballot_w64(flag == 1), inr = __builtin_amdgcn_ballot_w64(flag != 0);
-        if (lane == 0) { cnt[wave][0] = (double)__builtin_popcountll(eff); cnt[wave][1] = (double)__builtin_popcountll(inr); }
-    }
-    if (MODE == 1) clk[4] = clock64();
-    __syncthreads();
-    double *my_rows = partials + (size_t)pose_id * n_blocks_x * kSlots;
+    const unsigned long long eff = __builtin_amdgcn_ballot_w64(flag == 1), inr = __builtin_amdgcn_ballot_w64(flag != 0);
+    if (lane == 0) { cnt[wave][0] = (double)__builtin_popcountll(eff); cnt[wave][1] = (double)__builtin_popcountll(inr); }
+}
+// ... and, after a block barrier: the block partial (fixed order, no float atomics) and, for single-pose launches, the arrival at
+// the chunk's ticket: the last of its blocks sums the chunk and publishes the row to the host.  All 256 threads call.
+template <bool FUSED>
+__device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cnt)[2], int *s_role, double *my_rows, uint32_t vb,
+                                              uint32_t n_blocks_x, const FinArgs &fin) {
     if (threadIdx.x < kSlots) {
         double t = 0.0;
         if (threadIdx.x < 29) {
@@ -329,11 +297,11 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_role = (prev == csize - 1) ? 1 : 0;
+            *s_role = (prev == csize - 1) ? 1 : 0;
             if (prev == csize - 1) __hip_atomic_store(&fin.tickets[chunk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
+        if (*s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
             const double t = block_sum_rows(my_rows + (size_t)chunk * kChunk * kSlots, csize, red);
             double *orow = fin.out + (size_t)chunk * kSlots;
             if (threadIdx.x < 31) { st_system(orow + threadIdx.x, t); wait_stores(); }
@@ -342,17 +310,213 @@ static __global__ __launch_bounds__(kBlock, 4) void k_linearize(const float4 *__
                 __hip_atomic_store((unsigned long long *)(orow + 31), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (MODE == 1 && dbg.clocks && lane == 0) {
-        clk[5] = clock64();
-        unsigned long long *o = dbg.clocks + ((size_t)vb * (kBlock / 64) + wave) * 16;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = clk[k];
-        o[6] = sst[0] ? (sst[0] - clk[1]) | ((sst[1] - sst[0]) << 20) | ((sst[2] - sst[1]) << 40) : 0;   // phase A | phase B | shells
-        o[7] = blockIdx.x;
-        // ring walk of lane 0 of the wave (search.hpp knn_shells): cycles inside the candidate scans, cycles waiting for table
-        // entries, row iterations, scans
-        o[8] = sst[3]; o[9] = sst[4]; o[10] = sst[5]; o[11] = sst[6];
+}
+
+// ---------------------------------------------------------------- k_rows: the search-free linearisation
+// LISTED = false: all blocks of the poses given, certificates tested first.  LISTED = true: the blocks on the block lists, after
+// k_search_list has refreshed the queries that were out of budget; certificates are taken as they stand.
+// LDS: 4.5 KB staging per wave + 2 KB; no run lists, no heaps: this kernel's occupancy is set by the plane fit's registers alone.
+template <bool FUSED, bool FAST, bool LISTED>
+static __global__ __launch_bounds__(kBlock, 4) void k_rows(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
+                                                           const PoseArg *__restrict__ poses, const uint32_t *__restrict__ pose_ids,
+                                                           LinArgs a, double *__restrict__ partials,
+                                                           uint32_t n_blocks_x, FinArgs fin, ListArgs wl,
+                                                           const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
+    __shared__ double red[8][kSlots];
+    __shared__ double cnt[kBlock / 64][2];
+    __shared__ int s_role;
+    __shared__ uint32_t s_wcnt[kBlock / 64], s_qbase;
+    __shared__ double stage[kBlock / kWave][kWave * kRowStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t n_entries = 1, e = 0, e_step = 1;
+    const uint2 *list = nullptr;
+    if (LISTED) {
+        const uint32_t l = blockIdx.x & (kWorkLists - 1);
+        n_entries = *wl.bcount(l);
+        list = wl.b_entries + (size_t)l * wl.b_cap;
+        e = blockIdx.x / kWorkLists; e_step = gridDim.x / kWorkLists;
+        if (blockIdx.x == 0 && threadIdx.x < 2 && wl.host_counts) {       // last kernel of the launch: tell the host how much there was
+            unsigned long long tot = 0;
+            for (int k = 0; k < kWorkLists; ++k) tot += threadIdx.x == 0 ? *wl.qcount(k) : *wl.bcount(k);
+            __hip_atomic_store(wl.host_counts + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * kWorkLists) {
+        wl.count[(1u - wl.parity) * 2u * kWorkLists + threadIdx.x] = 0u;       // the successor's counters
     }
+    for (; e < n_entries; e += e_step) {
+        uint32_t pose_id, vb;
+        if (LISTED) { const uint2 en = list[e]; pose_id = en.x; vb = en.y; }
+        else { pose_id = pose_ids ? pose_ids[blockIdx.y] : blockIdx.y; vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk); }
+        const uint32_t i = vb * kBlock + threadIdx.x;
+        PoseArg P;
+        if (poses) P = poses[pose_id]; else P = pose1;
+        double row[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = 0.0;
+        uint8_t flag = 0;
+        const bool have_q = i < n_src;
+        uint32_t *st = a.state + (size_t)P.state * kStateRows * a.state_stride;
+        const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t cert = kCertSearch, pos[5], q0[3] = {0u, 0u, 0u};
+        if (have_q) cert = st[(size_t)6 * a.state_stride + i];
+        if (!LISTED && have_q) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * a.state_stride + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pos[j] = have_q ? st[(size_t)j * a.state_stride + i] : 0u;     // issued with the certificate: one latency
+        float qx, qy, qz;
+        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
+        bool unc = false;
+        unsigned long long unc_mask = 0ull;
+        if (!LISTED) {          // does every query's certificate hold at its new position?
+            unc = have_q && !cert_holds(cert, __uint_as_float(q0[0]), __uint_as_float(q0[1]), __uint_as_float(q0[2]), qx, qy, qz);
+            unc_mask = __builtin_amdgcn_ballot_w64(unc);
+            if (lane == 0) s_wcnt[wave] = (uint32_t)__builtin_popcountll(unc_mask);
+        }
+        if (unc_mask == 0ull && have_q && !(cert & 0x80000000u)) {         // SET certificate: the five known neighbours at the new pose
+            KnnResult<5> nn;
+            double nrm[3], r_pt, s_pt;
+            flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, r_pt, s_pt);
+        }
+        wave_rows_to_lds(row, flag, stage[wave], red, cnt);
+        __syncthreads();
+        bool dirty = false;
+        if (!LISTED) {
+            const uint32_t w0 = s_wcnt[0], w1 = s_wcnt[1], w2 = s_wcnt[2], w3 = s_wcnt[3];
+            const uint32_t tot = w0 + w1 + w2 + w3;
+            dirty = tot != 0u;
+            if (dirty) {              // some query needs a search: its queries go on the query list, the block on the block list
+                const uint32_t l = blockIdx.x & (kWorkLists - 1);
+                if (threadIdx.x == 0) {
+                    s_qbase = atomicAdd(wl.qcount(l), tot);
+                    const uint32_t slot = atomicAdd(wl.bcount(l), 1u);
+                    wl.b_entries[(size_t)l * wl.b_cap + slot] = make_uint2(pose_id, vb);
+                }
+                __syncthreads();
+                if (unc) {
+                    const uint32_t before = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+                    const uint32_t off = (uint32_t)__builtin_popcountll(unc_mask & ((1ull << lane) - 1ull));
+                    wl.q_entries[(size_t)l * wl.q_cap + s_qbase + before + off] = make_uint2(pose_id, i);
+                }
+            }
+        }
+        if (!dirty) block_publish<FUSED>(red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
+        if (LISTED) __syncthreads();            // the next entry reuses the block's LDS
+    }
+}
+
+// ---------------------------------------------------------------- k_search_list: the searches a certifying launch still needs
+// One query per lane, taken from the query lists in order (the entries of a block are consecutive: neighbouring queries stay
+// neighbours): transform, bound by the old neighbours, exact 6-NN, certificate, state update.  No rows: this kernel's registers are
+// the search's alone.
+static __global__ __launch_bounds__(kBlock, 4) void k_search_list(const float4 *__restrict__ src, GridDev g, PoseArg pose1,
+                                                                  const PoseArg *__restrict__ poses, LinArgs a, ListArgs wl,
+                                                                  const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;
+    __shared__ RunList runs[kBlock / kWave];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t l = blockIdx.x & (kWorkLists - 1);
+    const uint32_t n = *wl.qcount(l);
+    const uint2 *list = wl.q_entries + (size_t)l * wl.q_cap;
+    const uint32_t step = (gridDim.x / kWorkLists) * kBlock;
+    for (uint32_t base = (blockIdx.x / kWorkLists) * kBlock; base < n; base += step) {
+        const uint32_t e = base + threadIdx.x;
+        const bool have = e < n;
+        const uint2 en = have ? list[e] : make_uint2(0u, 0u);
+        const uint32_t i = en.y;
+        const PoseArg &P = poses ? poses[en.x] : pose1;
+        uint32_t *st = a.state + (size_t)P.state * kStateRows * a.state_stride;
+        const float4 s4 = have ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t pos6[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pos6[j] = (have && a.warm) ? st[(size_t)j * a.state_stride + i] : kNoIdx;
+        float qx, qy, qz;
+        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
+        Set6 s6;
+        uint32_t cert;
+        lin_search6(g, runs[wave], a, have, a.warm != 0, pos6, qx, qy, qz, s6, cert);
+        if (have) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) st[(size_t)j * a.state_stride + i] = s6.pos[j];
+            st[(size_t)6 * a.state_stride + i] = cert;
+            st[(size_t)7 * a.state_stride + i] = __float_as_uint(qx); st[(size_t)8 * a.state_stride + i] = __float_as_uint(qy);
+            st[(size_t)9 * a.state_stride + i] = __float_as_uint(qz);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- k_full: search + rows in one kernel
+template <int MODE, bool FUSED, bool FAST>
+static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+                                                           PoseArg pose1, const PoseArg *__restrict__ poses,
+                                                           const uint32_t *__restrict__ pose_ids, LinArgs a,
+                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
+                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
+    __shared__ double red[8][kSlots];
+    __shared__ double cnt[kBlock / 64][2];
+    __shared__ int s_role;
+    __shared__ RunList runs[kBlock / kWave];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t pose_id = pose_ids ? pose_ids[blockIdx.y] : blockIdx.y;
+    const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
+    const uint32_t i = vb * kBlock + threadIdx.x;
+    PoseArg P;
+    if (poses) P = poses[pose_id]; else P = pose1;
+    double row[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) row[k] = 0.0;
+    uint8_t flag = 0;
+    const bool have_q = i < n_src;
+    const bool keep = a.state != nullptr && P.state != kNoIdx;              // the pose owns a state
+    const bool old = keep && P.fresh == 0u && a.warm != 0;                  // ... whose old neighbours bound this search
+    uint32_t *st = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride : nullptr;
+    const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t pos6[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pos6[j] = (old && have_q) ? st[(size_t)j * a.state_stride + i] : kNoIdx;
+    float qx, qy, qz;
+    body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
+    Set6 s6;
+    uint32_t cert;
+    lin_search6(g, runs[wave], a, have_q, old, pos6, qx, qy, qz, s6, cert);
+    if (keep && have_q) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) st[(size_t)j * a.state_stride + i] = s6.pos[j];
+        st[(size_t)6 * a.state_stride + i] = cert;
+        st[(size_t)7 * a.state_stride + i] = __float_as_uint(qx); st[(size_t)8 * a.state_stride + i] = __float_as_uint(qy);
+        st[(size_t)9 * a.state_stride + i] = __float_as_uint(qz);
+    }
+    // rows: the queries with a SET certificate gather their five neighbours - the same code k_rows runs
+    KnnResult<5> nn;
+    double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
+    if (have_q && !(cert & 0x80000000u)) {
+        uint32_t pos[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pos[j] = s6.pos[j];
+        flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, r_pt, s_pt);
+    }
+    if (MODE == 1 && have_q) {
+        const uint32_t oi = __float_as_uint(s4.w);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {        // the neighbour list is defined for queries that pass the radius gate (:1726)
+            if (dbg.nn_idx) dbg.nn_idx[5 * (size_t)oi + j] = flag != 0 ? (int32_t)nn.idx[j] : -1;
+            if (dbg.nn_d2) dbg.nn_d2[5 * (size_t)oi + j] = flag != 0 ? nn.d2[j] : __builtin_inff();
+        }
+        if (flag == 1 || flag == 4) {
+            if (dbg.normal) { dbg.normal[3 * (size_t)oi] = nrm[0]; dbg.normal[3 * (size_t)oi + 1] = nrm[1]; dbg.normal[3 * (size_t)oi + 2] = nrm[2]; }
+            if (dbg.r) dbg.r[oi] = r_pt;
+            if (dbg.s) dbg.s[oi] = s_pt;
+        }
+        if (dbg.flag) dbg.flag[oi] = flag;
+        if (dbg.stats) dbg.stats[oi] = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+    }
+    // (the wave's RunList is free now: it stages the rows)
+    wave_rows_to_lds(row, flag, runs[wave].stage, red, cnt);
+    __syncthreads();
+    block_publish<FUSED>(red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
 }
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused

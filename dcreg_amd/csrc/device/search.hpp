@@ -61,27 +61,36 @@ struct GridDev {
 
 struct PoseArg {
     double R[9]; double t[3];
-    uint32_t state;      // batched launches: which warm-start state this pose reads and updates (kNoIdx = search cold); single pose: 0
-    uint32_t pad_;
+    uint32_t state;      // which neighbour state this pose reads and updates (kNoIdx = none: search cold, keep nothing); single pose: 0
+    uint32_t fresh;      // 1: the state holds nothing yet (never searched, or its clouds changed): every query is searched and the old
+                         // contents are not read - a state never needs clearing
 };
-// the pose of a single-pose launch minus the pose of the launch that last wrote the warm-start state (zeros for a fresh state):
-// |dR p + dt| bounds how far source point p has moved since (small-move launches, lin_search).  Kept out of PoseArg: the batched
-// launches copy an array of PoseArg to the device per launch, and that copy is on the device's critical path.
-struct PoseDelta { float dR[9]; float dt[3]; };
-
-static_assert(offsetof(PoseDelta, dt) == offsetof(PoseDelta, dR) + 9 * sizeof(float), "dR and dt are read as 12 consecutive floats");
+// Neighbour state of one source cloud against one target (one per single-pose context, one per Monte-Carlo trial slot):
+//   uint32 [kStateRows][stride]   rows 0-5: positions in the sorted target of the query's 6 nearest neighbours as of its last search,
+//                                 ascending (kNoIdx = fewer were found inside the search bound);
+//                                 rows 7-9: the query's position q0 at that search (the float-stored transform, bit patterns);
+//                                 row 6: the CERTIFICATE of that search, a float s >= 0 (bit pattern) with a mode in the sign bit:
+//     SET (sign 0): while the query stays within s metres of q0 its 5-nearest SET cannot change: s = (a5 - a4) / 2 of the 5th / 6th
+//                   neighbour distances a4 / a5 at q0.  A linearisation at a pose that keeps it there needs no search: it gathers the 5
+//                   points, recomputes the five float distances and sorts them - bitwise what a fresh search returns.
+//     OUT (sign 1): the 5th neighbour was beyond the search radius by s metres (or not found at all inside the slightly larger search
+//                   bound): within s metres of q0 the query fails the radius gate (:1726) and nothing needs to be loaded at all.
+// Nothing of a state changes between two searches of a query, and the test is on the two stored float positions themselves (their
+// difference is exact), so neither the length of a trajectory nor the rounding of the float store wears a certificate down.
+constexpr int kStateRows = 10;
+constexpr uint32_t kCertSearch = 0xFFFFFFFFu;      // (a NaN: no certificate)
 
 struct LinArgs {
     double radius_sq;             // R^2 in double (gate :1726)
-    float radius_sq_f;            // smallest float >= R^2 (candidate prefilter)
+    float radius_sq_f;            // the SEARCH bound: smallest float above (R (1 + cert_margin))^2 - searches cover a little more than
+                                  // the gate radius so that "5th neighbour beyond R" can be certified with some slack
+    float cert_r_out;             // R (1 + 1e-5), rounded up: OUT certificates measure from here
     double max_thick_sq, min_norm, w_slope, w_min;
     int use_wd;
-    int max_ring;                 // rings needed to cover the radius
-    PoseDelta delta;              // small-move launches with a pose known at launch time
-    const PoseDelta *delta_dev;   // ... or, for a launch queued behind the gate, where the gate puts it (null: use `delta`)
-    uint32_t *prev;               // [state][6][prev_stride]: rows 0-4 = sorted-target positions of a query's neighbour set as of its last
-    uint32_t prev_stride;         //   gathering launch (kNoIdx = none), row 5 = bits of the squared distance to the 5th neighbour found by
-                                  //   its last launch of either kind (+inf, or the NaN 0xFFFFFFFF of a fresh state = none); or null
+    int max_ring;                 // rings needed to cover the search bound
+    int warm;                     // searches of a non-fresh state are bounded by the old neighbours' distances from the new position
+    uint32_t *state;              // [state][kStateRows][state_stride], or null (nothing is kept)
+    uint32_t state_stride;
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
@@ -188,6 +197,41 @@ struct HeapFast {
                   [p0] "+v"(pos[0]), [p1] "+v"(pos[1]), [p2] "+v"(pos[2]), [p3] "+v"(pos[3]), [p4] "+v"(pos[4]),
                   [om] "+v"(outside_min), [t] "=&v"(t),
                   [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4)
+                : [x] "v"(d2), [p] "v"(p));
+        } else if constexpr (K == 6) {
+            // the same network one entry longer (25 VALU): the searches of the linearisation keep SIX neighbours - the 6th distance is
+            // what certifies the 5-set against later moves (make_cert)
+            unsigned long long m0, m1, m2, m3, m4, m5;
+            float t;
+            asm("v_cmp_lt_f32_e64 %[m0], %[x], %[d0]\n\t"
+                "v_cmp_lt_f32_e64 %[m1], %[x], %[d1]\n\t"
+                "v_cmp_lt_f32_e64 %[m2], %[x], %[d2]\n\t"
+                "v_cmp_lt_f32_e64 %[m3], %[x], %[d3]\n\t"
+                "v_cmp_lt_f32_e64 %[m4], %[x], %[d4]\n\t"
+                "v_cmp_lt_f32_e64 %[m5], %[x], %[d5]\n\t"
+                "v_max_f32_e32 %[t], %[x], %[d5]\n\t"
+                "v_min_f32_e32 %[om], %[om], %[t]\n\t"
+                "v_med3_f32 %[d5], %[d4], %[d5], %[x]\n\t"
+                "v_med3_f32 %[d4], %[d3], %[d4], %[x]\n\t"
+                "v_med3_f32 %[d3], %[d2], %[d3], %[x]\n\t"
+                "v_med3_f32 %[d2], %[d1], %[d2], %[x]\n\t"
+                "v_med3_f32 %[d1], %[d0], %[d1], %[x]\n\t"
+                "v_min_f32_e32 %[d0], %[d0], %[x]\n\t"
+                "v_cndmask_b32_e64 %[p5], %[p5], %[p], %[m5]\n\t"
+                "v_cndmask_b32_e64 %[p5], %[p5], %[p4], %[m4]\n\t"
+                "v_cndmask_b32_e64 %[p4], %[p4], %[p], %[m4]\n\t"
+                "v_cndmask_b32_e64 %[p4], %[p4], %[p3], %[m3]\n\t"
+                "v_cndmask_b32_e64 %[p3], %[p3], %[p], %[m3]\n\t"
+                "v_cndmask_b32_e64 %[p3], %[p3], %[p2], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p1], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p0], %[m0]\n\t"
+                "v_cndmask_b32_e64 %[p0], %[p0], %[p], %[m0]"
+                : [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [d4] "+v"(d[4]), [d5] "+v"(d[5]),
+                  [p0] "+v"(pos[0]), [p1] "+v"(pos[1]), [p2] "+v"(pos[2]), [p3] "+v"(pos[3]), [p4] "+v"(pos[4]), [p5] "+v"(pos[5]),
+                  [om] "+v"(outside_min), [t] "=&v"(t),
+                  [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5)
                 : [x] "v"(d2), [p] "v"(p));
         } else
 #endif
@@ -996,75 +1040,89 @@ DCREG_DEVFN void plane_fit_qr_fast(const double (&qx)[5], const double (&qy)[5],
     x[2] = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
 }
 
-// ---------------------------------------------------------------- one source point: search, then row
-// Steps 1-2 of an iteration for one query (icp_test_runner.cpp:1716-1726): pose transform (double -> float store), warm
-// bound, exact 5-NN.  `i` = position of the query in the sorted source (index into the warm-start state), `prev` = base of
-// this pose's state ([6][prev_stride]) or null.
+// ---------------------------------------------------------------- one source point: search, certificate, row
+// Step 2 of an iteration for one query (icp_test_runner.cpp:1720-1726) is an exact 5-NN search; the linearisation searches for SIX
+// neighbours and keeps, next to the positions, how far the query may move before the set of the nearest five can change.
 struct PointQuery {
     float qx, qy, qz;     // transformed query, float (utils.hpp:630-636)
     bool reach;           // the query is close enough to the grid for a neighbour inside the radius to exist
 };
 
-// SMALL = false: the warm bound is the largest distance from the new query position to the 5 points its last gathering launch
-//   found (any pose): 5 position loads, 5 point gathers (issued ahead of the pose transform and the cell-table loads), tight
-//   whatever the motion.
-// SMALL = true (the host launches this form when the pose has all but stopped moving - every iteration of a converged
-//   trajectory): the last launch found the 5 neighbours within sqrt(d2_old); the query has moved by |dR p + dt| since, so they lie
-//   within sqrt(d2_old) + |move| of it now (triangle inequality).  One float of state instead of ten dependent loads and five
-//   distances - two memory latencies off the front of every wave - and as tight as the gather when the move is tiny.  Valid for
-//   ANY move (only looser), so a wrong guess of the host costs time, never a neighbour.
-template <bool SMALL>
-DCREG_DEVFN void lin_search(const GridDev &g, RunList &runs, const PoseArg &P, const LinArgs &a, uint32_t *prev, bool have_q,
-                            const float4 &s4, uint32_t i, PointQuery &q, KnnResult<5> &nn, unsigned long long *sst = nullptr) {
-    // warm start: the K-th neighbour distance is at most the largest distance to ANY K distinct target points, so what an earlier
-    // search of this query (same source point, same target) found bounds this search; the result is the same exact set, found
-    // after visiting only the cells that ball touches.
-    const bool warm_any = prev && have_q;
+struct Set6 {
+    uint32_t pos[6];      // positions in the sorted target, ascending distance (kNoIdx = not found inside the bound)
+    float d2[6];          // squared distances (the bound where not found: a lower bound for that neighbour)
+    uint32_t n_eval, n_shell;
+};
+
+// Exact 6 nearest neighbours under `bound_f` (strict).  The 32-bit-key search decides the SET of the nearest five exactly unless the
+// 5th and 6th best distances are equal floats; then - lattices, duplicated points - the 64-bit-key search (distance, original index)
+// is run for this lane and its first five entries are the canonical set.  (A tie between the 6th best and a point outside does not
+// matter: neither belongs to the five, and both are at the distance the certificate uses.)
+DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, Set6 &out) {
+    HeapFast<6> hf;
+    knn_search<HeapFast<6>>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
+    out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
+    if (hf.pos[5] != kNoIdx && hf.d[4] == hf.d[5]) {
+        HeapExact<6> he;
+        knn_search<HeapExact<6>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
+        out.n_eval += he.n_eval;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { out.pos[j] = he.pos[j]; out.d2[j] = he.dist(j); }
+    }
+}
+
+// The certificate of a search (kStateRows comment above).  a4 / a5 = distances of the 5th / 6th neighbour, or - where the search
+// found fewer inside its bound - the bound, which every point it did not return lies beyond.  All distances are floats of
+// dist2_nofma (within 3e-7 relative of the real squared distance) and of a 1-ulp square root, i.e. within 2.1e-7 of the real distance:
+// each enters with a 2e-6 relative margin on its bad side, so that a certified set also keeps a 5th / 6th FLOAT distance gap of
+// > 1.7e-6 (a4 + a5) wherever the certificate holds - ten times what the rounding of the fresh distances can close.
+DCREG_DEVFN uint32_t make_cert(const Set6 &s, const LinArgs &a) {
+    const float a4 = sqrt_approx(s.d2[4]), a5 = sqrt_approx(s.d2[5]);
+    const float s_out = a4 * 0.999998f - a.cert_r_out;                                          // > 0: the 5th neighbour is beyond the gate radius
+    const float s_set = s.pos[4] != kNoIdx ? 0.5f * (a5 * 0.999998f - a4 * 1.000002f) : -1.f;
+    if (s_out > 0.f && s_out >= s_set) return __float_as_uint(s_out) | 0x80000000u;
+    return __float_as_uint(fmaxf(s_set, 0.f));                                                   // 0: valid now, to be searched again next time
+}
+
+// A later linearisation of the same query: does the certificate of its last search still hold at the new position?  The displacement
+// is the difference of two stored floats per coordinate - exact unless a coordinate changed by more than a factor of two, and then it is
+// rounded to 6e-8 relative -; its squared length and the square of s round at 1e-7: a 1e-5 relative margin covers all of it.
+DCREG_DEVFN bool cert_holds(uint32_t cert, float q0x, float q0y, float q0z, float qx, float qy, float qz) {
+    const float dx = qx - q0x, dy = qy - q0y, dz = qz - q0z;
+    const float m2 = (dx * dx + dy * dy + dz * dz) * 1.00001f;
+    const float s = __uint_as_float(cert & 0x7FFFFFFFu);            // kCertSearch is a NaN: the comparison below is false
+    return m2 < s * s;
+}
+
+// Bound of a search from what the last one found: the 6th-neighbour distance is at most the largest distance to ANY six distinct
+// target points.  oldpos = the state's six positions (all valid).  Inclusive bound for a strict '<' heap: the next float up.
+DCREG_DEVFN float warm_bound6(const GridDev &g, const uint32_t (&oldpos)[6], float qx, float qy, float qz, float bound) {
+    float4 pv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pv[j] = g.pts[oldpos[j]];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m = fmaxf(m, dist2_nofma(qx, qy, qz, pv[j]));
+    const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
+    return fminf(bound, incl);
+}
+
+// search of one query inside a linearisation: bound (warm or cold), reach test, 6-NN, certificate
+DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, bool have_q, bool warm, const uint32_t (&oldpos)[6],
+                             float qx, float qy, float qz, Set6 &st, uint32_t &cert) {
     float bound = a.radius_sq_f;
-    if (SMALL) {
-        const float w_old = warm_any ? __uint_as_float(prev[(size_t)5 * a.prev_stride + i]) : __builtin_inff();
-        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
-        const PoseDelta &D = a.delta_dev ? *a.delta_dev : a.delta;
-        const float mx = D.dR[0] * s4.x + D.dR[1] * s4.y + D.dR[2] * s4.z + D.dt[0];
-        const float my = D.dR[3] * s4.x + D.dR[4] * s4.y + D.dR[5] * s4.z + D.dt[1];
-        const float mz = D.dR[6] * s4.x + D.dR[7] * s4.y + D.dR[8] * s4.z + D.dt[2];
-        // conservative: 1e-5 relative on both lengths (the float chains round at ~1e-7), the float store of the two query
-        // positions (half an ulp per coordinate each), and a floor that keeps the bound a normal float
-        const float move = sqrt_approx(mx * mx + my * my + mz * mz) * 1.00001f + 4e-7f * (fabsf(q.qx) + fabsf(q.qy) + fabsf(q.qz)) + 1e-15f;
-        const float b = sqrt_approx(w_old) * 1.00001f + move;          // +inf stays +inf, NaN (fresh state) stays NaN: no bound below
-        bound = fminf(bound, b * b * 1.00001f);
-    } else {
-        uint32_t pp[5];
-        float4 pv[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) pp[j] = warm_any ? prev[(size_t)j * a.prev_stride + i] : kNoIdx;
-        const bool warm = pp[4] != kNoIdx;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) pv[j] = warm ? g.pts[pp[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
-        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, q.qx, q.qy, q.qz);
-        if (warm) {
-            float m = 0.f;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) m = fmaxf(m, dist2_nofma(q.qx, q.qy, q.qz, pv[j]));
-            // inclusive bound for a strict '<' heap: next float above m (m >= 0, finite)
-            const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
-            bound = fminf(bound, incl);
-        }
-    }
-    const double fx = ((double)q.qx - g.ox) * g.inv_h, fy = ((double)q.qy - g.oy) * g.inv_h, fz = ((double)q.qz - g.oz) * g.inv_h;
+    if (warm && oldpos[5] != kNoIdx) bound = warm_bound6(g, oldpos, qx, qy, qz, bound);
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)a.max_ring + 1.0;
-    // a query farther than max_ring cells from the grid has no neighbour inside the radius
-    q.reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
-    nn.full = false; nn.n_eval = 0; nn.n_shell = 1;
-    if (q.reach) knn_exact<5>(g, runs, q.qx, q.qy, q.qz, bound, a.max_ring, nn, sst);
-    if (warm_any) {
-        const bool keep = q.reach && nn.full;
-        if (!SMALL) {       // (a small-move launch leaves the positions of the last gathering launch: older, still valid)
+    // a query farther than max_ring cells from the grid has no neighbour inside the search bound
+    const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) prev[(size_t)j * a.prev_stride + i] = keep ? nn.pos[j] : kNoIdx;
-        }
-        prev[(size_t)5 * a.prev_stride + i] = keep ? __float_as_uint(nn.d2[4]) : 0x7F800000u;
-    }
+    for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
+    st.n_eval = 0; st.n_shell = 1;
+    if (reach) search6(g, runs, qx, qy, qz, bound, a.max_ring, st);
+    cert = make_cert(st, a);
 }
 
 // Steps 3-5 for one query with its neighbour set (icp_test_runner.cpp:1727-1812, 1863-1907): plane fit, gates, weight,
@@ -1146,6 +1204,39 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
     row[6] = b;
     row[7] = r;
     return 1;
+}
+
+// Steps 2b-5 for a query whose nearest-five SET is known (pos: positions in the sorted target, any order): gather the points,
+// recompute the float distances from the query's current position, put them into the canonical (distance, original index) order -
+// bitwise the result list of a fresh search at this pose - and build the row.  `nn` receives the ordered set (debug dumps).
+template <bool FASTMATH>
+DCREG_DEVFN uint8_t row_from_set(const GridDev &g, const PoseArg &P, const LinArgs &a, const float4 &s4, float qx, float qy, float qz,
+                                 const uint32_t (&pos)[5], KnnResult<5> &nn, double (&row)[8], double (&nrm)[3], double &r_out, double &s_out) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { nn.pos[j] = pos[j]; nn.pt[j] = g.pts[pos[j]]; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nn.d2[j] = dist2_nofma(qx, qy, qz, nn.pt[j]);
+    // sorting network of 9 compare-exchanges on the key (distance bits, original index): distances are >= 0, so their bit patterns
+    // order like the values
+    auto cswap = [&](int x, int y) {
+        const uint64_t kx = ((uint64_t)__float_as_uint(nn.d2[x]) << 32) | __float_as_uint(nn.pt[x].w);
+        const uint64_t ky = ((uint64_t)__float_as_uint(nn.d2[y]) << 32) | __float_as_uint(nn.pt[y].w);
+        const bool sw = ky < kx;
+        const float dx = nn.d2[x], dy = nn.d2[y];
+        const float4 px = nn.pt[x], py = nn.pt[y];
+        const uint32_t ox = nn.pos[x], oy = nn.pos[y];
+        nn.d2[x] = sw ? dy : dx; nn.d2[y] = sw ? dx : dy;
+        nn.pt[x].x = sw ? py.x : px.x; nn.pt[x].y = sw ? py.y : px.y; nn.pt[x].z = sw ? py.z : px.z; nn.pt[x].w = sw ? py.w : px.w;
+        nn.pt[y].x = sw ? px.x : py.x; nn.pt[y].y = sw ? px.y : py.y; nn.pt[y].z = sw ? px.z : py.z; nn.pt[y].w = sw ? px.w : py.w;
+        nn.pos[x] = sw ? oy : ox; nn.pos[y] = sw ? ox : oy;
+    };
+    cswap(0, 1); cswap(3, 4); cswap(2, 4); cswap(2, 3); cswap(0, 3); cswap(0, 2); cswap(1, 4); cswap(1, 3); cswap(1, 2);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nn.idx[j] = __float_as_uint(nn.pt[j].w);
+    nn.full = true; nn.n_eval = 0; nn.n_shell = 0;
+    PointQuery q;
+    q.qx = qx; q.qy = qy; q.qz = qz; q.reach = true;
+    return lin_row<FASTMATH>(P, a, s4, q, nn, row, nrm, r_out, s_out);
 }
 
 // The 31 sums' contribution of one point, from its row and flag: [0..20] upper triangle of A A^T (row-major), [21..26]

@@ -14,7 +14,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../../include/dcreg.h"
+#include "../../../include/dcreg_debug.h"
 #include "linalg.hpp"
 #include "se3.hpp"
 
@@ -479,6 +479,7 @@ size_t dcreg_sizeof(const char *name) {
     if (!std::strcmp(name, "dcreg_iter_log")) return sizeof(dcreg_iter_log);
     if (!std::strcmp(name, "dcreg_icp_result")) return sizeof(dcreg_icp_result);
     if (!std::strcmp(name, "dcreg_trial_result")) return sizeof(dcreg_trial_result);
+    if (!std::strcmp(name, "dcreg_launch_stats")) return sizeof(dcreg_launch_stats);
     return 0;
 }
 

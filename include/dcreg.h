@@ -87,21 +87,6 @@ typedef struct dcreg_lin_out {
     int64_t n_pt;       /* correspondence_pt_count (:1731) -> fitness */
 } dcreg_lin_out;
 
-/* per-point dump for parity tests (original source order; any pointer may be NULL).
- * flag: 1 valid, 0 radius/knn gate, 2 |x|<min_normal_norm, 3 plane thickness, 4 weight<=weight_min */
-typedef struct dcreg_lin_debug {
-    int32_t *nn_idx; /* [5*n] original target indices, ascending (d2, idx); -1 = none */
-    float *nn_d2;    /* [5*n] */
-    uint8_t *flag;   /* [n] */
-    double *normal;  /* [3*n] */
-    double *r;       /* [n] */
-    double *s;       /* [n] */
-    uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 */
-    uint64_t *clocks; /* [16 * ceil(n/64)] per-wave shader-clock stamps: start, query ready, search done, rows done,
-                         wave reduced, end, packed search sub-phases, hw block id; [8..11] ring walk of lane 0: cycles in
-                         candidate scans, cycles waiting for table entries, row iterations, scans; [12..15] unused */
-} dcreg_lin_debug;
-
 typedef struct dcreg_index_info {
     double cell;        /* grid cell edge (m) */
     double origin[3];
@@ -118,20 +103,23 @@ void dcreg_backend_destroy(dcreg_ctx *);
 const char *dcreg_last_error(const dcreg_ctx *);
 /* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream */
 int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
-/* options: "cell" (force grid cell edge, 0 = auto), "cell_factor" (auto = factor * est. 5th-NN distance),
- * "time_kernels" (N > 0 = bracket every N-th linearisation with HIP events, 0 = off), "spin" (1 = wait on the pinned
- * result flag instead of hipStreamSynchronize, default), "warm_start" (1 = bound each search by the previous neighbour
- * set, default; results are identical either way), "gap_field" (1 = build the empty-space distance field at the next
- * dcreg_set_target, default; results are identical either way), "fast_plane_fit" (1 = the reduced-instruction plane fit,
- * default; 0 = the Eigen-shaped factorisation step for step; planes agree to a few ulp), "xcd_chunk" (query-block -> XCD
- * mapping: 0 = one contiguous run per XCD, c = runs of c blocks round-robin), "x_subdiv" (1 / 2 / 4 / 8 / 16 = x sub-cells per grid cell
- * at the next dcreg_set_target, default 8: candidate runs are trimmed to the sub-cell; results are identical either way),
- * "small_move" (fraction of a cell edge, default 0.05, 0 = never: a single-pose launch whose pose change moves no source point
- * farther than that bounds each search by the old 5th-neighbour distance plus the point's move instead of gathering the old
- * neighbours; results are identical either way);
- * experiment knobs: "lds_pad" (extra dynamic LDS
- * bytes per block), "keep_source_order" (1 = the next dcreg_set_source keeps the caller's point order instead of the
- * Hilbert sort) */
+/* options (every one of them changes speed only: results are identical whatever their values)
+ *   "warm_start"    1 (default) = keep, per source point, the neighbours its last search found and a certificate of how far the
+ *                   point may move before the nearest five can change; later linearisations skip the search of every point whose
+ *                   certificate still holds and bound the searches that remain by the old neighbours.  0 = search every point
+ *                   from scratch in every call;
+ *   "cert_move"     fraction of a grid cell edge, default 0.5, 0 = never: a single-pose launch whose pose change moves no source point
+ *                   farther than that tests certificates first (k_rows + work lists); a larger change searches everything at once;
+ *   "cert_margin"   default 0.05: searches cover search_radius * (1 + margin), so that "the 5th neighbour is beyond the radius" can
+ *                   be certified too (takes effect at the next dcreg_set_target: the grid cells follow the search radius);
+ *   "fast_plane_fit" 1 (default) = the reduced-instruction 5x3 plane fit; 0 = the Eigen-shaped factorisation step for step (planes
+ *                   agree to a few ulp, gate flags are identical on every test scene);
+ *   "spin"          1 (default) = wait for results on the pinned result flags instead of hipStreamSynchronize;
+ *   "wait_seconds"  default 30: how long a result is awaited before the stream is drained to look for a device fault;
+ *   "cell", "cell_factor", "x_subdiv", "gap_field": the grid index (cell edge in metres, 0 = auto = cell_factor x the estimated
+ *                   5th-neighbour distance; x sub-cells per cell 1..16, default 8; 1 = build the empty-space distance field) at the
+ *                   next dcreg_set_target.
+ * Profiling / experiment knobs are listed in dcreg_debug.h. */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
  * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */
@@ -155,28 +143,27 @@ int dcreg_linearize_batch_begin(dcreg_ctx *, int slot, int n_poses, const double
  * calls the queued linearisation off (it returns without touching results or warm state).  Exactly one of the two must follow every
  * _gated_begin, before anything else is queued on the context (other launches are refused meanwhile); results come through
  * dcreg_linearize_batch_end(slot).  Needs the default "spin" option (a stream synchronise would wait for the gate).  A gate nobody
- * opens gives up after ~5 s. */
+ * opens gives up after two minutes. */
 int dcreg_linearize_gated_begin(dcreg_ctx *, int slot, const dcreg_lin_params *);
 int dcreg_linearize_gate_open(dcreg_ctx *, const double R[9], const double t[3]);
 int dcreg_linearize_gate_abort(dcreg_ctx *);
 int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
-/* Warm-start states for batched launches.  A single-pose linearisation bounds its search by the neighbour set its own
- * previous call found (kept inside the ctx); poses of a batch belong to different trajectories, so each needs a state of
- * its own: reserve n_states of them (20 B per source point each; all reset to "none"), then name the state of every pose in
- * state_ids (0 <= id < n_states, each id at most once per launch, -1 = search cold).  A state is read and overwritten by
- * the launch, so consecutive launches of one Monte-Carlo trial under the same id search warm.  Results are identical with
- * or without states (the bound only prunes).  dcreg_set_target / dcreg_set_source drop all states. */
+/* Neighbour states for batched launches.  A single-pose linearisation reuses what its own previous call found (neighbours +
+ * certificates, kept inside the ctx); poses of a batch belong to different trajectories, so each needs a state of its own:
+ * reserve n_states of them (40 B per source point each; nothing is cleared - a state counts as empty until its first launch
+ * has filled it), then name the state of every pose in state_ids (0 <= id < n_states, each id at most once per launch,
+ * -1 = search from scratch, keep nothing).  A state is read and updated by the launch, so consecutive launches of one
+ * Monte-Carlo trial under the same id skip the searches their certificates cover.  dcreg_reset_warm_state marks one state
+ * empty again (a trial slot that takes the next trial).  Results are identical with or without states.
+ * dcreg_set_target / dcreg_set_source drop all states. */
 int dcreg_reserve_warm_states(dcreg_ctx *, int64_t n_states);
+int dcreg_reset_warm_state(dcreg_ctx *, int64_t state_id);
 int dcreg_linearize_batch_begin_warm(dcreg_ctx *, int slot, int n_poses, const double *R9, const double *t3,
                                      const int32_t *state_ids, const dcreg_lin_params *);
-int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], const dcreg_lin_params *,
-                          dcreg_lin_out *, dcreg_lin_debug *);
 /* exact k-NN (k = 1 or 5) of host queries against the target index; float sq. distances, (d2, idx) order */
 int dcreg_knn(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_floats, int k, double max_radius,
               int32_t *idx, float *d2);
 int dcreg_index_info_get(const dcreg_ctx *, dcreg_index_info *);
-/* mean duration (ms, HIP events on the ctx stream) of the linearisation kernels since the last reset */
-int dcreg_kernel_time(dcreg_ctx *, double *ms_total, int64_t *launches, int reset);
 
 /* ---------------- solver seam (host only, no device needed) ---------------- */
 /* Config + ICPParameters subset (utils.hpp:82-171) */

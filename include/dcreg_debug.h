@@ -1,0 +1,55 @@
+/*
+ * dcreg_debug.h -- test, profiling and experiment hooks of libdcreg_hip.so.  NOT part of the drop-in boundary (dcreg.h is; see
+ * INTEGRATION.md): nothing a maintainer of the reference binds lives here.  Used by tests/, bench.py and scripts/.
+ */
+#ifndef DCREG_DEBUG_H
+#define DCREG_DEBUG_H
+
+#include "dcreg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-point dump for parity tests (original source order; any pointer may be NULL).
+ * flag: 1 valid, 0 radius/knn gate, 2 |x|<min_normal_norm, 3 plane thickness, 4 weight<=weight_min.
+ * nn_idx / nn_d2 are the reference's result list of nearestKSearch (icp_test_runner.cpp:1722) for the points that pass its radius
+ * gate (:1726, flag != 0); for the others (flag 0) the reference never looks at the list and the dump holds -1 / +inf. */
+typedef struct dcreg_lin_debug {
+    int32_t *nn_idx; /* [5*n] original target indices, ascending (d2, idx); -1 = none */
+    float *nn_d2;    /* [5*n] */
+    uint8_t *flag;   /* [n] */
+    double *normal;  /* [3*n] */
+    double *r;       /* [n] */
+    double *s;       /* [n] */
+    uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 */
+} dcreg_lin_debug;
+
+/* dcreg_linearize with the dump; always searches every point (k_full), shares the ctx's neighbour state with the plain calls */
+int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], const dcreg_lin_params *,
+                          dcreg_lin_out *, dcreg_lin_debug *);
+
+/* total duration (ms, HIP events on the ctx stream around ALL kernels of a linearisation) of the timed linearisations since the
+ * last reset, and their number; option "time_kernels" = N > 0 brackets every N-th linearisation of slot 0 (an event pair costs ~10 us
+ * of host time), 0 = off */
+int dcreg_kernel_time(dcreg_ctx *, double *ms_total, int64_t *launches, int reset);
+
+/* how the linearisations since the last reset were carried out */
+typedef struct dcreg_launch_stats {
+    int64_t poses_searched;      /* poses linearised by searching every point (k_full) */
+    int64_t poses_certified;     /* poses linearised by testing certificates first (k_rows + work lists) */
+    int64_t last_queries_listed; /* the most recent certifying launch the device has reported on: points it had to search ... */
+    int64_t last_blocks_listed;  /* ... and 256-point blocks it had to redo after those searches */
+} dcreg_launch_stats;
+int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
+
+/* experiment knobs of dcreg_set_option (defaults are what the product runs with):
+ *   "time_kernels"       see dcreg_kernel_time;
+ *   "xcd_chunk"          query-block -> XCD mapping: 0 = one contiguous run of query blocks per XCD, c = runs of c blocks dealt
+ *                        round-robin (default 16);
+ *   "keep_source_order"  1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert-curve sort. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCREG_DEBUG_H */

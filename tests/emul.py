@@ -18,7 +18,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 class LinParams(C.Structure):
     _fields_ = [("search_radius", C.c_double), ("max_plane_thickness_sq", C.c_double), ("min_normal_norm", C.c_double),
                 ("weight_slope", C.c_double), ("weight_min", C.c_double), ("use_weight_derivative", C.c_int32),
-                ("fast_plane_fit", C.c_int32)]
+                ("fast_plane_fit", C.c_int32), ("cert_margin", C.c_double)]
 
 
 def build(force=False):
@@ -41,7 +41,7 @@ def lib():
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
-                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_double] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64]
+                                    C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_plane_fit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         _lib = L
@@ -66,15 +66,20 @@ def plane_fit(Q, fast):
     return x
 
 
+CERT_MARGIN = 0.05      # dcreg_ctx::opt_cert_margin
+CERT_MOVE = 0.5         # dcreg_ctx::opt_cert_move
+
+
 class Index:
     """The device's grid index over a target cloud, built on the host."""
 
-    def __init__(self, xyz, radius, cell=0.0, cell_factor=2.0, gap_field=True, x_subdiv=8):
-        """gap_field: True / False = with / without the empty-space distance field (the block occupancy bitmap is built either
-        way); -1 = neither structure."""
+    def __init__(self, xyz, radius, cell=0.0, cell_factor=2.0, gap_field=True, x_subdiv=8, cert_margin=CERT_MARGIN):
+        """gap_field: True / False = with / without the empty-space distance field."""
         self.xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         self.radius = radius
-        self.ptr = lib().emu_index_build(_ptr(self.xyz), len(self.xyz), float(radius), float(cell), float(cell_factor), int(gap_field), int(x_subdiv))
+        self.cert_margin = cert_margin
+        # the cells are sized for the search radius R (1 + margin), as context.hip set_target
+        self.ptr = lib().emu_index_build(_ptr(self.xyz), len(self.xyz), float(radius) * (1.0 + cert_margin), float(cell), float(cell_factor), int(gap_field), int(x_subdiv))
         h, dims, nc, gc = C.c_double(), (C.c_int32 * 3)(), C.c_int64(), C.c_int32()
         lib().emu_index_info(self.ptr, C.byref(h), dims, C.byref(nc), C.byref(gc))
         self.cell, self.dims, self.n_cells, self.gap_cap = h.value, tuple(dims), nc.value, gc.value
@@ -95,7 +100,7 @@ def knn(index, q, k=5, max_radius=0.0):
 
 
 class Source:
-    """A source cloud in the device's processing order (Hilbert curve of the body-frame position) + its warm-start state."""
+    """A source cloud in the device's processing order (Hilbert curve of the body-frame position) + its neighbour state."""
 
     def __init__(self, xyz, hilbert=True):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
@@ -103,24 +108,37 @@ class Source:
         self.sorted = np.ascontiguousarray(xyz[self.order])
         self.n = len(xyz)
         self.stride = (self.n + 63) & ~63
+        self.radius_body = float(np.sqrt((np.abs(xyz).max(axis=0).astype(np.float64) ** 2).sum())) if len(xyz) else 0.0
         self.reset_warm()
 
     def reset_warm(self):
-        """state = neighbour positions (last gathering launch) + squared 5th-neighbour distance, pose and index of the last launch"""
-        self.prev, self.prev_pose, self.prev_index = None, None, None
+        """state = 6 neighbour positions + certificate + search position per query (search.hpp kStateRows), the pose of the last launch, the index"""
+        self.state, self.prev_pose, self.prev_index = None, None, None
+        self.searched = 0          # queries searched by the last linearisation
 
 
-def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0, small_move=0.05):
+def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0, cert_move=CERT_MOVE,
+              plan=None):
     """One linearisation through the device functions on the host -> dict like Context.linearize (+ "stats" [n, 8] in
-    processing order: candidates, outermost shell, table loads, rows, runs, trips, faces, face skips)."""
+    processing order: candidates, outermost shell, table loads, rows, runs, trips, faces, face skips).
+    plan: None = as context.hip decides ("full" on a fresh state / debug / a pose change that may move a point farther than cert_move
+    cells, else "cert"), or force "full" / "cert" (a fresh state is always searched in full)."""
     radius = index.radius if radius is None else radius
-    prm = LinParams(radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, int(wd), int(fast))
+    prm = LinParams(radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, int(wd), int(fast), index.cert_margin)
     n = source.n
-    if warm and (source.prev is None or source.prev_index is not index):      # a new target voids the stored distances
-        st = np.full((6, source.stride), 0xFFFFFFFF, np.uint32)      # as context.hip clear_states: row 5 starts as a NaN = "none"
-        source.prev, source.prev_pose, source.prev_index = st.reshape(-1), None, index
-    prev = source.prev if warm else None
-    prev_pose = source.prev_pose if warm else None
+    fresh = source.state is None or source.prev_index is not index      # a new target voids positions and certificates
+    if warm and fresh:
+        source.state = np.full(10 * source.stride, 0xA5A5A5A5, np.uint32)      # garbage on purpose: a fresh state is never read
+        source.prev_pose, source.prev_index = None, index
+    state = source.state if warm else None
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    pose = np.concatenate([R, t])
+    delta, certify = None, 0
+    if warm and not fresh and source.prev_pose is not None:
+        delta = pose - source.prev_pose
+        max_move = np.sqrt((delta[:9] ** 2).sum()) * source.radius_body + np.sqrt((delta[9:] ** 2).sum())
+        certify = int(cert_move > 0 and max_move <= cert_move * index.cell and not debug) if plan is None else int(plan == "cert")
     out = np.zeros(32)
     keep = {}
     if debug:
@@ -128,15 +146,17 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
                 "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n)}
     st = np.zeros((n, 8), np.uint32) if stats else None
     tr = np.zeros((n, trace_cap), np.uint32) if trace_cap else None
-    R = np.ascontiguousarray(R, np.float64).reshape(9)
-    t = np.ascontiguousarray(t, np.float64).reshape(3)
-    lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(prev), source.stride, _ptr(prev_pose), float(small_move),
-                        _ptr(out), _ptr(keep.get("nn_idx")), _ptr(keep.get("nn_d2")), _ptr(keep.get("flag")), _ptr(keep.get("normal")),
-                        _ptr(keep.get("r")), _ptr(keep.get("s")), _ptr(st), _ptr(tr), int(trace_cap))
+    counts = np.zeros(2, np.int64)
+    rc = lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(state), source.stride,
+                             int(fresh), certify, int(bool(warm)),
+                             _ptr(out), _ptr(keep.get("nn_idx")), _ptr(keep.get("nn_d2")), _ptr(keep.get("flag")), _ptr(keep.get("normal")),
+                             _ptr(keep.get("r")), _ptr(keep.get("s")), _ptr(st), _ptr(tr), int(trace_cap), _ptr(counts))
+    assert rc == 0
     if warm:
-        source.prev_pose = np.concatenate([R, t])
+        source.prev_pose = pose
+    source.searched = int(counts[0])
     res = {"H_upper": out[:21].copy(), "g": out[21:27].copy(), "sum_r2": out[27], "sum_b2": out[28], "n_eff": int(round(out[29])),
-           "n_pt": int(round(out[30]))}
+           "n_pt": int(round(out[30])), "searched": int(counts[0]), "plan": "cert" if certify else "full"}
     res.update(keep)
     if stats:
         res["stats"] = st

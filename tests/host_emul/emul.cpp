@@ -182,60 +182,97 @@ void emu_hilbert_order(const float *xyz, int64_t n, uint32_t *order) {
 struct EmuLinParams {
     double search_radius, max_plane_thickness_sq, min_normal_norm, weight_slope, weight_min;
     int32_t use_weight_derivative, fast_plane_fit;
+    double cert_margin;
 };
 
 // One linearisation of `n` queries (src_xyz in the order given; order[i] = original index written into the per-point
-// outputs, or null for identity).  prev: [6][prev_stride] warm-start state, read and updated (null = cold).
+// outputs, or null for identity), replaying what the kernels of kernels.hpp do per query.
+//   state   : [kStateRows][stride] neighbour state, read and updated (null = keep nothing); fresh != 0: it holds nothing yet
+//   certify : 0 = k_full (search every query, bounded by the old neighbours when the state has some);
+//             1 = k_rows / k_search_list / k_rows<LISTED>: test every certificate at the query's new position, search only the
+//                 queries whose certificate does not hold there
 // out32: 21 H + 6 g + sum r^2 + sum b^2 + n_eff + n_pt.  Per-point outputs may be null.  stats: [n][8] counters
-// {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}.
+// {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}; counts[0] = queries searched.
 int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_t n, const double R[9], const double t[3],
-                  const EmuLinParams *p, uint32_t *prev, int64_t prev_stride, const double *prev_pose12, double small_move_frac, double *out32, int32_t *nn_idx, float *nn_d2,
-                  uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats, uint32_t *trace, int64_t trace_cap_per_query) {
+                  const EmuLinParams *p, uint32_t *state, int64_t stride, int fresh, int certify, int warm,
+                  double *out32, int32_t *nn_idx, float *nn_d2,
+                  uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats, uint32_t *trace, int64_t trace_cap_per_query,
+                  int64_t *counts) {
     EmuIndex *E = (EmuIndex *)idx;
     const GridDev &g = E->g;
     LinArgs a{};
     a.radius_sq = p->search_radius * p->search_radius;
-    float rf = (float)a.radius_sq;
-    if ((double)rf < a.radius_sq) rf = std::nextafterf(rf, INFINITY);
-    a.radius_sq_f = std::nextafterf(rf, INFINITY);
+    {   // as context.hip make_lin_args
+        const double rs = p->search_radius * (1.0 + p->cert_margin), r2 = rs * rs;
+        float rf = (float)r2;
+        if ((double)rf < r2) rf = std::nextafterf(rf, INFINITY);
+        a.radius_sq_f = std::nextafterf(rf, INFINITY);
+        float ro = (float)(p->search_radius * (1.0 + 1e-5));
+        if ((double)ro < p->search_radius * (1.0 + 1e-5)) ro = std::nextafterf(ro, INFINITY);
+        a.cert_r_out = ro;
+    }
     a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm; a.w_slope = p->weight_slope; a.w_min = p->weight_min;
     a.use_wd = p->use_weight_derivative;
     int k = 1;
     while (k < 100000) { const double safe = (double)k * g.h * (1.0 - 1e-9); if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break; ++k; }
     a.max_ring = k;
-    a.prev = prev; a.prev_stride = (uint32_t)prev_stride; a.euler = 0;
+    a.warm = warm;
+    a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0;
     PoseArg P{};
     std::memcpy(P.R, R, sizeof(P.R)); std::memcpy(P.t, t, sizeof(P.t));
-    bool small = false;
-    {   // prev_pose12 = R (9) and t (3) of the launch that last wrote the state, or null for a fresh state (context.hip pose_delta)
-        double fro = 0.0, tr = 0.0, mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-        for (int k = 0; k < 9; ++k) { const double d = prev_pose12 ? R[k] - prev_pose12[k] : 0.0; a.delta.dR[k] = (float)d; fro += d * d; }
-        for (int k = 0; k < 3; ++k) { const double d = prev_pose12 ? t[k] - prev_pose12[9 + k] : 0.0; a.delta.dt[k] = (float)d; tr += d * d; }
-        for (int64_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], (double)src_xyz[3 * i + c]); mx[c] = std::max(mx[c], (double)src_xyz[3 * i + c]); }
-        double r2 = 0.0;
-        for (int c = 0; c < 3; ++c) { const double m = std::max(std::fabs(mn[c]), std::fabs(mx[c])); r2 += m * m; }
-        small = prev && prev_pose12 && small_move_frac > 0.0 && std::sqrt(fro) * std::sqrt(r2) + std::sqrt(tr) <= small_move_frac * g.h;
-    }
+    P.state = state ? 0u : kNoIdx; P.fresh = fresh ? 1u : 0u;
+    if (certify && (!state || fresh)) return -1;
     static thread_local RunList runs;
     double tot[31];
     for (double &v : tot) v = 0.0;
     threadIdx.x = 0;
+    int64_t n_searched = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t oi = order ? order[i] : (uint32_t)i;
         const float4 s4{src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], __uint_as_float(oi)};
-        PointQuery q;
-        KnnResult<5> nn;
         emu_stats = EmuStats{};
         if (trace) { emu_trace.buf = trace + (size_t)i * (size_t)trace_cap_per_query; emu_trace.cap = (uint32_t)trace_cap_per_query - 1; emu_trace.n = 0; }
-        if (small) lin_search<true>(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
-        else lin_search<false>(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
+        float qx, qy, qz;
+        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
+        uint32_t cert = kCertSearch, pos6[6];
+        for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
+        const bool old = state && !fresh;
+        bool need = true;
+        if (certify) {                           // k_rows<LISTED = false>: does the certificate hold here?
+            cert = state[(size_t)6 * stride + i];
+            need = !cert_holds(cert, __uint_as_float(state[(size_t)7 * stride + i]), __uint_as_float(state[(size_t)8 * stride + i]),
+                               __uint_as_float(state[(size_t)9 * stride + i]), qx, qy, qz);
+        }
+        if (old && (certify || warm)) for (int j = 0; j < 6; ++j) pos6[j] = state[(size_t)j * stride + i];
+        Set6 s6{};
+        if (need) {                              // k_search_list / k_full
+            uint32_t c2;
+            uint32_t bpos[6];
+            for (int j = 0; j < 6; ++j) bpos[j] = warm ? pos6[j] : kNoIdx;
+            lin_search6(g, runs, a, true, warm && old, bpos, qx, qy, qz, s6, c2);
+            cert = c2;
+            for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
+            if (state) {
+                for (int j = 0; j < 6; ++j) state[(size_t)j * stride + i] = s6.pos[j];
+                state[(size_t)6 * stride + i] = c2;
+                state[(size_t)7 * stride + i] = __float_as_uint(qx); state[(size_t)8 * stride + i] = __float_as_uint(qy); state[(size_t)9 * stride + i] = __float_as_uint(qz);
+            }
+            ++n_searched;
+        }
         if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
         double row[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
-        const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, row, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, row, nrm, rr, ss);
+        uint8_t fl = 0;
+        KnnResult<5> nn{};
+        if (!(cert & 0x80000000u)) {             // SET: rows from the five positions (k_rows / k_full)
+            uint32_t pos[5];
+            for (int j = 0; j < 5; ++j) pos[j] = pos6[j];
+            fl = p->fast_plane_fit ? row_from_set<true>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, rr, ss)
+                                   : row_from_set<false>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, rr, ss);
+        }
         row_products(row, fl, acc);
         for (int j = 0; j < 31; ++j) tot[j] += acc[j];
-        if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = (q.reach && nn.idx[j] != kNoIdx) ? (int32_t)nn.idx[j] : -1;
-        if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = (q.reach && nn.idx[j] != kNoIdx) ? nn.d2[j] : INFINITY;
+        if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = fl != 0 ? (int32_t)nn.idx[j] : -1;
+        if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = fl != 0 ? nn.d2[j] : INFINITY;
         if (flag_out) flag_out[oi] = fl;
         if (fl == 1 || fl == 4) {
             if (normal) { normal[3 * (size_t)oi] = nrm[0]; normal[3 * (size_t)oi + 1] = nrm[1]; normal[3 * (size_t)oi + 2] = nrm[2]; }
@@ -244,12 +281,13 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         }
         if (stats) {
             uint32_t *s = stats + 8 * (size_t)i;      // in processing order (the wave model groups consecutive queries)
-            s[0] = nn.n_eval; s[1] = nn.n_shell; s[2] = emu_stats.table_loads; s[3] = emu_stats.rows; s[4] = emu_stats.runs;
+            s[0] = s6.n_eval; s[1] = need ? s6.n_shell : 0; s[2] = emu_stats.table_loads; s[3] = emu_stats.rows; s[4] = emu_stats.runs;
             s[5] = emu_stats.trips; s[6] = emu_stats.faces; s[7] = emu_stats.face_skips;
         }
     }
     for (int j = 0; j < 31; ++j) out32[j] = tot[j];
     out32[31] = 0.0;
+    if (counts) counts[0] = n_searched;
     return 0;
 }
 

@@ -585,33 +585,41 @@ def test_empty_space_skip_is_exact(ctx):
     assert np.array_equal(got[0][1][0], got[1][1][0])
 
 
-def test_both_warm_bounds_give_the_same_runs(cyl):
-    """"small_move" picks, per launch, how the warm bound is obtained (gather of the old neighbours / old 5th-neighbour distance plus
-    the point's move).  Both are exact for any motion: runs with the small-move form never taken, taken by the default rule and
-    ALWAYS taken (also across big jumps, where it is merely loose) are bitwise the same, blocking and pipelined."""
+def test_certificates_only_spare_searches(cyl):
+    """"cert_move" picks, per launch, whether certificates are tested first (k_rows + work lists) or every point is searched at once
+    (k_full).  Either way the sums are bitwise the same: runs with certificates never tested, tested by the default rule and ALWAYS
+    tested (also across big jumps, where every point ends up on the search list) agree bit for bit, blocking and pipelined - and the
+    certifying runs do leave most points unsearched once the pose has settled."""
     tgt = cyl[0]
     src = tgt[::2]
     T0 = h.pose6d_matrix(0.3, -0.2, 0.1, h.deg2rad(2.0), h.deg2rad(-1.0), h.deg2rad(3.0))
     cfg = api.default_config(search_radius=1.0, max_iterations=25, CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0)
     prm = api.default_lin_params(1.0, 1)
     walk = [T0, T0 @ h.pose6d_matrix(1e-5, 0.0, 2e-5, 1e-7, 0.0, -1e-7), T0 @ h.pose6d_matrix(0.5, 0.5, -0.2, 0.0, h.deg2rad(4.0), 0.0), T0,
-            T0 @ h.pose6d_matrix(300.0, 0.0, 0.0, 0.0, 0.0, 0.0), T0]
+            T0 @ h.pose6d_matrix(300.0, 0.0, 0.0, 0.0, 0.0, 0.0), T0, T0]
     got = {}
-    for frac in (0.0, 0.05, 1e9):
+    for frac in (0.0, 0.5, 1e9):
         c = api.Context(0)
-        c.set_option("small_move", frac); c.set_target(tgt, 1.0); c.set_source(src)
+        c.set_option("cert_move", frac); c.set_target(tgt, 1.0); c.set_source(src)
         lin = [c.linearize(T[:3, :3], T[:3, 3], prm) for T in walk]
+        st_walk = c.launch_stats(reset=True)
         res, logs = c.icp_run(T0, "Ours", cfg)                      # pipelined engine, state carried over from the walk
         res2, _ = c.icp_run(T0, "Ours", cfg)                        # and once more from the converged state
+        st_run = c.launch_stats()
         got[frac] = (lin, res.iterations, np.array(res.R[:]), np.array(res.t[:]), np.array(res2.R[:]), np.array(res2.t[:]),
-                     [np.array(L.H_upper[:]) for L in logs])
+                     [np.array(L.H_upper[:]) for L in logs], st_walk, st_run)
         c.close()
-    for frac in (0.05, 1e9):
+    for frac in (0.5, 1e9):
         a, b = got[frac], got[0.0]
         for x, y in zip(a[0], b[0]):
             assert x["n_eff"] == y["n_eff"] and np.array_equal(x["H_upper"], y["H_upper"]) and np.array_equal(x["g"], y["g"])
         assert a[1] == b[1] and all(np.array_equal(a[k], b[k]) for k in (2, 3, 4, 5))
         assert all(np.array_equal(x, y) for x, y in zip(a[6], b[6]))
+    assert got[0.0][7]["poses_certified"] == 0 and got[0.0][8]["poses_certified"] == 0
+    assert got[1e9][7]["poses_certified"] == len(walk) - 1                      # all but the first launch (fresh state)
+    assert 2 <= got[0.5][7]["poses_certified"] < len(walk) - 1                  # the tiny step and the repeated pose, not the jumps
+    assert got[0.5][8]["poses_certified"] >= 30                                  # most of the two 25-iteration runs
+    assert got[0.5][8]["last_queries_listed"] < 0.02 * len(src)                  # converged: (almost) nothing left to search
 
 
 def test_far_from_the_origin_and_very_dense_cells(ctx):

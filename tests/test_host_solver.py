@@ -16,7 +16,7 @@ METHODS = ["ME-SR", "ME-TSVD", "ME-TReg", "FCN-SR", "Ours", "NONE"]
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = api.load()
-    hdr = open(os.path.join(h.REPO, "include", "dcreg.h")).read()
+    hdr = open(os.path.join(h.REPO, "include", "dcreg.h")).read() + open(os.path.join(h.REPO, "include", "dcreg_debug.h")).read()
     declared = set(re.findall(r"\b(dcreg_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
     for name in declared:
