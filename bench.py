@@ -29,7 +29,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_QUERY = 72           # 12 B source point + 5 x 12 B neighbours
@@ -50,7 +49,7 @@ WORKLOADS = {
 
 
 def make_pair(scene, n, seed):
-    import helpers as h
+    from dcreg_amd import scenes as h
     if scene == "fixture":
         pts = h.cylinder_cloud()
         return pts, pts.copy()
@@ -65,7 +64,7 @@ def make_pair(scene, n, seed):
 
 
 def initial_pose(scene):
-    import helpers as h
+    from dcreg_amd import scenes as h
     if scene == "parkinglot":
         return h.pose6d_matrix(**h.PK01_INIT)          # config/icp_pk01.yaml:29-35
     # a few cm / tenths of a degree (frame-to-frame LiDAR odometry regime); over the 200 m corridor the 0.5 deg yaw is
@@ -227,7 +226,7 @@ class Pair:
         self.mc_iters = 0
         if self.mc:
             from dcreg_amd import montecarlo as mcm
-            import helpers as h
+            from dcreg_amd import scenes as h
             base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
             T0s = np.stack([mcm.trial_pose(base, 1 + k + 1000 * D.rank, 2024, 0.3, h.deg2rad(1.0)) for k in range(MC_BATCH)])
             self.R0s = np.ascontiguousarray(T0s[:, :3, :3]).reshape(MC_BATCH, 9)
@@ -433,7 +432,7 @@ def main(argv=None):
     if D.dry:
         return dry_run(args, D)
     n_gpus = D.world
-    import helpers as h
+    from dcreg_amd import scenes as h
     from dcreg_amd import api
 
     P = Pair(args.workload, D, args, seed=100 + (0 if args.sharding == "points" else D.rank))   # pairs: every rank its own scan pair

@@ -1,11 +1,10 @@
 // Per-thread device functions of the DCReg hot path (gfx950): exact 5-NN on the cell grid, 5x3 plane fit, point-to-plane
 // row (DCReg/src/icp_test_runner.cpp:1714-1907).  Included by kernels.hpp (the __global__ kernels and the reductions).
 //
-// The same functions also compile for the host when DCREG_HOST_EMUL is defined: tests/host_emul/ builds them with a small
-// shim (float4, bit casts, a fake threadIdx) into a TEST-ONLY library that replays the device algorithm on the CPU, so the
-// search logic (exactness on ties / borders / empty space, visit counts) and the plane fit can be checked against the
-// oracle without a GPU (tests/test_host_emul.py).  It is test infrastructure like oracle/: nothing under dcreg_amd/ links
-// or loads it and libdcreg_hip.so has no host path.
+// The same functions also compile for the host when the includer defines DCREG_HOST_EMUL and has provided the handful of device
+// types and intrinsics they use (float4, bit casts, a threadIdx): the test suite does that to replay the device algorithm on the
+// CPU against the oracle.  That is test infrastructure, outside this package: nothing here links or loads it and
+// libdcreg_hip.so has no host path.
 //
 // Layout in HBM
 //   target : float4 {x,y,z,bits(orig_idx)} sorted by linear grid cell (x fastest) + cell_start[n_cells+1]
@@ -18,7 +17,6 @@
 #include <stddef.h>
 #include <stdint.h>
 #if defined(DCREG_HOST_EMUL)
-#include "host_emul_shim.hpp"
 #define DCREG_DEVFN inline
 #define DCREG_ON_DEVICE 0
 #else

@@ -3,7 +3,7 @@
 // (DCReg/src/icp_test_runner.cpp:2418-2469) and the pieces the released source leaves as stubs
 // (SCHUR_CONDITION_NUMBER detection dcreg.hpp:96-98, PCG dcreg.hpp:186-193,279-287, axis alignment
 // dcreg.hpp:267-276), written from the paper's description and pinned by the committed "Ours" traces
-// (tests/golden/paper).  Pure functions of (H, g, config); no device involved.
+// (results/simulation/table3_fig9_fig10 of the reference).  Pure functions of (H, g, config); no device involved.
 #include <cmath>
 #include <cstring>
 #include <limits>

@@ -122,7 +122,8 @@ def main(argv=None):
     (one rank per GPU, trials k = rank mod world, one RCCL all_gather of the trial records at the end)."""
     import argparse, json, os, time
     ap = argparse.ArgumentParser(description=main.__doc__)
-    ap.add_argument("--cloud", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cylinder_7562.pcd"),
+    from .scenes import FIXTURE_PCD
+    ap.add_argument("--cloud", default=FIXTURE_PCD,
                     help="PCD (binary or ascii, float32 x y z ...) used as source AND target, like the reference's simulated experiment")
     ap.add_argument("--trials", type=int, default=5000)
     ap.add_argument("--methods", default="Ours,ME-SR,ME-TSVD,ME-TReg,FCN-SR")

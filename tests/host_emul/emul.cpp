@@ -10,6 +10,7 @@
 #include <vector>
 
 #define DCREG_HOST_EMUL 1
+#include "host_emul_shim.hpp"
 #include "../../dcreg_amd/csrc/device/search.hpp"
 
 using namespace dcreg;

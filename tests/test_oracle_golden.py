@@ -4,7 +4,7 @@ Golden files are data copied from the reference's committed run outputs:
   tests/golden/release  <- DCReg/dataset/icp_results/            (released source, wd=0, init 1 cm)
   tests/golden/paper    <- results/simulation/table3_fig9_fig10/ (paper run, wd=1, incl. "Ours")
   tests/golden/fig8     <- results/simulation/fig8_5000iters/    (5000-iteration run)
-  tests/golden/cylinder_7562.pcd <- DCReg/dataset/icp_results/target_clouds.pcd (the input cloud)
+  dcreg_amd/data/cylinder_7562.pcd <- DCReg/dataset/icp_results/target_clouds.pcd (the input cloud)
 """
 import os
 import sys

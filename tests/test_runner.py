@@ -40,11 +40,11 @@ def test_pcd_reader_refuses_what_it_cannot_read(tmp_path):
         "integer_xyz.pcd": (hdr % ("4 4 4 4", "U U U F", 3, 3)).encode() + struct.pack("<IIIf", 1, 2, 3, 0) * 3,
         "lying_header.pcd": (hdr % ("4 4 4 4", "F F F F", 10 ** 9, 10 ** 9)).encode() + struct.pack("<ffff", 1, 2, 3, 0) * 3,
     }
-    good = os.path.join(h.GOLDEN, "cylinder_7562.pcd")
+    good = h.FIXTURE_PCD
     for name, blob in cases.items():
         (tmp_path / name).write_bytes(blob)
         cfg = open(os.path.join(h.REPO, "configs", "icp.yaml")).read()
-        cfg = cfg.replace('folder_path: "tests/golden/"', 'folder_path: "%s/"' % tmp_path).replace('source_pcd: "cylinder_7562.pcd"', 'source_pcd: "%s"' % name)
+        cfg = cfg.replace('folder_path: "dcreg_amd/data/"', 'folder_path: "%s/"' % tmp_path).replace('source_pcd: "cylinder_7562.pcd"', 'source_pcd: "%s"' % name)
         cfg = cfg.replace('target_pcd: "cylinder_7562.pcd"', 'target_pcd: "%s"' % good)
         (tmp_path / "cfg.yaml").write_text(cfg)
         p = subprocess.run([RUNNER, str(tmp_path / "cfg.yaml"), str(tmp_path) + "/out/"], cwd=h.REPO, capture_output=True, text=True, timeout=120)
