@@ -293,6 +293,8 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm;
     a.w_slope = p->weight_slope; a.w_min = p->weight_min; a.use_wd = p->use_weight_derivative;
     a.warm = c->opt_warm ? 1 : 0;
+    a.prune_infl = (float)((1.0 + c->opt_cert_inflate) * (1.0 + c->opt_cert_inflate));
+    a.infl_max_d2 = (float)(4.0 * c->grid.h * c->grid.h);
     int k = 1;
     while (k < 100000) {
         const double safe = (double)k * c->grid.h * (1.0 - 1e-9);
@@ -372,8 +374,8 @@ static void gate_call_off(dcreg_ctx *c) { gate_publish(c, (c->gate_seq << 1) | 1
 // work lists of certifying launches: room for every query / block of the launch on any one of the lists' shares
 static int ensure_lists(dcreg_ctx *c, uint32_t nbx, int n_poses, ListArgs &wl) {
     if (!c->d_list_count) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_list_count, sizeof(uint32_t) * 2 * 2 * kWorkLists));
-        HIP_TRY(c, hipMemsetAsync(c->d_list_count, 0, sizeof(uint32_t) * 2 * 2 * kWorkLists, c->stream));
+        HIP_TRY(c, hipMalloc((void **)&c->d_list_count, sizeof(uint32_t) * 2 * 2 * kWorkLists * kCounterStride));
+        HIP_TRY(c, hipMemsetAsync(c->d_list_count, 0, sizeof(uint32_t) * 2 * 2 * kWorkLists * kCounterStride, c->stream));
         HIP_TRY(c, hipHostMalloc((void **)&c->h_list_counts, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
         c->h_list_counts[0] = c->h_list_counts[1] = 0;
         HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_list_counts_host, c->h_list_counts, 0));
@@ -386,12 +388,15 @@ static int ensure_lists(dcreg_ctx *c, uint32_t nbx, int n_poses, ListArgs &wl) {
     wl.host_counts = c->d_list_counts_host;
     return DCREG_OK;
 }
-// grid of a list kernel: persistent blocks, sized by what the last certifying launch had on its lists (the loops inside take whatever
-// there is); a multiple of the number of lists
-static unsigned list_grid(size_t hint_items, size_t max_items, size_t per_block) {
-    const size_t want = std::min(max_items, std::max<size_t>(2 * hint_items, 64 * per_block));
+// grid of a list kernel: persistent blocks, a multiple of the number of lists.  The loops inside take whatever is on the lists, so the
+// size only matters for speed: a kernel whose 2048 blocks all find their list empty still occupies the stream for 5-6 us (a small
+// one for 2-3), a kernel with too few blocks serialises real work.  hint = what the previous certifying launch had on its lists (the
+// lists shrink along a converging trajectory), or -1 when that is not known: then, and for anything but a short list, be generous.
+static unsigned list_grid(size_t max_items, size_t per_block, long long hint) {
+    size_t want = max_items;
+    if (hint >= 0 && (size_t)hint * 8 < 64 * per_block) want = std::min(max_items, std::max<size_t>((size_t)hint * 8, 1));
     size_t blocks = (want + per_block - 1) / per_block;
-    blocks = std::min<size_t>(std::max<size_t>(blocks, kWorkLists), 8192);
+    blocks = std::min<size_t>(std::max<size_t>(blocks, kWorkLists), 2048);
     return (unsigned)((blocks + kWorkLists - 1) / kWorkLists * kWorkLists);
 }
 
@@ -427,7 +432,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const size_t n_rows = fused ? (size_t)n_chunks : (size_t)n_poses;      // result rows the host waits for
     if (fused) {   // tickets: zero when (re)allocated, afterwards every completed launch leaves them zero
         const size_t had = S.tickets_cap;
-        if (ensure(c, S.d_tickets, S.tickets_cap, (size_t)n_chunks)) return DCREG_E_NOMEM;
+        if (ensure(c, S.d_tickets, S.tickets_cap, (size_t)n_chunks * kCounterStride)) return DCREG_E_NOMEM;
         if (S.tickets_cap != had || S.tickets_dirty) {
             HIP_TRY(c, hipMemsetAsync(S.d_tickets, 0, sizeof(unsigned int) * S.tickets_cap, c->stream));
             S.tickets_dirty = false;
@@ -451,6 +456,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     // The launch plan.  n_cert poses are linearised by charging certificates (k_rows, then the two list kernels), n_full by
     // searching everything (k_full); d_ids_* = which poses, for batched launches that mix both.
     int n_cert = 0, n_full = n_poses;
+    bool inwave = false;            // the searching kernel tests certificates itself and searches only the lanes that need it
     const uint32_t *d_ids_cert = nullptr, *d_ids_full = nullptr;
     bool uses_state = false;
     const bool state_was_valid = c->state_valid;
@@ -470,7 +476,9 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             // saw - a wrong guess only costs time
             double max_move = c->last_max_move;
             if (!gated) max_move = pose_move(c, one.R, one.t);
-            if (c->state_valid && !dbg_host && certifies(c, max_move)) { n_cert = 1; n_full = 0; }
+            if (c->state_valid && !dbg_host && certifies(c, max_move)) {
+                if (c->opt_cert_plan == 0) inwave = true; else { n_cert = 1; n_full = 0; }
+            }
         }
         if (gated) {
             if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
@@ -526,7 +534,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             const bool valid = has && c->batch_state_valid[(size_t)state_ids[i]] != 0;
             hp[i].fresh = valid ? 0u : 1u;
             // a state that holds certificates is charged (k_rows); anything else is searched in full (k_full)
-            if (valid && c->opt_cert_move > 0.0) hid[n_cert++] = (uint32_t)i; else hid[n_poses - 1 - n_full++] = (uint32_t)i;
+            if (valid && c->opt_cert_move > 0.0 && c->opt_cert_plan != 0) hid[n_cert++] = (uint32_t)i; else hid[n_poses - 1 - n_full++] = (uint32_t)i;
             if (has) c->batch_state_valid[(size_t)state_ids[i]] = 1;
         }
         HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->stream));
@@ -534,6 +542,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         const uint32_t *d_ids = (const uint32_t *)(S.d_poses + (size_t)n_poses * sizeof(PoseArg));
         d_ids_cert = d_ids; d_ids_full = d_ids + (n_poses - n_full);
         if (use_states) { a.state = c->d_state_batch; a.state_stride = (uint32_t)c->state_batch_stride; }
+        inwave = use_states && c->opt_cert_move > 0.0 && c->opt_cert_plan == 0;      // (fresh states are flagged per pose)
     }
     ListArgs wl{};
     if (n_cert > 0) {
@@ -589,7 +598,10 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (n_cert > 0) {
         const dim3 grid(nbx, (unsigned)n_cert);
         const size_t max_q = (size_t)n_cert * (size_t)n, max_b = (size_t)n_cert * nbx;
-        const unsigned gq = list_grid((size_t)c->h_list_counts[0], max_q, kBlock), gb = list_grid((size_t)c->h_list_counts[1], max_b, 1);
+        // (the hint is one launch stale when launches are pipelined, and unknown after a searching launch)
+        const bool hinted = false;      // (see list_grid: a stale report after a pose jump must never shrink a grid)
+        const unsigned gq = list_grid(max_q, kBlock, hinted ? (long long)__atomic_load_n(&c->h_list_counts[0], __ATOMIC_ACQUIRE) : -1);
+        const unsigned gb = list_grid(max_b, 1, hinted ? (long long)__atomic_load_n(&c->h_list_counts[1], __ATOMIC_ACQUIRE) : -1);
 #define DCREG_LAUNCH_ROWS(FUSED, FAST, LISTED, GRID)                                                                                      \
     hipLaunchKernelGGL((k_rows<FUSED, FAST, LISTED>), GRID, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses,    \
                        d_ids_cert, a, S.d_partials, nbx, fin, wl, abort_flag)
@@ -602,12 +614,16 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     }
     if (n_full > 0) {
         const dim3 grid(nbx, (unsigned)n_full);
-#define DCREG_LAUNCH_FULL(MODE, FUSED, FAST)                                                                                               \
-    hipLaunchKernelGGL((k_full<MODE, FUSED, FAST>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses,       \
+#define DCREG_LAUNCH_FULL(MODE, FUSED, FAST, CERT)                                                                                         \
+    hipLaunchKernelGGL((k_full<MODE, FUSED, FAST, CERT>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, \
                        d_ids_full, a, S.d_partials, nbx, fin, dd, abort_flag)
-        if (dbg_host) { if (fast) DCREG_LAUNCH_FULL(1, true, true); else DCREG_LAUNCH_FULL(1, true, false); }
-        else if (fused) { if (fast) DCREG_LAUNCH_FULL(0, true, true); else DCREG_LAUNCH_FULL(0, true, false); }
-        else { if (fast) DCREG_LAUNCH_FULL(0, false, true); else DCREG_LAUNCH_FULL(0, false, false); }
+        if (dbg_host) { if (fast) DCREG_LAUNCH_FULL(1, true, true, false); else DCREG_LAUNCH_FULL(1, true, false, false); }
+        else if (inwave) {
+            if (fused) { if (fast) DCREG_LAUNCH_FULL(0, true, true, true); else DCREG_LAUNCH_FULL(0, true, false, true); }
+            else { if (fast) DCREG_LAUNCH_FULL(0, false, true, true); else DCREG_LAUNCH_FULL(0, false, false, true); }
+        }
+        else if (fused) { if (fast) DCREG_LAUNCH_FULL(0, true, true, false); else DCREG_LAUNCH_FULL(0, true, false, false); }
+        else { if (fast) DCREG_LAUNCH_FULL(0, false, true, false); else DCREG_LAUNCH_FULL(0, false, false, false); }
 #undef DCREG_LAUNCH_FULL
     }
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
@@ -638,7 +654,9 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             return bail("copying the debug dump back", ce);
         }
     }
-    c->n_poses_searched += n_full; c->n_poses_certified += n_cert;
+    if (inwave) c->n_poses_certified += n_full; else c->n_poses_searched += n_full;
+    c->n_poses_certified += n_cert;
+    c->last_plan_certified = n_cert > 0 && n_full == 0;
     if (uses_state) c->state_valid = true;          // once this launch has run, the state holds a search of the current clouds
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr; S.certifying = n_cert > 0;
@@ -852,6 +870,8 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
     else if (k == "cert_move" || k == "small_move") c->opt_cert_move = v >= 0.0 ? v : 0.0;
     else if (k == "cert_margin") { c->opt_cert_margin = v >= 1e-4 ? std::min(v, 1.0) : 1e-4; drop_warm(c); }    // the cells follow at the next dcreg_set_target
+    else if (k == "cert_plan") c->opt_cert_plan = (int)v;
+    else if (k == "cert_inflate") { c->opt_cert_inflate = v >= 0.0 ? std::min(v, 1.0) : 0.0; drop_warm(c); }
     else if (k == "wait_seconds") c->opt_wait_seconds = v > 0.0 ? v : 30.0;
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }

@@ -80,6 +80,7 @@ struct dcreg_ctx {
     uint32_t *d_list_count = nullptr;
     uint2 *d_q_entries = nullptr, *d_b_entries = nullptr; size_t q_entries_cap = 0, b_entries_cap = 0;
     uint32_t list_parity = 0;
+    bool last_plan_certified = false;      // the pinned list counts below describe the launch before this one
     unsigned long long *h_list_counts = nullptr, *d_list_counts_host = nullptr;    // pinned [2]: queries / blocks of the last certifying launch
 
     // build scratch
@@ -119,6 +120,8 @@ struct dcreg_ctx {
     int opt_x_subdiv = 8;          // x sub-cells per grid cell (1, 2, 4, 8, 16)
     double opt_cert_move = 0.5;    // fraction of a cell edge: a pose change that moves no source point farther is linearised by testing
                                    // certificates (k_rows + work lists) instead of searching every query (0 = never)
+    int opt_cert_plan = 0;         // how certificates are used: 0 = inside the searching kernel (k_full<CERT>), 1 = k_rows + work lists
+    double opt_cert_inflate = 0.04; // searches prune at (1 + inflate) x the 6th best distance: the 7th neighbour's lower bound (SET6 certificates)
     double opt_cert_margin = 0.05; // searches cover R (1 + margin): what "5th neighbour beyond R" certificates can spend
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
     uint64_t launch_counter = 0;

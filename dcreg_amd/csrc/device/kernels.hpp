@@ -149,8 +149,11 @@ struct DebugDev {
 // each) use k_finalize instead: a ticket per block costs more there than the extra launch (measured, profiles/r01_search_ablation.md
 // addendum 5).
 constexpr int kChunk = 64;
+// counters that many blocks hit with atomics live one per 128-byte line: atomics on ONE line are served one after the other (~11 ns
+// each), whatever word they address - 3907 ticket arrivals on two lines were 22 us of a 46 us kernel, 7800 list appends on one 94 us
+constexpr int kCounterStride = 32;      // uint32 words
 struct FinArgs {
-    unsigned int *tickets;         // [n_chunks], zero between launches (the last arrival resets its ticket)
+    unsigned int *tickets;         // [n_chunks * kCounterStride], zero between launches (the last arrival resets its ticket)
     double *out;                   // pinned, device-mapped: [n_chunks][kSlots]; slot 31 = sequence number
     unsigned long long seq;
 };
@@ -161,14 +164,14 @@ struct FinArgs {
 // be reset between launches
 constexpr int kWorkLists = 8;
 struct ListArgs {
-    uint32_t *count;               // [2][2][kWorkLists]: parity, kind (0 queries, 1 blocks), list
+    uint32_t *count;               // [2][2][kWorkLists] counters, kCounterStride words apart: parity, kind (0 queries, 1 blocks), list
     uint2 *q_entries;              // [kWorkLists][q_cap]: {pose, query}
     uint2 *b_entries;              // [kWorkLists][b_cap]: {pose, query block}
     uint32_t q_cap, b_cap;
     uint32_t parity;
     unsigned long long *host_counts;   // pinned [2]: queries searched / blocks redone by the launch, for the host's next grid sizes (may be null)
-    __device__ uint32_t *qcount(uint32_t l) const { return count + (parity * 2u + 0u) * kWorkLists + l; }
-    __device__ uint32_t *bcount(uint32_t l) const { return count + (parity * 2u + 1u) * kWorkLists + l; }
+    __device__ uint32_t *qcount(uint32_t l) const { return count + (size_t)((parity * 2u + 0u) * kWorkLists + l) * kCounterStride; }
+    __device__ uint32_t *bcount(uint32_t l) const { return count + (size_t)((parity * 2u + 1u) * kWorkLists + l) * kCounterStride; }
 };
 // Cross-block traffic of the tree uses agent-scope (sc1, write-through / L2-coherent) relaxed atomics plus an explicit
 // s_waitcnt instead of __threadfence(): a release fence on gfx950 is a full L2 write-back (buffer_wbl2), measured at
@@ -296,9 +299,9 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
         const uint32_t csize = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[(size_t)chunk * kCounterStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_role = (prev == csize - 1) ? 1 : 0;
-            if (prev == csize - 1) __hip_atomic_store(&fin.tickets[chunk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == csize - 1) __hip_atomic_store(&fin.tickets[(size_t)chunk * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (*s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
@@ -342,7 +345,7 @@ static __global__ __launch_bounds__(kBlock, 4) void k_rows(const float4 *__restr
             __hip_atomic_store(wl.host_counts + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     } else if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * kWorkLists) {
-        wl.count[(1u - wl.parity) * 2u * kWorkLists + threadIdx.x] = 0u;       // the successor's counters
+        wl.count[(size_t)((1u - wl.parity) * 2u * kWorkLists + threadIdx.x) * kCounterStride] = 0u;       // the successor's counters
     }
     for (; e < n_entries; e += e_step) {
         uint32_t pose_id, vb;
@@ -358,14 +361,14 @@ static __global__ __launch_bounds__(kBlock, 4) void k_rows(const float4 *__restr
         const bool have_q = i < n_src;
         uint32_t *st = a.state + (size_t)P.state * kStateRows * a.state_stride;
         const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t cert = kCertSearch, pos[5], q0[3] = {0u, 0u, 0u};
+        uint32_t cert = kCertSearch, pos[6], q0[3] = {0u, 0u, 0u};
         if (have_q) cert = st[(size_t)6 * a.state_stride + i];
         if (!LISTED && have_q) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * a.state_stride + i];
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) pos[j] = have_q ? st[(size_t)j * a.state_stride + i] : 0u;     // issued with the certificate: one latency
+        for (int j = 0; j < 6; ++j) pos[j] = have_q ? st[(size_t)j * a.state_stride + i] : 0u;     // issued with the certificate: one latency
         float qx, qy, qz;
         body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
         bool unc = false;
@@ -375,10 +378,15 @@ static __global__ __launch_bounds__(kBlock, 4) void k_rows(const float4 *__restr
             unc_mask = __builtin_amdgcn_ballot_w64(unc);
             if (lane == 0) s_wcnt[wave] = (uint32_t)__builtin_popcountll(unc_mask);
         }
-        if (unc_mask == 0ull && have_q && !(cert & 0x80000000u)) {         // SET certificate: the five known neighbours at the new pose
-            KnnResult<5> nn;
-            double nrm[3], r_pt, s_pt;
-            flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, r_pt, s_pt);
+        if (unc_mask == 0ull) {                // SET certificates: the known neighbours at the new pose
+            const bool set = have_q && !cert_is_out(cert);
+            const bool six = wave_any(set && cert_is_set6(cert));
+            if (!cert_is_set6(cert)) pos[5] = kNoIdx;
+            if (set) {
+                KnnResult<5> nn;
+                double nrm[3], r_pt, s_pt;
+                flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos, six, nn, row, nrm, r_pt, s_pt);
+            }
         }
         wave_rows_to_lds(row, flag, stage[wave], red, cnt);
         __syncthreads();
@@ -448,7 +456,10 @@ static __global__ __launch_bounds__(kBlock, 4) void k_search_list(const float4 *
 }
 
 // ---------------------------------------------------------------- k_full: search + rows in one kernel
-template <int MODE, bool FUSED, bool FAST>
+// CERT = false: every query is searched.  CERT = true: a query whose certificate holds at its new position is not; the waves in which
+// every certificate holds skip the search altogether (the common case on a settled trajectory), the others run it for the lanes that
+// need it.  No lists, no second launch - and no compaction: a wave with one query to search takes about as long as a wave with 64.
+template <int MODE, bool FUSED, bool FAST, bool CERT>
 static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                            PoseArg pose1, const PoseArg *__restrict__ poses,
                                                            const uint32_t *__restrict__ pose_ids, LinArgs a,
@@ -471,32 +482,51 @@ static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restr
     uint8_t flag = 0;
     const bool have_q = i < n_src;
     const bool keep = a.state != nullptr && P.state != kNoIdx;              // the pose owns a state
-    const bool old = keep && P.fresh == 0u && a.warm != 0;                  // ... whose old neighbours bound this search
+    const bool old = keep && P.fresh == 0u;                                 // ... that holds the results of earlier searches
     uint32_t *st = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride : nullptr;
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t pos6[6];
+    uint32_t pos6[6], cert = kCertSearch, q0[3] = {0u, 0u, 0u};
+    const bool rd = old && have_q && (CERT || a.warm != 0);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) pos6[j] = (old && have_q) ? st[(size_t)j * a.state_stride + i] : kNoIdx;
+    for (int j = 0; j < 6; ++j) pos6[j] = rd ? st[(size_t)j * a.state_stride + i] : kNoIdx;
+    if (CERT && old && have_q) {
+        cert = st[(size_t)6 * a.state_stride + i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * a.state_stride + i];
+    }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
-    Set6 s6;
-    uint32_t cert;
-    lin_search6(g, runs[wave], a, have_q, old, pos6, qx, qy, qz, s6, cert);
-    if (keep && have_q) {
+    bool need = have_q;
+    if (CERT) need = have_q && !cert_holds(cert, __uint_as_float(q0[0]), __uint_as_float(q0[1]), __uint_as_float(q0[2]), qx, qy, qz);
+    uint32_t stats = 0;
+    if (!CERT || wave_any(need)) {
+        Set6 s6;
+        uint32_t c2;
+        lin_search6(g, runs[wave], a, need, old && a.warm != 0, pos6, qx, qy, qz, s6, c2);
+        if (need) {
+            cert = c2;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) st[(size_t)j * a.state_stride + i] = s6.pos[j];
-        st[(size_t)6 * a.state_stride + i] = cert;
-        st[(size_t)7 * a.state_stride + i] = __float_as_uint(qx); st[(size_t)8 * a.state_stride + i] = __float_as_uint(qy);
-        st[(size_t)9 * a.state_stride + i] = __float_as_uint(qz);
+            for (int j = 0; j < 5; ++j) pos6[j] = s6.pos[j];
+            pos6[5] = kNoIdx;                      // (the search has just put the set in order: five are enough for this launch's row)
+            if (keep) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) st[(size_t)j * a.state_stride + i] = s6.pos[j];
+                st[(size_t)6 * a.state_stride + i] = c2;
+                st[(size_t)7 * a.state_stride + i] = __float_as_uint(qx); st[(size_t)8 * a.state_stride + i] = __float_as_uint(qy);
+                st[(size_t)9 * a.state_stride + i] = __float_as_uint(qz);
+            }
+            stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+        }
     }
-    // rows: the queries with a SET certificate gather their five neighbours - the same code k_rows runs
+    // rows: the queries with a SET certificate gather their neighbours - searched a moment ago or known - the same code for both
     KnnResult<5> nn;
     double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
-    if (have_q && !(cert & 0x80000000u)) {
-        uint32_t pos[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) pos[j] = s6.pos[j];
-        flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, r_pt, s_pt);
+    {
+        const bool set = have_q && !cert_is_out(cert);
+        const bool use6 = CERT && !need && cert_is_set6(cert);
+        const bool six = CERT && wave_any(set && use6);
+        if (!use6) pos6[5] = kNoIdx;
+        if (set) flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos6, six, nn, row, nrm, r_pt, s_pt);
     }
     if (MODE == 1 && have_q) {
         const uint32_t oi = __float_as_uint(s4.w);
@@ -511,7 +541,7 @@ static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restr
             if (dbg.s) dbg.s[oi] = s_pt;
         }
         if (dbg.flag) dbg.flag[oi] = flag;
-        if (dbg.stats) dbg.stats[oi] = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+        if (dbg.stats) dbg.stats[oi] = stats;
     }
     // (the wave's RunList is free now: it stages the rows)
     wave_rows_to_lds(row, flag, runs[wave].stage, red, cnt);

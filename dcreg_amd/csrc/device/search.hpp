@@ -67,10 +67,15 @@ struct PoseArg {
 //   uint32 [kStateRows][stride]   rows 0-5: positions in the sorted target of the query's 6 nearest neighbours as of its last search,
 //                                 ascending (kNoIdx = fewer were found inside the search bound);
 //                                 rows 7-9: the query's position q0 at that search (the float-stored transform, bit patterns);
-//                                 row 6: the CERTIFICATE of that search, a float s >= 0 (bit pattern) with a mode in the sign bit:
-//     SET (sign 0): while the query stays within s metres of q0 its 5-nearest SET cannot change: s = (a5 - a4) / 2 of the 5th / 6th
-//                   neighbour distances a4 / a5 at q0.  A linearisation at a pose that keeps it there needs no search: it gathers the 5
-//                   points, recomputes the five float distances and sorts them - bitwise what a fresh search returns.
+//                                 row 6: the CERTIFICATE of that search, a float s >= 0 (bit pattern) with a mode in the sign bit and
+//                                 the lowest mantissa bit:
+//     SET5 (sign 0, low bit 0): while the query stays within s metres of q0 its 5-nearest SET cannot change: s = (a5 - a4) / 2 of
+//                   the 5th / 6th neighbour distances a4 / a5 at q0.  A linearisation at a pose that keeps it there needs no search:
+//                   it gathers the 5 points, recomputes the five float distances and sorts them - bitwise what a fresh search returns.
+//     SET6 (sign 0, low bit 1): the same one neighbour further out - within s = (a6 - a5) / 2 metres the SIX nearest are the six
+//                   known points (a6 = a lower bound of the 7th neighbour's distance, which the search gets for free: what it looked
+//                   at and did not keep, and the pruning radius it never looked beyond): gather 6, sort, take the first five.  The
+//                   gaps a5 - a4 and a6 - a5 are independent, so the better of the two certificates fails quadratically less often.
 //     OUT (sign 1): the 5th neighbour was beyond the search radius by s metres (or not found at all inside the slightly larger search
 //                   bound): within s metres of q0 the query fails the radius gate (:1726) and nothing needs to be loaded at all.
 // Nothing of a state changes between two searches of a query, and the test is on the two stored float positions themselves (their
@@ -87,6 +92,9 @@ struct LinArgs {
     int use_wd;
     int max_ring;                 // rings needed to cover the search bound
     int warm;                     // searches of a non-fresh state are bounded by the old neighbours' distances from the new position
+    float prune_infl;             // (1 + cert_inflate)^2: the searches prune at the 6th best distance x (1 + cert_inflate), which is
+                                  // what makes the 7th neighbour's lower bound - and SET6 certificates - worth something ...
+    float infl_max_d2;            // ... for searches bounded by at most this squared distance (a couple of cells)
     uint32_t *state;              // [state][kStateRows][state_stride], or null (nothing is kept)
     uint32_t state_stride;
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
@@ -105,7 +113,9 @@ struct HeapExact {
     uint32_t pos[K];
     uint32_t n_eval;     // candidates evaluated (statistics only; dead code unless read)
     uint32_t n_shell;    // outermost shell scanned
-    DCREG_DEVFN void init(float bound_f) {
+    float infl;          // the walk prunes at worst_d2() = K-th best x infl (>= 1): everything it never looked at is at least that far
+    DCREG_DEVFN void init(float bound_f, float infl_ = 1.f) {
+        infl = infl_;
         const uint64_t bound = ((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull;
 #pragma unroll
         for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
@@ -126,7 +136,7 @@ struct HeapExact {
             }
         }
     }
-    DCREG_DEVFN float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)); }
+    DCREG_DEVFN float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)) * infl; }
     DCREG_DEVFN float dist(int j) const { return __uint_as_float((uint32_t)(key[j] >> 32)); }
     DCREG_DEVFN bool full() const { return pos[K - 1] != kNoIdx; }
 };
@@ -150,7 +160,10 @@ struct HeapFast {
     uint32_t pos[K];
     float outside_min;   // smallest d2 among all points seen that are not in the heap
     uint32_t n_eval, n_shell;
-    DCREG_DEVFN void init(float bound_f) {
+    float infl;          // the walk prunes at worst_d2() = K-th best x infl (>= 1): everything it never looked at is at least that far,
+                         // everything it looked at and did not keep is in outside_min - together a lower bound for the (K+1)-th neighbour
+    DCREG_DEVFN void init(float bound_f, float infl_ = 1.f) {
+        infl = infl_;
 #pragma unroll
         for (int i = 0; i < K; ++i) { d[i] = bound_f; pos[i] = kNoIdx; }
         outside_min = __builtin_inff();
@@ -247,7 +260,7 @@ struct HeapFast {
             d[0] = fminf(d[0], d2);
         }
     }
-    DCREG_DEVFN float worst_d2() const { return d[K - 1]; }
+    DCREG_DEVFN float worst_d2() const { return d[K - 1] * infl; }
     DCREG_DEVFN float dist(int j) const { return d[j]; }
     DCREG_DEVFN bool full() const { return pos[K - 1] != kNoIdx; }
     // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
@@ -292,8 +305,7 @@ DCREG_DEVFN float sqrt_approx(float x) {
 
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp,
-                                           unsigned long long *stamp = nullptr);
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
 
 // Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
 // Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
@@ -357,8 +369,8 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
 // the ball covers the search radius.
 template <class H>
 DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, H &hp, unsigned long long *stamp = nullptr) {   // max_ring < 0: unbounded
-    hp.init(bound_f);
+                                           int max_ring, H &hp, float infl = 1.f) {   // max_ring < 0: unbounded
+    hp.init(bound_f, infl);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)max_ring + 1.0;
     if (max_ring >= 0) {
@@ -425,7 +437,6 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             }
         }
     }
-    if (stamp) stamp[0] = clock64();
     // ---- phase B: flattened walk over the runs (the wave iterates max-over-lanes of the total, not the
     // sum of per-row maxima), 4 candidates in flight per trip
     {
@@ -508,8 +519,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             hp.note_outside(om);
         }
     }
-    if (stamp) stamp[1] = clock64();
-    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp, stamp);
+    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
 // Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
@@ -528,7 +538,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
 template <class H>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp, unsigned long long *stamp) {
+                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
     {   // what ring 1's test would say, before anything is loaded: an aligned query is done after the centre block (its K-th best lies
@@ -544,18 +554,10 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
         k0 = max(1, f - 1);
     }
-    // instrumented builds (MODE 1, stamp != null): stamp[3] += cycles inside the candidate scans, [4] += cycles waiting for table
-    // entries, [5] += row iterations, [6] += scans
     auto lookup_scan = [&](int64_t c0, int64_t c1) {
         DCREG_STAT(table_loads); DCREG_STAT(table_loads); DCREG_STAT(faces);
-        unsigned long long t_a = stamp ? clock64() : 0ull;
-        uint32_t s_ = g.cell_start[c0], e_ = g.cell_start[c1];
-#if DCREG_ON_DEVICE
-        if (stamp) asm volatile("" : "+v"(s_), "+v"(e_));      // the entries have arrived
-#endif
-        unsigned long long t_b = stamp ? clock64() : 0ull;
+        const uint32_t s_ = g.cell_start[c0], e_ = g.cell_start[c1];
         scan_run<H>(g, s_, e_, qx, qy, qz, hp);
-        if (stamp) { stamp[4] += t_b - t_a; stamp[3] += clock64() - t_b; stamp[6] += 1; }
     };
     // slab distance (metres, float) from the query to cell index c along an axis (cq = the query's cell, fr = the query's position
     // inside that cell, in cells): single precision - every use carries a 1e-5 relative safety factor against 1e-7 of rounding
@@ -570,7 +572,6 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
     };
     // one (y,z) row of a z or y face: x-run [cx-kk, cx+kk] trimmed to the ball (conservative), then scanned
     auto face_row = [&](int y, int z, float dyz, int kk, int dz, int dy) {
-        if (stamp) stamp[5] += 1;
         DCREG_STAT(rows);
         const float w = hp.worst_d2();
         if (dyz > w) return;
@@ -679,8 +680,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
                 for (int dy = ylo; dy <= yhi; ++dy) {
                     const int y = cy + dy;
                     if (y < 0 || y >= ny) continue;
-                    if (stamp) stamp[5] += 1;
-                    DCREG_STAT(rows);
+                                DCREG_STAT(rows);
                     const float gy = slab(y, cy, fry);
                     const float dyz = (gy * gy + gz2) * 0.99999f;
                     const float w = hp.worst_d2();
@@ -709,12 +709,11 @@ struct KnnResult {
 
 template <int K>
 DCREG_DEVFN void knn_exact(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring,
-                                          KnnResult<K> &res, unsigned long long *stamp = nullptr) {
+                                          KnnResult<K> &res) {
     uint32_t pos[K];
     {
         HeapFast<K> hf;
-        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, stamp);
-        if (stamp) stamp[2] = clock64();
+        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
         res.full = hf.full();
         res.n_eval = hf.n_eval; res.n_shell = hf.n_shell;
 #pragma unroll
@@ -1049,6 +1048,7 @@ struct PointQuery {
 struct Set6 {
     uint32_t pos[6];      // positions in the sorted target, ascending distance (kNoIdx = not found inside the bound)
     float d2[6];          // squared distances (the bound where not found: a lower bound for that neighbour)
+    float lb7;            // lower bound of the 7th neighbour's squared distance
     uint32_t n_eval, n_shell;
 };
 
@@ -1056,33 +1056,43 @@ struct Set6 {
 // 5th and 6th best distances are equal floats; then - lattices, duplicated points - the 64-bit-key search (distance, original index)
 // is run for this lane and its first five entries are the canonical set.  (A tie between the 6th best and a point outside does not
 // matter: neither belongs to the five, and both are at the distance the certificate uses.)
-DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, Set6 &out) {
+DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, Set6 &out) {
     HeapFast<6> hf;
-    knn_search<HeapFast<6>>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
+    knn_search<HeapFast<6>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl);
     out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
+    // the 7th neighbour: nothing the walk saw and did not keep is nearer than outside_min, and it never looked at anything nearer
+    // than its final pruning distance or, failing that, the bound it started from
+    out.lb7 = fminf(hf.outside_min, fminf(hf.worst_d2(), bound_f));
     if (hf.pos[5] != kNoIdx && hf.d[4] == hf.d[5]) {
         HeapExact<6> he;
         knn_search<HeapExact<6>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
         out.n_eval += he.n_eval;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { out.pos[j] = he.pos[j]; out.d2[j] = he.dist(j); }
+        out.lb7 = out.d2[5];         // (no claim beyond the 6th: such a query is searched again every time)
     }
 }
 
-// The certificate of a search (kStateRows comment above).  a4 / a5 = distances of the 5th / 6th neighbour, or - where the search
-// found fewer inside its bound - the bound, which every point it did not return lies beyond.  All distances are floats of
-// dist2_nofma (within 3e-7 relative of the real squared distance) and of a 1-ulp square root, i.e. within 2.1e-7 of the real distance:
-// each enters with a 2e-6 relative margin on its bad side, so that a certified set also keeps a 5th / 6th FLOAT distance gap of
-// > 1.7e-6 (a4 + a5) wherever the certificate holds - ten times what the rounding of the fresh distances can close.
+// The certificate of a search (kStateRows comment above).  a4 / a5 = distances of the 5th / 6th neighbour, a6 = the lower bound of
+// the 7th's, or - where the search found fewer inside its bound - the bound, which every point it did not return lies beyond.  All
+// distances are floats of dist2_nofma (within 3e-7 relative of the real squared distance) and of a 1-ulp square root, i.e. within
+// 2.1e-7 of the real distance: each enters with a 2e-6 relative margin on its bad side, so that a certified set also keeps a FLOAT
+// distance gap of > 1.7e-6 (a4 + a5) to the first point outside it wherever the certificate holds - ten times what the rounding of
+// the fresh distances can close.
 DCREG_DEVFN uint32_t make_cert(const Set6 &s, const LinArgs &a) {
-    const float a4 = sqrt_approx(s.d2[4]), a5 = sqrt_approx(s.d2[5]);
+    const float a4 = sqrt_approx(s.d2[4]), a5 = sqrt_approx(s.d2[5]), a6 = sqrt_approx(s.lb7);
     const float s_out = a4 * 0.999998f - a.cert_r_out;                                          // > 0: the 5th neighbour is beyond the gate radius
-    const float s_set = s.pos[4] != kNoIdx ? 0.5f * (a5 * 0.999998f - a4 * 1.000002f) : -1.f;
-    if (s_out > 0.f && s_out >= s_set) return __float_as_uint(s_out) | 0x80000000u;
-    return __float_as_uint(fmaxf(s_set, 0.f));                                                   // 0: valid now, to be searched again next time
+    const float s5 = s.pos[4] != kNoIdx ? 0.5f * (a5 * 0.999998f - a4 * 1.000002f) : -1.f;
+    const float s6 = s.pos[5] != kNoIdx ? 0.5f * (a6 * 0.999998f - a5 * 1.000002f) : -1.f;
+    if (s_out > 0.f && s_out >= fmaxf(s5, s6)) return __float_as_uint(s_out) | 0x80000000u;
+    // (clearing / setting the lowest mantissa bit moves s by at most one ulp: rounded down where it matters)
+    if (s6 > s5) return (__float_as_uint(fmaxf(s6 * 0.9999998f, 0.f)) & ~1u) | 1u;
+    return __float_as_uint(fmaxf(s5, 0.f)) & ~1u;                                                // 0: valid now, to be searched again next time
 }
+DCREG_DEVFN bool cert_is_out(uint32_t cert) { return (cert & 0x80000000u) != 0u; }
+DCREG_DEVFN bool cert_is_set6(uint32_t cert) { return (cert & 0x80000001u) == 1u; }
 
 // A later linearisation of the same query: does the certificate of its last search still hold at the new position?  The displacement
 // is the difference of two stored floats per coordinate - exact unless a coordinate changed by more than a factor of two, and then it is
@@ -1112,14 +1122,19 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
                              float qx, float qy, float qz, Set6 &st, uint32_t &cert) {
     float bound = a.radius_sq_f;
     if (warm && oldpos[5] != kNoIdx) bound = warm_bound6(g, oldpos, qx, qy, qz, bound);
+    // a search whose ball is small (the query sits among its neighbours: the regime in which certificates get used) looks a little
+    // further than it must - bound and pruning distance inflated alike, so that what lies beyond is a useful lower bound for the 7th
+    // neighbour; a search over many cells (a query far from the surface it belongs to) is expensive enough as it is
+    float infl = 1.f;
+    if (bound <= a.infl_max_d2) { infl = a.prune_infl; bound = fminf(bound * infl, a.radius_sq_f); }
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)a.max_ring + 1.0;
     // a query farther than max_ring cells from the grid has no neighbour inside the search bound
     const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
-    st.n_eval = 0; st.n_shell = 1;
-    if (reach) search6(g, runs, qx, qy, qz, bound, a.max_ring, st);
+    st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;
+    if (reach) search6(g, runs, qx, qy, qz, bound, a.max_ring, infl, st);
     cert = make_cert(st, a);
 }
 
@@ -1204,33 +1219,42 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
     return 1;
 }
 
-// Steps 2b-5 for a query whose nearest-five SET is known (pos: positions in the sorted target, any order): gather the points,
-// recompute the float distances from the query's current position, put them into the canonical (distance, original index) order -
-// bitwise the result list of a fresh search at this pose - and build the row.  `nn` receives the ordered set (debug dumps).
+// Steps 2b-5 for a query whose nearest-five SET is known - exactly (five positions; six = false or this lane's pos[5] = kNoIdx) or as
+// "the five nearest of these six" (SET6 certificate): gather the points, recompute the float distances from the query's current
+// position, put them into the canonical (distance, original index) order - the first five are bitwise the result list of a fresh
+// search at this pose - and build the row.  `six` is uniform over the wave; `nn` receives the ordered five (debug dumps).
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t row_from_set(const GridDev &g, const PoseArg &P, const LinArgs &a, const float4 &s4, float qx, float qy, float qz,
-                                 const uint32_t (&pos)[5], KnnResult<5> &nn, double (&row)[8], double (&nrm)[3], double &r_out, double &s_out) {
+                                 const uint32_t (&pos)[6], bool six, KnnResult<5> &nn, double (&row)[8], double (&nrm)[3], double &r_out,
+                                 double &s_out) {
+    float d2[6];
+    float4 pt[6];
+    const bool use6 = six && pos[5] != kNoIdx;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) { nn.pos[j] = pos[j]; nn.pt[j] = g.pts[pos[j]]; }
+    for (int j = 0; j < 5; ++j) pt[j] = g.pts[pos[j]];
+    pt[5] = use6 ? g.pts[pos[5]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) nn.d2[j] = dist2_nofma(qx, qy, qz, nn.pt[j]);
-    // sorting network of 9 compare-exchanges on the key (distance bits, original index): distances are >= 0, so their bit patterns
-    // order like the values
+    for (int j = 0; j < 5; ++j) d2[j] = dist2_nofma(qx, qy, qz, pt[j]);
+    d2[5] = use6 ? dist2_nofma(qx, qy, qz, pt[5]) : __builtin_inff();            // a lane with five sorts its padding last
+    // sorting network on the key (distance bits, original index): distances are >= 0, so their bit patterns order like the values
     auto cswap = [&](int x, int y) {
-        const uint64_t kx = ((uint64_t)__float_as_uint(nn.d2[x]) << 32) | __float_as_uint(nn.pt[x].w);
-        const uint64_t ky = ((uint64_t)__float_as_uint(nn.d2[y]) << 32) | __float_as_uint(nn.pt[y].w);
+        const uint64_t kx = ((uint64_t)__float_as_uint(d2[x]) << 32) | __float_as_uint(pt[x].w);
+        const uint64_t ky = ((uint64_t)__float_as_uint(d2[y]) << 32) | __float_as_uint(pt[y].w);
         const bool sw = ky < kx;
-        const float dx = nn.d2[x], dy = nn.d2[y];
-        const float4 px = nn.pt[x], py = nn.pt[y];
-        const uint32_t ox = nn.pos[x], oy = nn.pos[y];
-        nn.d2[x] = sw ? dy : dx; nn.d2[y] = sw ? dx : dy;
-        nn.pt[x].x = sw ? py.x : px.x; nn.pt[x].y = sw ? py.y : px.y; nn.pt[x].z = sw ? py.z : px.z; nn.pt[x].w = sw ? py.w : px.w;
-        nn.pt[y].x = sw ? px.x : py.x; nn.pt[y].y = sw ? px.y : py.y; nn.pt[y].z = sw ? px.z : py.z; nn.pt[y].w = sw ? px.w : py.w;
-        nn.pos[x] = sw ? oy : ox; nn.pos[y] = sw ? ox : oy;
+        const float dx = d2[x], dy = d2[y];
+        const float4 px = pt[x], py = pt[y];
+        d2[x] = sw ? dy : dx; d2[y] = sw ? dx : dy;
+        pt[x].x = sw ? py.x : px.x; pt[x].y = sw ? py.y : px.y; pt[x].z = sw ? py.z : px.z; pt[x].w = sw ? py.w : px.w;
+        pt[y].x = sw ? px.x : py.x; pt[y].y = sw ? px.y : py.y; pt[y].z = sw ? px.z : py.z; pt[y].w = sw ? px.w : py.w;
     };
-    cswap(0, 1); cswap(3, 4); cswap(2, 4); cswap(2, 3); cswap(0, 3); cswap(0, 2); cswap(1, 4); cswap(1, 3); cswap(1, 2);
+    if (six) {          // 12 compare-exchanges for six
+        cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(0, 2); cswap(3, 5); cswap(1, 4);
+        cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(1, 2); cswap(3, 4); cswap(2, 3);
+    } else {            // 9 for five
+        cswap(0, 1); cswap(3, 4); cswap(2, 4); cswap(2, 3); cswap(0, 3); cswap(0, 2); cswap(1, 4); cswap(1, 3); cswap(1, 2);
+    }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) nn.idx[j] = __float_as_uint(nn.pt[j].w);
+    for (int j = 0; j < 5; ++j) { nn.d2[j] = d2[j]; nn.pt[j] = pt[j]; nn.idx[j] = __float_as_uint(pt[j].w); nn.pos[j] = 0u; }
     nn.full = true; nn.n_eval = 0; nn.n_shell = 0;
     PointQuery q;
     q.qx = qx; q.qy = qy; q.qz = qz; q.reach = true;

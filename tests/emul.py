@@ -18,7 +18,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 class LinParams(C.Structure):
     _fields_ = [("search_radius", C.c_double), ("max_plane_thickness_sq", C.c_double), ("min_normal_norm", C.c_double),
                 ("weight_slope", C.c_double), ("weight_min", C.c_double), ("use_weight_derivative", C.c_int32),
-                ("fast_plane_fit", C.c_int32), ("cert_margin", C.c_double)]
+                ("fast_plane_fit", C.c_int32), ("cert_margin", C.c_double), ("cert_inflate", C.c_double)]
 
 
 def build(force=False):
@@ -68,6 +68,7 @@ def plane_fit(Q, fast):
 
 CERT_MARGIN = 0.05      # dcreg_ctx::opt_cert_margin
 CERT_MOVE = 0.5         # dcreg_ctx::opt_cert_move
+CERT_INFLATE = 0.04     # dcreg_ctx::opt_cert_inflate
 
 
 class Index:
@@ -118,13 +119,13 @@ class Source:
 
 
 def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0, cert_move=CERT_MOVE,
-              plan=None):
+              plan=None, cert_inflate=CERT_INFLATE):
     """One linearisation through the device functions on the host -> dict like Context.linearize (+ "stats" [n, 8] in
     processing order: candidates, outermost shell, table loads, rows, runs, trips, faces, face skips).
     plan: None = as context.hip decides ("full" on a fresh state / debug / a pose change that may move a point farther than cert_move
     cells, else "cert"), or force "full" / "cert" (a fresh state is always searched in full)."""
     radius = index.radius if radius is None else radius
-    prm = LinParams(radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, int(wd), int(fast), index.cert_margin)
+    prm = LinParams(radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, int(wd), int(fast), index.cert_margin, cert_inflate)
     n = source.n
     fresh = source.state is None or source.prev_index is not index      # a new target voids positions and certificates
     if warm and fresh:

@@ -183,7 +183,7 @@ void emu_hilbert_order(const float *xyz, int64_t n, uint32_t *order) {
 struct EmuLinParams {
     double search_radius, max_plane_thickness_sq, min_normal_norm, weight_slope, weight_min;
     int32_t use_weight_derivative, fast_plane_fit;
-    double cert_margin;
+    double cert_margin, cert_inflate;
 };
 
 // One linearisation of `n` queries (src_xyz in the order given; order[i] = original index written into the per-point
@@ -218,6 +218,8 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     while (k < 100000) { const double safe = (double)k * g.h * (1.0 - 1e-9); if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break; ++k; }
     a.max_ring = k;
     a.warm = warm;
+    a.prune_infl = (float)((1.0 + p->cert_inflate) * (1.0 + p->cert_inflate));
+    a.infl_max_d2 = (float)(4.0 * g.h * g.h);
     a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0;
     PoseArg P{};
     std::memcpy(P.R, R, sizeof(P.R)); std::memcpy(P.t, t, sizeof(P.t));
@@ -264,11 +266,13 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         double row[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
         uint8_t fl = 0;
         KnnResult<5> nn{};
-        if (!(cert & 0x80000000u)) {             // SET: rows from the five positions (k_rows / k_full)
-            uint32_t pos[5];
-            for (int j = 0; j < 5; ++j) pos[j] = pos6[j];
-            fl = p->fast_plane_fit ? row_from_set<true>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, rr, ss)
-                                   : row_from_set<false>(g, P, a, s4, qx, qy, qz, pos, nn, row, nrm, rr, ss);
+        if (!cert_is_out(cert)) {                // SET5 / SET6: rows from the known positions (k_rows; k_full after a search takes five)
+            uint32_t pos[6];
+            for (int j = 0; j < 6; ++j) pos[j] = pos6[j];
+            const bool six = !need && cert_is_set6(cert);
+            if (!six) pos[5] = kNoIdx;
+            fl = p->fast_plane_fit ? row_from_set<true>(g, P, a, s4, qx, qy, qz, pos, six, nn, row, nrm, rr, ss)
+                                   : row_from_set<false>(g, P, a, s4, qx, qy, qz, pos, six, nn, row, nrm, rr, ss);
         }
         row_products(row, fl, acc);
         for (int j = 0; j < 31; ++j) tot[j] += acc[j];
