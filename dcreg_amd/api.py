@@ -48,8 +48,7 @@ class LinDebug(C.Structure):
 
 
 class LaunchStats(C.Structure):
-    _fields_ = [("poses_searched", C.c_int64), ("poses_certified", C.c_int64), ("last_queries_listed", C.c_int64),
-                ("last_blocks_listed", C.c_int64)]
+    _fields_ = [("launches", C.c_int64), ("poses", C.c_int64), ("points", C.c_int64), ("points_searched", C.c_int64)]
 
 
 class IndexInfo(C.Structure):

@@ -41,6 +41,7 @@ static int ensure(dcreg_ctx *c, T *&ptr, size_t &cap, size_t need) {
     return DCREG_OK;
 }
 
+constexpr size_t kSearchCountBytes = 64 * kCounterStride * sizeof(uint32_t);     // 64 counters, one per 128-byte line
 static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 static void drop_warm(dcreg_ctx *c);
 
@@ -332,26 +333,11 @@ static void free_tmp(LinSlot &S) {
     S.tmp_dev.clear();
 }
 
-// bound on how far any source point has moved since the launch that last touched the ctx's own state (|dR|_F * largest |p| + |dt|);
-// then that launch's pose becomes this one
-static double pose_move(dcreg_ctx *c, const double *R, const double *t) {
-    WarmPose &w = c->prev_pose;
-    double fro = 0.0, tr = 0.0;
-    for (int k = 0; k < 9; ++k) { const double d = w.valid ? R[k] - w.R[k] : 0.0; fro += d * d; }
-    for (int k = 0; k < 3; ++k) { const double d = w.valid ? t[k] - w.t[k] : 0.0; tr += d * d; }
-    const double max_move = w.valid ? std::sqrt(fro) * c->src_radius + std::sqrt(tr) : 1e300;
-    std::memcpy(w.R, R, sizeof(w.R)); std::memcpy(w.t, t, sizeof(w.t));
-    w.valid = true;
-    c->last_max_move = max_move;
-    return max_move;
-}
 // after a launch that may not have run: what the states hold is unknown
 static void drop_warm(dcreg_ctx *c) {
-    c->state_valid = false; c->prev_pose.valid = false; c->last_max_move = 1e300;
+    c->state_valid = false;
     std::fill(c->batch_state_valid.begin(), c->batch_state_valid.end(), (uint8_t)0);
 }
-static bool certifies(const dcreg_ctx *c, double max_move) { return c->opt_cert_move > 0.0 && max_move <= c->opt_cert_move * c->grid.h; }
-
 // publish a gate record (kernels.hpp GateHost): pose words and checksum first, the number last.  R == null: an abort, the pose words
 // stay whatever they were.
 static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double *R, const double *t) {
@@ -370,35 +356,6 @@ static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double
     __atomic_store_n(&c->h_gate->w[0], w[0], __ATOMIC_RELEASE);
 }
 static void gate_call_off(dcreg_ctx *c) { gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr); }
-
-// work lists of certifying launches: room for every query / block of the launch on any one of the lists' shares
-static int ensure_lists(dcreg_ctx *c, uint32_t nbx, int n_poses, ListArgs &wl) {
-    if (!c->d_list_count) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_list_count, sizeof(uint32_t) * 2 * 2 * kWorkLists * kCounterStride));
-        HIP_TRY(c, hipMemsetAsync(c->d_list_count, 0, sizeof(uint32_t) * 2 * 2 * kWorkLists * kCounterStride, c->stream));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_list_counts, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
-        c->h_list_counts[0] = c->h_list_counts[1] = 0;
-        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_list_counts_host, c->h_list_counts, 0));
-    }
-    const size_t b_cap = ((size_t)nbx + kWorkLists - 1) / kWorkLists * (size_t)n_poses, q_cap = b_cap * kBlock;
-    if (b_cap >= ((size_t)1 << 31) / kBlock) { c->fail("too many queries in one launch for the work lists"); return DCREG_E_INVALID; }
-    if (ensure(c, c->d_q_entries, c->q_entries_cap, q_cap * kWorkLists) || ensure(c, c->d_b_entries, c->b_entries_cap, b_cap * kWorkLists)) return DCREG_E_NOMEM;
-    wl.count = c->d_list_count; wl.q_entries = c->d_q_entries; wl.b_entries = c->d_b_entries;
-    wl.q_cap = (uint32_t)q_cap; wl.b_cap = (uint32_t)b_cap;
-    wl.host_counts = c->d_list_counts_host;
-    return DCREG_OK;
-}
-// grid of a list kernel: persistent blocks, a multiple of the number of lists.  The loops inside take whatever is on the lists, so the
-// size only matters for speed: a kernel whose 2048 blocks all find their list empty still occupies the stream for 5-6 us (a small
-// one for 2-3), a kernel with too few blocks serialises real work.  hint = what the previous certifying launch had on its lists (the
-// lists shrink along a converging trajectory), or -1 when that is not known: then, and for anything but a short list, be generous.
-static unsigned list_grid(size_t max_items, size_t per_block, long long hint) {
-    size_t want = max_items;
-    if (hint >= 0 && (size_t)hint * 8 < 64 * per_block) want = std::min(max_items, std::max<size_t>((size_t)hint * 8, 1));
-    size_t blocks = (want + per_block - 1) / per_block;
-    blocks = std::min<size_t>(std::max<size_t>(blocks, kWorkLists), 2048);
-    return (unsigned)((blocks + kWorkLists - 1) / kWorkLists * kWorkLists);
-}
 
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
 // _gate_abort decide its fate)
@@ -453,11 +410,6 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     PoseArg one{};
     one.state = kNoIdx; one.fresh = 1;
     const PoseArg *d_poses = nullptr;
-    // The launch plan.  n_cert poses are linearised by charging certificates (k_rows, then the two list kernels), n_full by
-    // searching everything (k_full); d_ids_* = which poses, for batched launches that mix both.
-    int n_cert = 0, n_full = n_poses;
-    bool inwave = false;            // the searching kernel tests certificates itself and searches only the lanes that need it
-    const uint32_t *d_ids_cert = nullptr, *d_ids_full = nullptr;
     bool uses_state = false;
     const bool state_was_valid = c->state_valid;
     if (n_poses == 1 && !state_ids) {
@@ -467,18 +419,10 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             if (!c->state_valid || c->state_stride != stride) {
                 if (ensure(c, c->d_state, c->state_cap, kStateRows * stride)) return DCREG_E_NOMEM;
                 c->state_stride = stride; c->state_valid = false;
-                c->prev_pose.valid = false; c->last_max_move = 1e300;
             }
             uses_state = true;
             one.state = 0; one.fresh = c->state_valid ? 0u : 1u;
             a.state = c->d_state; a.state_stride = (uint32_t)c->state_stride;
-            // which plan: a launch with a known pose decides on that pose; a gated one (its pose comes later) on what the last launch
-            // saw - a wrong guess only costs time
-            double max_move = c->last_max_move;
-            if (!gated) max_move = pose_move(c, one.R, one.t);
-            if (c->state_valid && !dbg_host && certifies(c, max_move)) {
-                if (c->opt_cert_plan == 0) inwave = true; else { n_cert = 1; n_full = 0; }
-            }
         }
         if (gated) {
             if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
@@ -513,44 +457,30 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
                 seen[(size_t)sid] = 1;
             }
         }
-        const size_t bytes = (size_t)n_poses * (sizeof(PoseArg) + sizeof(uint32_t));
+        const size_t bytes = (size_t)n_poses * sizeof(PoseArg);
         if (bytes > S.poses_cap) {      // the pinned block stays alive until end(): source of the asynchronous copy
             if (S.h_poses) (void)hipHostFree(S.h_poses);
             if (S.d_poses) (void)hipFree(S.d_poses);
             S.h_poses = nullptr; S.d_poses = nullptr; S.poses_cap = 0;
-            const size_t cap = std::max<size_t>(bytes, 256 * (sizeof(PoseArg) + sizeof(uint32_t)));
+            const size_t cap = std::max<size_t>(bytes, 256 * sizeof(PoseArg));
             HIP_TRY(c, hipHostMalloc((void **)&S.h_poses, cap, hipHostMallocDefault));
             if (hipMalloc((void **)&S.d_poses, cap) != hipSuccess) { c->fail("hipMalloc(%zu B) failed", cap); return DCREG_E_NOMEM; }
             S.poses_cap = cap;
         }
         PoseArg *hp = (PoseArg *)S.h_poses;
-        uint32_t *hid = (uint32_t *)(S.h_poses + (size_t)n_poses * sizeof(PoseArg));
-        // pose ids: the certifying poses first (front to back), the searching ones last (back to front)
-        n_cert = 0; n_full = 0;
         for (int i = 0; i < n_poses; ++i) {
             std::memcpy(hp[i].R, R9 + 9 * i, sizeof(one.R)); std::memcpy(hp[i].t, t3 + 3 * i, sizeof(one.t));
             const bool has = use_states && state_ids[i] >= 0;
             hp[i].state = has ? (uint32_t)state_ids[i] : kNoIdx;
-            const bool valid = has && c->batch_state_valid[(size_t)state_ids[i]] != 0;
-            hp[i].fresh = valid ? 0u : 1u;
-            // a state that holds certificates is charged (k_rows); anything else is searched in full (k_full)
-            if (valid && c->opt_cert_move > 0.0 && c->opt_cert_plan != 0) hid[n_cert++] = (uint32_t)i; else hid[n_poses - 1 - n_full++] = (uint32_t)i;
+            hp[i].fresh = (has && c->batch_state_valid[(size_t)state_ids[i]] != 0) ? 0u : 1u;
             if (has) c->batch_state_valid[(size_t)state_ids[i]] = 1;
         }
         HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->stream));
         d_poses = (const PoseArg *)S.d_poses;
-        const uint32_t *d_ids = (const uint32_t *)(S.d_poses + (size_t)n_poses * sizeof(PoseArg));
-        d_ids_cert = d_ids; d_ids_full = d_ids + (n_poses - n_full);
         if (use_states) { a.state = c->d_state_batch; a.state_stride = (uint32_t)c->state_batch_stride; }
-        inwave = use_states && c->opt_cert_move > 0.0 && c->opt_cert_plan == 0;      // (fresh states are flagged per pose)
     }
-    ListArgs wl{};
-    if (n_cert > 0) {
-        rc = ensure_lists(c, nbx, n_cert, wl);
-        if (rc) { c->state_valid = state_was_valid; if (!fused) drop_warm(c); return rc; }
-        c->list_parity ^= 1u;
-        wl.parity = c->list_parity;
-    }
+    a.use_cert = (dbg_host || !c->opt_use_cert) ? 0 : 1;          // a debug dump searches every point (its statistics are those of the searches)
+    a.search_count = c->opt_count_searches ? c->d_search_count : nullptr;
     DebugDev dd{};
     free_tmp(S);
     if (dbg_host) {
@@ -595,36 +525,15 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     const bool fast = c->opt_fast_plane;
-    if (n_cert > 0) {
-        const dim3 grid(nbx, (unsigned)n_cert);
-        const size_t max_q = (size_t)n_cert * (size_t)n, max_b = (size_t)n_cert * nbx;
-        // (the hint is one launch stale when launches are pipelined, and unknown after a searching launch)
-        const bool hinted = false;      // (see list_grid: a stale report after a pose jump must never shrink a grid)
-        const unsigned gq = list_grid(max_q, kBlock, hinted ? (long long)__atomic_load_n(&c->h_list_counts[0], __ATOMIC_ACQUIRE) : -1);
-        const unsigned gb = list_grid(max_b, 1, hinted ? (long long)__atomic_load_n(&c->h_list_counts[1], __ATOMIC_ACQUIRE) : -1);
-#define DCREG_LAUNCH_ROWS(FUSED, FAST, LISTED, GRID)                                                                                      \
-    hipLaunchKernelGGL((k_rows<FUSED, FAST, LISTED>), GRID, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses,    \
-                       d_ids_cert, a, S.d_partials, nbx, fin, wl, abort_flag)
-        if (fused) { if (fast) DCREG_LAUNCH_ROWS(true, true, false, grid); else DCREG_LAUNCH_ROWS(true, false, false, grid); }
-        else { if (fast) DCREG_LAUNCH_ROWS(false, true, false, grid); else DCREG_LAUNCH_ROWS(false, false, false, grid); }
-        hipLaunchKernelGGL(k_search_list, dim3(gq), dim3(kBlock), 0, c->stream, c->d_src, c->grid, one, d_poses, a, wl, abort_flag);
-        if (fused) { if (fast) DCREG_LAUNCH_ROWS(true, true, true, dim3(gb)); else DCREG_LAUNCH_ROWS(true, false, true, dim3(gb)); }
-        else { if (fast) DCREG_LAUNCH_ROWS(false, true, true, dim3(gb)); else DCREG_LAUNCH_ROWS(false, false, true, dim3(gb)); }
-#undef DCREG_LAUNCH_ROWS
-    }
-    if (n_full > 0) {
-        const dim3 grid(nbx, (unsigned)n_full);
-#define DCREG_LAUNCH_FULL(MODE, FUSED, FAST, CERT)                                                                                         \
-    hipLaunchKernelGGL((k_full<MODE, FUSED, FAST, CERT>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, \
-                       d_ids_full, a, S.d_partials, nbx, fin, dd, abort_flag)
-        if (dbg_host) { if (fast) DCREG_LAUNCH_FULL(1, true, true, false); else DCREG_LAUNCH_FULL(1, true, false, false); }
-        else if (inwave) {
-            if (fused) { if (fast) DCREG_LAUNCH_FULL(0, true, true, true); else DCREG_LAUNCH_FULL(0, true, false, true); }
-            else { if (fast) DCREG_LAUNCH_FULL(0, false, true, true); else DCREG_LAUNCH_FULL(0, false, false, true); }
-        }
-        else if (fused) { if (fast) DCREG_LAUNCH_FULL(0, true, true, false); else DCREG_LAUNCH_FULL(0, true, false, false); }
-        else { if (fast) DCREG_LAUNCH_FULL(0, false, true, false); else DCREG_LAUNCH_FULL(0, false, false, false); }
-#undef DCREG_LAUNCH_FULL
+    {
+        const dim3 grid(nbx, (unsigned)n_poses);
+#define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
+    hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
+                       S.d_partials, nbx, fin, dd, abort_flag)
+        if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
+        else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
+        else { if (fast) DCREG_LAUNCH_LIN(0, false, true); else DCREG_LAUNCH_LIN(0, false, false); }
+#undef DCREG_LAUNCH_LIN
     }
     {   // an invalid launch (bad grid, too many resources) must surface here, not as a spin timeout in end()
         const hipError_t le = hipGetLastError();
@@ -654,15 +563,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             return bail("copying the debug dump back", ce);
         }
     }
-    if (inwave) c->n_poses_certified += n_full; else c->n_poses_searched += n_full;
-    c->n_poses_certified += n_cert;
-    c->last_plan_certified = n_cert > 0 && n_full == 0;
+    c->n_launches += 1; c->n_poses_launched += n_poses; c->n_points_launched += (int64_t)n_poses * n;
     if (uses_state) c->state_valid = true;          // once this launch has run, the state holds a search of the current clouds
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
-    S.seq = seq; S.sync = dbg_host != nullptr; S.certifying = n_cert > 0;
+    S.seq = seq; S.sync = dbg_host != nullptr;
     if (gated) {
         c->gate_slot = slot;
-        c->gate_uses_state = uses_state; c->gate_certifying = n_cert > 0; c->gate_state_was_valid = state_was_valid;
+        c->gate_uses_state = uses_state; c->gate_state_was_valid = state_was_valid;
     }
     return DCREG_OK;
 }
@@ -839,10 +746,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_list_count, c->d_q_entries,
-                    c->d_b_entries, c->d_gap};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap};
     for (void *b : bufs) if (b) (void)hipFree(b);
-    if (c->h_list_counts) (void)hipHostFree(c->h_list_counts);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
         for (void *b : S.tmp_dev) (void)hipFree(b);
@@ -868,9 +773,15 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     const std::string k(key);
     if (k == "cell") c->opt_cell = v;
     else if (k == "cell_factor") c->opt_cell_factor = v > 0.1 ? v : 2.0;
-    else if (k == "cert_move" || k == "small_move") c->opt_cert_move = v >= 0.0 ? v : 0.0;
+    else if (k == "use_certificates") c->opt_use_cert = v != 0.0;
+    else if (k == "count_searches") {
+        if (v != 0.0 && !c->d_search_count) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_search_count, kSearchCountBytes));
+            HIP_TRY(c, hipMemsetAsync(c->d_search_count, 0, kSearchCountBytes, c->stream));
+        }
+        c->opt_count_searches = v != 0.0;
+    }
     else if (k == "cert_margin") { c->opt_cert_margin = v >= 1e-4 ? std::min(v, 1.0) : 1e-4; drop_warm(c); }    // the cells follow at the next dcreg_set_target
-    else if (k == "cert_plan") c->opt_cert_plan = (int)v;
     else if (k == "cert_inflate") { c->opt_cert_inflate = v >= 0.0 ? std::min(v, 1.0) : 0.0; drop_warm(c); }
     else if (k == "wait_seconds") c->opt_wait_seconds = v > 0.0 ? v : 30.0;
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
@@ -943,7 +854,6 @@ int dcreg_linearize_gated_begin(dcreg_ctx *c, int slot, const dcreg_lin_params *
 int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
-    if (c->gate_uses_state) (void)pose_move(c, R, t);             // the queued launch reads and writes the ctx's own state
     gate_publish(c, c->gate_seq << 1, R, t);
     c->gate_slot = -1;
     return DCREG_OK;
@@ -957,7 +867,6 @@ int dcreg_linearize_gate_abort(dcreg_ctx *c) {
     free_tmp(S);
     // the kernels behind the gate return without touching anything: the state, its pose and the list counters are as before
     if (c->gate_uses_state) c->state_valid = c->gate_state_was_valid;
-    if (c->gate_certifying) c->list_parity ^= 1u;
     c->gate_slot = -1;
     return DCREG_OK;
 }
@@ -993,10 +902,18 @@ int dcreg_index_info_get(const dcreg_ctx *c, dcreg_index_info *info) {
 
 int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
     if (!c || !st) return DCREG_E_INVALID;
-    st->poses_searched = c->n_poses_searched; st->poses_certified = c->n_poses_certified;
-    st->last_queries_listed = c->h_list_counts ? (int64_t)__atomic_load_n(&c->h_list_counts[0], __ATOMIC_ACQUIRE) : 0;
-    st->last_blocks_listed = c->h_list_counts ? (int64_t)__atomic_load_n(&c->h_list_counts[1], __ATOMIC_ACQUIRE) : 0;
-    if (reset) { c->n_poses_searched = 0; c->n_poses_certified = 0; }
+    st->launches = c->n_launches; st->poses = c->n_poses_launched; st->points = c->n_points_launched;
+    st->points_searched = -1;
+    if (c->opt_count_searches && c->d_search_count) {      // synchronous: every launch so far has finished when this returns
+        std::vector<unsigned long long> v(kSearchCountBytes / sizeof(unsigned long long));
+        HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_search_count, kSearchCountBytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        unsigned long long tot = 0;
+        for (size_t k = 0; k < v.size(); k += kCounterStride / 2) tot += v[k];
+        st->points_searched = (int64_t)tot;
+        if (reset) HIP_TRY(c, hipMemsetAsync(c->d_search_count, 0, kSearchCountBytes, c->stream));
+    }
+    if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; }
     return DCREG_OK;
 }
 

@@ -14,8 +14,6 @@ struct dcreg_lin_out;
 struct dcreg_lin_debug;
 
 // buffers and in-flight state of one linearisation slot
-// pose of the launch that last wrote a warm-start state (valid = false: the state is fresh)
-struct WarmPose { double R[9]; double t[3]; bool valid = false; };
 
 struct LinSlot {
     double *d_partials = nullptr; size_t partials_cap = 0;
@@ -27,7 +25,6 @@ struct LinSlot {
     bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
     std::vector<void *> tmp_dev;   // debug dump buffers of the launch in flight
     bool pending = false, fused = false, timed = false, sync = false;
-    bool certifying = false;       // the launch in flight charges certificates (k_rows + lists) rather than searching everything
     int n_poses = 0;
     uint32_t n_chunks = 0;
     size_t n_rows = 0;
@@ -66,9 +63,6 @@ struct dcreg_ctx {
     uint32_t *d_state = nullptr; size_t state_cap = 0;
     size_t state_stride = 0;
     bool state_valid = false;      // the state holds the results of a search of the current clouds
-    WarmPose prev_pose;            // pose of the launch that last touched the ctx's own state
-    double last_max_move = 1e300;  // bound on any source point's move at the last single-pose launch (what a gated launch, queued
-                                   // before its pose exists, assumes about itself)
     double src_radius = 0.0;       // largest distance of a source point from the body-frame origin (bounds a pose change's effect)
     // batched launches: n_batch_states states of the same layout, [state][kStateRows][state_batch_stride] (dcreg_reserve_warm_states),
     // and whether each holds anything yet
@@ -76,12 +70,7 @@ struct dcreg_ctx {
     size_t state_batch_stride = 0;
     int64_t n_batch_states = 0;
     std::vector<uint8_t> batch_state_valid;
-    // work lists of certifying launches (kernels.hpp ListArgs)
-    uint32_t *d_list_count = nullptr;
-    uint2 *d_q_entries = nullptr, *d_b_entries = nullptr; size_t q_entries_cap = 0, b_entries_cap = 0;
-    uint32_t list_parity = 0;
-    bool last_plan_certified = false;      // the pinned list counts below describe the launch before this one
-    unsigned long long *h_list_counts = nullptr, *d_list_counts_host = nullptr;    // pinned [2]: queries / blocks of the last certifying launch
+    unsigned long long *d_search_count = nullptr;      // option "count_searches": points searched since the last reset
 
     // build scratch
     float *d_stage = nullptr; size_t stage_cap = 0;
@@ -99,7 +88,6 @@ struct dcreg_ctx {
     unsigned long long gate_seq = 0;       // number of the gated launch last queued
     int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)
     bool gate_uses_state = false;          // what the queued launch was built with: it reads / writes the ctx's own state,
-    bool gate_certifying = false;          //   it tests certificates (k_rows + work lists: the list parity was advanced for it),
     bool gate_state_was_valid = false;     //   and what state_valid was before it was queued (restored if it is called off)
     static constexpr int kLinSlots = 2;
     LinSlot slots[kLinSlots];
@@ -118,9 +106,8 @@ struct dcreg_ctx {
     // options / timing
     double opt_cell = 0.0, opt_cell_factor = 2.0;
     int opt_x_subdiv = 8;          // x sub-cells per grid cell (1, 2, 4, 8, 16)
-    double opt_cert_move = 0.5;    // fraction of a cell edge: a pose change that moves no source point farther is linearised by testing
-                                   // certificates (k_rows + work lists) instead of searching every query (0 = never)
-    int opt_cert_plan = 0;         // how certificates are used: 0 = inside the searching kernel (k_full<CERT>), 1 = k_rows + work lists
+    bool opt_use_cert = true;      // skip the search of every point whose certificate still holds (0: only bound the searches)
+    bool opt_count_searches = false;
     double opt_cert_inflate = 0.04; // searches prune at (1 + inflate) x the 6th best distance: the 7th neighbour's lower bound (SET6 certificates)
     double opt_cert_margin = 0.05; // searches cover R (1 + margin): what "5th neighbour beyond R" certificates can spend
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
@@ -135,7 +122,7 @@ struct dcreg_ctx {
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
     bool opt_keep_source_order = false;   // experiments only
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
-    int64_t n_poses_searched = 0, n_poses_certified = 0;    // dcreg_launch_stats
+    int64_t n_launches = 0, n_poses_launched = 0, n_points_launched = 0;    // dcreg_launch_stats
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
 

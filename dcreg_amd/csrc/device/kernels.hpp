@@ -120,22 +120,18 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t c
     return (k / chunk) * span + xcd * chunk + (k % chunk);
 }
 
-// ---------------------------------------------------------------- the linearisation kernels
-// One linearisation (steps 1-5 of an iteration, icp_test_runner.cpp:1714-1915) of a pose is either ONE launch
-//   k_full          every block: 6-NN search of every query (bounded by its old neighbours when the state has some), certificate,
-//                   state update, then rows + reduction.  The first launch on a state, launches after a large pose change, poses
-//                   without a state, debug dumps;
-// or, when the pose's state holds certificates (search.hpp kStateRows) and the pose has moved little, up to three:
-//   k_rows<false>   every block: test each query's certificate at its new position.  A block whose queries all still hold one
-//                   needs NO search: it gathers the five known neighbours per query, re-sorts them at the new pose and builds rows +
-//                   reduction.  Otherwise the queries out of budget go, compacted, on the query list, the block on the block list;
-//   k_search_list   dense waves over the query list: 6-NN search, certificate, state update;
-//   k_rows<true>    the listed blocks: rows + reduction for all their 256 queries from the (partly refreshed) state.
-// Every block partial is therefore produced by the same row code from the same exact neighbour sets in the same lane order, whichever
-// kernel runs it, and the chunk / pose sums take the partials in index order: the sums do not depend on which queries were searched.
-// On a converged trajectory the lists are empty, the host has its result after the first kernel and the other two retire in the
-// shadow of the host step.
-// MODE 0: reduction only.  MODE 1 (k_full): also dump per-point results (parity tests).
+// ---------------------------------------------------------------- the linearisation kernel
+// One linearisation (steps 1-5 of an iteration, icp_test_runner.cpp:1714-1915) of a pose is ONE launch of k_lin, one thread per source
+// point: transform; if the point's state holds a certificate (search.hpp kStateRows) that is still good at the new position, no
+// search - otherwise the exact 6-NN search (bounded by the old neighbours when there are some), a new certificate, the state update;
+// then, for every point alike, gather the known neighbours, order them at the new position, plane fit, gates, row; reduction.
+// A wave searches only if one of its 64 points needs it: on a settled trajectory almost none does.  The rows are built by the same
+// code from the same exact neighbour sets in the same lane order whether or not a point was searched, and the block / chunk / pose
+// sums take them in index order: the sums do not depend on the history of the state.
+// (Measured alternative, round 3: certificates tested by a lean search-free kernel that puts the points to search on compacted work
+// lists for two follow-up kernels - 38 us instead of 43.5 us for the settled 1 M launch, but the follow-up kernels cost 10 us of
+// stream time even when the lists are empty and a whole-run bench of 9.8 k instead of 11.4 k it/s: profiles/r03_ablation.md.)
+// MODE 0: reduction only.  MODE 1: also dump per-point results (parity tests).
 struct DebugDev {
     int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
     uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16
@@ -144,13 +140,13 @@ struct DebugDev {
 // Single-pose launches finish inside the kernel (no second launch): blocks are grouped in chunks of kChunk consecutive
 // partial rows; the last block to finish in a chunk (ticket counter) sums that chunk's rows in a fixed order and writes
 // the chunk row, stamped with the launch's sequence number, straight into pinned host-coherent memory.  The host spins on
-// the stamps and adds the few chunk rows in index order.  WHO sums is timing dependent - it may be a block of the last kernel of
-// the launch -, WHAT is summed in which order is not: the result is deterministic.  Batched launches (many poses, few blocks
+// the stamps and adds the few chunk rows in index order.  WHO sums is timing dependent, WHAT is summed in which order is not: the
+// result is deterministic.  Batched launches (many poses, few blocks
 // each) use k_finalize instead: a ticket per block costs more there than the extra launch (measured, profiles/r01_search_ablation.md
 // addendum 5).
 constexpr int kChunk = 64;
 // counters that many blocks hit with atomics live one per 128-byte line: atomics on ONE line are served one after the other (~11 ns
-// each), whatever word they address - 3907 ticket arrivals on two lines were 22 us of a 46 us kernel, 7800 list appends on one 94 us
+// each), whatever word they address - 3907 ticket arrivals on two lines were 10 us of a 46 us kernel
 constexpr int kCounterStride = 32;      // uint32 words
 struct FinArgs {
     unsigned int *tickets;         // [n_chunks * kCounterStride], zero between launches (the last arrival resets its ticket)
@@ -158,21 +154,6 @@ struct FinArgs {
     unsigned long long seq;
 };
 
-// the work lists of a certifying launch: queries to search and blocks to redo, each kept as eight lists (one per XCD's worth of
-// blocks: an append is an atomic on a counter, and one word takes ~88 of them per microsecond; a block appends once per list), double
-// buffered by launch parity - the launch of parity p appends to count[p] and clears count[1 - p] for its successor, so nothing has to
-// be reset between launches
-constexpr int kWorkLists = 8;
-struct ListArgs {
-    uint32_t *count;               // [2][2][kWorkLists] counters, kCounterStride words apart: parity, kind (0 queries, 1 blocks), list
-    uint2 *q_entries;              // [kWorkLists][q_cap]: {pose, query}
-    uint2 *b_entries;              // [kWorkLists][b_cap]: {pose, query block}
-    uint32_t q_cap, b_cap;
-    uint32_t parity;
-    unsigned long long *host_counts;   // pinned [2]: queries searched / blocks redone by the launch, for the host's next grid sizes (may be null)
-    __device__ uint32_t *qcount(uint32_t l) const { return count + (size_t)((parity * 2u + 0u) * kWorkLists + l) * kCounterStride; }
-    __device__ uint32_t *bcount(uint32_t l) const { return count + (size_t)((parity * 2u + 1u) * kWorkLists + l) * kCounterStride; }
-};
 // Cross-block traffic of the tree uses agent-scope (sc1, write-through / L2-coherent) relaxed atomics plus an explicit
 // s_waitcnt instead of __threadfence(): a release fence on gfx950 is a full L2 write-back (buffer_wbl2), measured at
 // +10 us per launch when every block executes one.
@@ -315,163 +296,19 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
     }
 }
 
-// ---------------------------------------------------------------- k_rows: the search-free linearisation
-// LISTED = false: all blocks of the poses given, certificates tested first.  LISTED = true: the blocks on the block lists, after
-// k_search_list has refreshed the queries that were out of budget; certificates are taken as they stand.
-// LDS: 4.5 KB staging per wave + 2 KB; no run lists, no heaps: this kernel's occupancy is set by the plane fit's registers alone.
-template <bool FUSED, bool FAST, bool LISTED>
-static __global__ __launch_bounds__(kBlock, 4) void k_rows(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
-                                                           const PoseArg *__restrict__ poses, const uint32_t *__restrict__ pose_ids,
-                                                           LinArgs a, double *__restrict__ partials,
-                                                           uint32_t n_blocks_x, FinArgs fin, ListArgs wl,
-                                                           const uint32_t *__restrict__ abort_flag) {
-    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
-    __shared__ double red[8][kSlots];
-    __shared__ double cnt[kBlock / 64][2];
-    __shared__ int s_role;
-    __shared__ uint32_t s_wcnt[kBlock / 64], s_qbase;
-    __shared__ double stage[kBlock / kWave][kWave * kRowStride];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t n_entries = 1, e = 0, e_step = 1;
-    const uint2 *list = nullptr;
-    if (LISTED) {
-        const uint32_t l = blockIdx.x & (kWorkLists - 1);
-        n_entries = *wl.bcount(l);
-        list = wl.b_entries + (size_t)l * wl.b_cap;
-        e = blockIdx.x / kWorkLists; e_step = gridDim.x / kWorkLists;
-        if (blockIdx.x == 0 && threadIdx.x < 2 && wl.host_counts) {       // last kernel of the launch: tell the host how much there was
-            unsigned long long tot = 0;
-            for (int k = 0; k < kWorkLists; ++k) tot += threadIdx.x == 0 ? *wl.qcount(k) : *wl.bcount(k);
-            __hip_atomic_store(wl.host_counts + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    } else if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * kWorkLists) {
-        wl.count[(size_t)((1u - wl.parity) * 2u * kWorkLists + threadIdx.x) * kCounterStride] = 0u;       // the successor's counters
-    }
-    for (; e < n_entries; e += e_step) {
-        uint32_t pose_id, vb;
-        if (LISTED) { const uint2 en = list[e]; pose_id = en.x; vb = en.y; }
-        else { pose_id = pose_ids ? pose_ids[blockIdx.y] : blockIdx.y; vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk); }
-        const uint32_t i = vb * kBlock + threadIdx.x;
-        PoseArg P;
-        if (poses) P = poses[pose_id]; else P = pose1;
-        double row[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) row[k] = 0.0;
-        uint8_t flag = 0;
-        const bool have_q = i < n_src;
-        uint32_t *st = a.state + (size_t)P.state * kStateRows * a.state_stride;
-        const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t cert = kCertSearch, pos[6], q0[3] = {0u, 0u, 0u};
-        if (have_q) cert = st[(size_t)6 * a.state_stride + i];
-        if (!LISTED && have_q) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * a.state_stride + i];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) pos[j] = have_q ? st[(size_t)j * a.state_stride + i] : 0u;     // issued with the certificate: one latency
-        float qx, qy, qz;
-        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
-        bool unc = false;
-        unsigned long long unc_mask = 0ull;
-        if (!LISTED) {          // does every query's certificate hold at its new position?
-            unc = have_q && !cert_holds(cert, __uint_as_float(q0[0]), __uint_as_float(q0[1]), __uint_as_float(q0[2]), qx, qy, qz);
-            unc_mask = __builtin_amdgcn_ballot_w64(unc);
-            if (lane == 0) s_wcnt[wave] = (uint32_t)__builtin_popcountll(unc_mask);
-        }
-        if (unc_mask == 0ull) {                // SET certificates: the known neighbours at the new pose
-            const bool set = have_q && !cert_is_out(cert);
-            const bool six = wave_any(set && cert_is_set6(cert));
-            if (!cert_is_set6(cert)) pos[5] = kNoIdx;
-            if (set) {
-                KnnResult<5> nn;
-                double nrm[3], r_pt, s_pt;
-                flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos, six, nn, row, nrm, r_pt, s_pt);
-            }
-        }
-        wave_rows_to_lds(row, flag, stage[wave], red, cnt);
-        __syncthreads();
-        bool dirty = false;
-        if (!LISTED) {
-            const uint32_t w0 = s_wcnt[0], w1 = s_wcnt[1], w2 = s_wcnt[2], w3 = s_wcnt[3];
-            const uint32_t tot = w0 + w1 + w2 + w3;
-            dirty = tot != 0u;
-            if (dirty) {              // some query needs a search: its queries go on the query list, the block on the block list
-                const uint32_t l = blockIdx.x & (kWorkLists - 1);
-                if (threadIdx.x == 0) {
-                    s_qbase = atomicAdd(wl.qcount(l), tot);
-                    const uint32_t slot = atomicAdd(wl.bcount(l), 1u);
-                    wl.b_entries[(size_t)l * wl.b_cap + slot] = make_uint2(pose_id, vb);
-                }
-                __syncthreads();
-                if (unc) {
-                    const uint32_t before = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-                    const uint32_t off = (uint32_t)__builtin_popcountll(unc_mask & ((1ull << lane) - 1ull));
-                    wl.q_entries[(size_t)l * wl.q_cap + s_qbase + before + off] = make_uint2(pose_id, i);
-                }
-            }
-        }
-        if (!dirty) block_publish<FUSED>(red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
-        if (LISTED) __syncthreads();            // the next entry reuses the block's LDS
-    }
-}
-
-// ---------------------------------------------------------------- k_search_list: the searches a certifying launch still needs
-// One query per lane, taken from the query lists in order (the entries of a block are consecutive: neighbouring queries stay
-// neighbours): transform, bound by the old neighbours, exact 6-NN, certificate, state update.  No rows: this kernel's registers are
-// the search's alone.
-static __global__ __launch_bounds__(kBlock, 4) void k_search_list(const float4 *__restrict__ src, GridDev g, PoseArg pose1,
-                                                                  const PoseArg *__restrict__ poses, LinArgs a, ListArgs wl,
-                                                                  const uint32_t *__restrict__ abort_flag) {
-    if (abort_flag && *abort_flag != 0u) return;
-    __shared__ RunList runs[kBlock / kWave];
-    const int wave = threadIdx.x >> 6;
-    const uint32_t l = blockIdx.x & (kWorkLists - 1);
-    const uint32_t n = *wl.qcount(l);
-    const uint2 *list = wl.q_entries + (size_t)l * wl.q_cap;
-    const uint32_t step = (gridDim.x / kWorkLists) * kBlock;
-    for (uint32_t base = (blockIdx.x / kWorkLists) * kBlock; base < n; base += step) {
-        const uint32_t e = base + threadIdx.x;
-        const bool have = e < n;
-        const uint2 en = have ? list[e] : make_uint2(0u, 0u);
-        const uint32_t i = en.y;
-        const PoseArg &P = poses ? poses[en.x] : pose1;
-        uint32_t *st = a.state + (size_t)P.state * kStateRows * a.state_stride;
-        const float4 s4 = have ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t pos6[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) pos6[j] = (have && a.warm) ? st[(size_t)j * a.state_stride + i] : kNoIdx;
-        float qx, qy, qz;
-        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
-        Set6 s6;
-        uint32_t cert;
-        lin_search6(g, runs[wave], a, have, a.warm != 0, pos6, qx, qy, qz, s6, cert);
-        if (have) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) st[(size_t)j * a.state_stride + i] = s6.pos[j];
-            st[(size_t)6 * a.state_stride + i] = cert;
-            st[(size_t)7 * a.state_stride + i] = __float_as_uint(qx); st[(size_t)8 * a.state_stride + i] = __float_as_uint(qy);
-            st[(size_t)9 * a.state_stride + i] = __float_as_uint(qz);
-        }
-    }
-}
-
-// ---------------------------------------------------------------- k_full: search + rows in one kernel
-// CERT = false: every query is searched.  CERT = true: a query whose certificate holds at its new position is not; the waves in which
-// every certificate holds skip the search altogether (the common case on a settled trajectory), the others run it for the lanes that
-// need it.  No lists, no second launch - and no compaction: a wave with one query to search takes about as long as a wave with 64.
-template <int MODE, bool FUSED, bool FAST, bool CERT>
-static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
-                                                           PoseArg pose1, const PoseArg *__restrict__ poses,
-                                                           const uint32_t *__restrict__ pose_ids, LinArgs a,
-                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
-                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
+// ---------------------------------------------------------------- k_lin
+template <int MODE, bool FUSED, bool FAST>
+static __global__ __launch_bounds__(kBlock, 4) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+                                                          PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
+                                                          double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
+                                                          DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
     __shared__ double red[8][kSlots];
     __shared__ double cnt[kBlock / 64][2];
     __shared__ int s_role;
     __shared__ RunList runs[kBlock / kWave];
     const int wave = threadIdx.x >> 6;
-    const uint32_t pose_id = pose_ids ? pose_ids[blockIdx.y] : blockIdx.y;
+    const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
     const uint32_t i = vb * kBlock + threadIdx.x;
     PoseArg P;
@@ -483,6 +320,7 @@ static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restr
     const bool have_q = i < n_src;
     const bool keep = a.state != nullptr && P.state != kNoIdx;              // the pose owns a state
     const bool old = keep && P.fresh == 0u;                                 // ... that holds the results of earlier searches
+    const bool CERT = old && a.use_cert != 0;                               // ... whose certificates are to be used (uniform)
     uint32_t *st = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride : nullptr;
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pos6[6], cert = kCertSearch, q0[3] = {0u, 0u, 0u};
@@ -499,7 +337,10 @@ static __global__ __launch_bounds__(kBlock, 4) void k_full(const float4 *__restr
     bool need = have_q;
     if (CERT) need = have_q && !cert_holds(cert, __uint_as_float(q0[0]), __uint_as_float(q0[1]), __uint_as_float(q0[2]), qx, qy, qz);
     uint32_t stats = 0;
-    if (!CERT || wave_any(need)) {
+    const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
+    if (need_mask != 0ull) {
+        if (a.search_count && (threadIdx.x & 63) == 0)       // 64 counters on lines of their own (kCounterStride): see there
+            atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)__builtin_popcountll(need_mask));
         Set6 s6;
         uint32_t c2;
         lin_search6(g, runs[wave], a, need, old && a.warm != 0, pos6, qx, qy, qz, s6, c2);

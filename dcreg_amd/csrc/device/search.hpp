@@ -92,9 +92,11 @@ struct LinArgs {
     int use_wd;
     int max_ring;                 // rings needed to cover the search bound
     int warm;                     // searches of a non-fresh state are bounded by the old neighbours' distances from the new position
+    int use_cert;                 // ... and skipped for the points whose certificate still holds (0: debug dumps search everything)
     float prune_infl;             // (1 + cert_inflate)^2: the searches prune at the 6th best distance x (1 + cert_inflate), which is
                                   // what makes the 7th neighbour's lower bound - and SET6 certificates - worth something ...
     float infl_max_d2;            // ... for searches bounded by at most this squared distance (a couple of cells)
+    unsigned long long *search_count;   // test / profiling hook: points searched are counted here (one atomic per searching wave), or null
     uint32_t *state;              // [state][kStateRows][state_stride], or null (nothing is kept)
     uint32_t state_stride;
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin

@@ -108,10 +108,10 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *                   point may move before the nearest five can change; later linearisations skip the search of every point whose
  *                   certificate still holds and bound the searches that remain by the old neighbours.  0 = search every point
  *                   from scratch in every call;
- *   "cert_move"     fraction of a grid cell edge, default 0.5, 0 = never: a single-pose launch whose pose change moves no source point
- *                   farther than that tests certificates first (k_rows + work lists); a larger change searches everything at once;
  *   "cert_margin"   default 0.05: searches cover search_radius * (1 + margin), so that "the 5th neighbour is beyond the radius" can
  *                   be certified too (takes effect at the next dcreg_set_target: the grid cells follow the search radius);
+ *   "cert_inflate"  default 0.04: searches among nearby points look 4 % further than they must, which yields the second kind of
+ *                   certificate ("the five nearest are among these six"; search.hpp);
  *   "fast_plane_fit" 1 (default) = the reduced-instruction 5x3 plane fit; 0 = the Eigen-shaped factorisation step for step (planes
  *                   agree to a few ulp, gate flags are identical on every test scene);
  *   "spin"          1 (default) = wait for results on the pinned result flags instead of hipStreamSynchronize;

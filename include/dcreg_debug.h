@@ -34,12 +34,13 @@ int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], con
  * of host time), 0 = off */
 int dcreg_kernel_time(dcreg_ctx *, double *ms_total, int64_t *launches, int reset);
 
-/* how the linearisations since the last reset were carried out */
+/* what the linearisations since the last reset did.  points_searched needs the option "count_searches" = 1 (one atomic per searching
+ * wave: off by default) and makes this call wait for the launches queued so far; -1 when the option is off. */
 typedef struct dcreg_launch_stats {
-    int64_t poses_searched;      /* poses linearised by searching every point (k_full) */
-    int64_t poses_certified;     /* poses linearised by testing certificates first (k_rows + work lists) */
-    int64_t last_queries_listed; /* the most recent certifying launch the device has reported on: points it had to search ... */
-    int64_t last_blocks_listed;  /* ... and 256-point blocks it had to redo after those searches */
+    int64_t launches;          /* kernel launches (a batched launch counts once) */
+    int64_t poses;             /* poses linearised */
+    int64_t points;            /* source points those poses had, all told */
+    int64_t points_searched;   /* ... of which went through the 6-NN search (the others' certificates held) */
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
 
@@ -47,7 +48,9 @@ int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
  *   "time_kernels"       see dcreg_kernel_time;
  *   "xcd_chunk"          query-block -> XCD mapping: 0 = one contiguous run of query blocks per XCD, c = runs of c blocks dealt
  *                        round-robin (default 16);
- *   "keep_source_order"  1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert-curve sort. */
+ *   "keep_source_order"  1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert-curve sort;
+ *   "use_certificates"   0 = search every point in every launch (the old neighbours still bound the searches), 1 = default;
+ *   "count_searches"     see dcreg_launch_stats. */
 
 #ifdef __cplusplus
 }

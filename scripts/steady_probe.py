@@ -23,7 +23,7 @@ T_init = bench.initial_pose(scene)
 res, logs = ctx.icp_run(T_init, "Ours", cfg)
 T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
 cfg.max_iterations = n_more
-ctx.set_option("time_kernels", 1)
+ctx.set_option("time_kernels", 1); ctx.set_option("count_searches", 1)
 ctx.kernel_time(reset=True); ctx.launch_stats(reset=True)
 t0 = time.perf_counter()
 res, logs = ctx.icp_run(T, "Ours", cfg)

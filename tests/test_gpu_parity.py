@@ -586,10 +586,10 @@ def test_empty_space_skip_is_exact(ctx):
 
 
 def test_certificates_only_spare_searches(cyl):
-    """"cert_move" picks, per launch, whether certificates are tested first (k_rows + work lists) or every point is searched at once
-    (k_full).  Either way the sums are bitwise the same: runs with certificates never tested, tested by the default rule and ALWAYS
-    tested (also across big jumps, where every point ends up on the search list) agree bit for bit, blocking and pipelined - and the
-    certifying runs do leave most points unsearched once the pose has settled."""
+    """Certificates decide, per point and launch, whether the 6-NN search can be skipped.  Either way the sums are bitwise the same:
+    a walk that mixes tiny steps, jumps and a trip far outside the cloud, then two pipelined ICP runs, with certificates used and not
+    used ("use_certificates" 0: every point is searched in every launch) agree bit for bit - and with them most points are left
+    unsearched once the pose has settled."""
     tgt = cyl[0]
     src = tgt[::2]
     T0 = h.pose6d_matrix(0.3, -0.2, 0.1, h.deg2rad(2.0), h.deg2rad(-1.0), h.deg2rad(3.0))
@@ -598,28 +598,31 @@ def test_certificates_only_spare_searches(cyl):
     walk = [T0, T0 @ h.pose6d_matrix(1e-5, 0.0, 2e-5, 1e-7, 0.0, -1e-7), T0 @ h.pose6d_matrix(0.5, 0.5, -0.2, 0.0, h.deg2rad(4.0), 0.0), T0,
             T0 @ h.pose6d_matrix(300.0, 0.0, 0.0, 0.0, 0.0, 0.0), T0, T0]
     got = {}
-    for frac in (0.0, 0.5, 1e9):
+    for use in (0, 1):
         c = api.Context(0)
-        c.set_option("cert_move", frac); c.set_target(tgt, 1.0); c.set_source(src)
-        lin = [c.linearize(T[:3, :3], T[:3, 3], prm) for T in walk]
-        st_walk = c.launch_stats(reset=True)
+        c.set_option("use_certificates", use); c.set_option("count_searches", 1)
+        c.set_target(tgt, 1.0); c.set_source(src)
+        lin, searched = [], []
+        for T in walk:
+            lin.append(c.linearize(T[:3, :3], T[:3, 3], prm))
+            searched.append(c.launch_stats(reset=True)["points_searched"])
         res, logs = c.icp_run(T0, "Ours", cfg)                      # pipelined engine, state carried over from the walk
+        st1 = c.launch_stats(reset=True)
         res2, _ = c.icp_run(T0, "Ours", cfg)                        # and once more from the converged state
-        st_run = c.launch_stats()
-        got[frac] = (lin, res.iterations, np.array(res.R[:]), np.array(res.t[:]), np.array(res2.R[:]), np.array(res2.t[:]),
-                     [np.array(L.H_upper[:]) for L in logs], st_walk, st_run)
+        st2 = c.launch_stats(reset=True)
+        got[use] = (lin, res.iterations, np.array(res.R[:]), np.array(res.t[:]), np.array(res2.R[:]), np.array(res2.t[:]),
+                    [np.array(L.H_upper[:]) for L in logs], searched, st1, st2)
         c.close()
-    for frac in (0.5, 1e9):
-        a, b = got[frac], got[0.0]
-        for x, y in zip(a[0], b[0]):
-            assert x["n_eff"] == y["n_eff"] and np.array_equal(x["H_upper"], y["H_upper"]) and np.array_equal(x["g"], y["g"])
-        assert a[1] == b[1] and all(np.array_equal(a[k], b[k]) for k in (2, 3, 4, 5))
-        assert all(np.array_equal(x, y) for x, y in zip(a[6], b[6]))
-    assert got[0.0][7]["poses_certified"] == 0 and got[0.0][8]["poses_certified"] == 0
-    assert got[1e9][7]["poses_certified"] == len(walk) - 1                      # all but the first launch (fresh state)
-    assert 2 <= got[0.5][7]["poses_certified"] < len(walk) - 1                  # the tiny step and the repeated pose, not the jumps
-    assert got[0.5][8]["poses_certified"] >= 30                                  # most of the two 25-iteration runs
-    assert got[0.5][8]["last_queries_listed"] < 0.25 * len(src)                  # settled (the degenerate directions keep drifting a little): few points left to search
+    a, b = got[1], got[0]
+    for x, y in zip(a[0], b[0]):
+        assert x["n_eff"] == y["n_eff"] and np.array_equal(x["H_upper"], y["H_upper"]) and np.array_equal(x["g"], y["g"])
+    assert a[1] == b[1] and all(np.array_equal(a[k], b[k]) for k in (2, 3, 4, 5))
+    assert all(np.array_equal(x, y) for x, y in zip(a[6], b[6]))
+    n = len(src)
+    assert b[7] == [n] * len(walk) and b[8]["points_searched"] == b[8]["points"] == 25 * n      # without: everything, always
+    assert a[7][0] == n and a[7][1] < 0.01 * n and a[7][6] == 0                                  # fresh / a 20 um step / the same pose again
+    assert a[7][4] == n                                                                          # 300 m away: every certificate fails
+    assert a[8]["points_searched"] < 0.75 * a[8]["points"] and a[9]["points_searched"] < 0.75 * a[9]["points"]      # (25 iterations from 0.4 m / 3 deg off)
 
 
 def test_far_from_the_origin_and_very_dense_cells(ctx):
