@@ -122,8 +122,8 @@ EXPORTS = [
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
-    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
-    "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
+    "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_icp_run_montecarlo", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
+    "dcreg_set_host_threads", "dcreg_get_host_threads", "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
 ]
 
 _lib = None
@@ -200,6 +200,10 @@ def load():
     L.dcreg_icp_run_trials.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(TrialResult)]
     L.dcreg_p2p_error.argtypes = [vp, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int64)]
     L.dcreg_trial_pose.argtypes = [dp, C.c_uint64, C.c_int64, C.c_double, C.c_double, dp, dp]
+    L.dcreg_set_host_threads.argtypes = [C.c_int]
+    L.dcreg_get_host_threads.argtypes = []
+    L.dcreg_icp_run_montecarlo.argtypes = [vp, dp, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
+                                           C.POINTER(Config), C.c_int, C.POINTER(TrialResult)]
     L.dcreg_sizeof.restype = C.c_size_t
     L.dcreg_sizeof.argtypes = [C.c_char_p]
     L.dcreg_version.restype = C.c_char_p
@@ -293,6 +297,13 @@ def trial_pose(base_xyzrpy, seed, k, trans_amp, rot_amp_rad):
     if rc:
         raise DcregError("dcreg_trial_pose rc=%d" % rc)
     return T.reshape(4, 4)
+
+
+def set_host_threads(n):
+    """dcreg_set_host_threads: OpenMP threads of the batched engines' host steps (overrides a launcher's OMP_NUM_THREADS=1)."""
+    if load().dcreg_set_host_threads(int(n)) != 0:
+        raise DcregError("dcreg_set_host_threads(%d)" % n)
+    return load().dcreg_get_host_threads()
 
 
 def comm_unique_id():
@@ -552,6 +563,15 @@ class Context:
         self._check(self._L.dcreg_icp_run_euler(self._h, _dp(p0), DETECTION[det], HANDLING[hand], C.byref(cfg), logs, cap,
                                                 C.byref(res), _dp(pf)), "dcreg_icp_run_euler")
         return res, [logs[i] for i in range(max(min(res.iterations, cap), 0))], pf
+
+    def icp_run_montecarlo(self, base_xyzrpy, seed, first_trial, trial_stride, n_trials, trans_amp, rot_amp_rad, method, cfg, slots=0):
+        """dcreg_icp_run_montecarlo: this rank's share of the Monte-Carlo experiment, poses generated and trials batched in C++."""
+        det, hand = METHODS[method]
+        res = (TrialResult * max(int(n_trials), 1))()
+        self._check(self._L.dcreg_icp_run_montecarlo(self._h, _dp(_f64(base_xyzrpy, 6)), int(seed), int(first_trial), int(trial_stride), int(n_trials),
+                                                     float(trans_amp), float(rot_amp_rad), DETECTION[det], HANDLING[hand], C.byref(cfg), int(slots), res),
+                    "dcreg_icp_run_montecarlo")
+        return [res[i] for i in range(int(n_trials))]
 
     def icp_run_trials(self, T0s, method, cfg):
         T0s = _f64(T0s).reshape(-1, 4, 4)

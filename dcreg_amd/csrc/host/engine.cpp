@@ -220,52 +220,69 @@ int dcreg_icp_run_many(int n, dcreg_ctx *const *ctxs, const double *R0, const do
     return DCREG_OK;
 }
 
-int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const double *t0, int detection, int handling,
-                         const dcreg_config *cfg, dcreg_trial_result *results) {
-    if (!ctx || !R0 || !t0 || !cfg || !results || n_trials < 0) return DCREG_E_INVALID;
-    if (n_trials == 0) return DCREG_OK;
-    if (n_trials > 2 * 65535) return DCREG_E_INVALID;   // two groups of at most 65535 poses per launch (grid.y)
+// The num_runs loop of TestRunner::runMethod (:331-390) over independent trials of one cloud pair, as a continuously refilled batch:
+// `slots` trials are in flight at a time, split into two groups that alternate on the device - while the kernel of one group runs
+// the host takes steps 6-9 of the other (the two linearisation slots of the ctx), so the 6x6 solves cost no wall time.  Every
+// group iteration is ONE batched launch over its live trials.  A trial that ends (converged, aborted, out of iterations) hands
+// its slot - and the slot's neighbour state, marked empty - to the next trial in line at once, so the batch stays full until the
+// queue runs dry instead of thinning out while its stragglers finish.  Each trial is bitwise the single run of its initial pose.
+static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, const double *t0, int detection, int handling,
+                           const dcreg_config *cfg, dcreg_trial_result *results, int slots_wanted) {
     const auto t_total = Clock::now();
     const dcreg_lin_params prm = lin_params_of(*cfg);
     dcreg_index_info info;
     dcreg_index_info_get(ctx, &info);
-    std::vector<double> R((size_t)n_trials * 9), t((size_t)n_trials * 3);
-    std::memcpy(R.data(), R0, sizeof(double) * 9 * (size_t)n_trials);
-    std::memcpy(t.data(), t0, sizeof(double) * 3 * (size_t)n_trials);
-    for (int i = 0; i < n_trials; ++i) std::memset(&results[i], 0, sizeof(results[i]));
+    for (int64_t i = 0; i < n_trials; ++i) std::memset(&results[i], 0, sizeof(results[i]));
     if (info.n_source <= 0 || info.n_target <= 0) {
-        for (int i = 0; i < n_trials; ++i) results[i].status = 3;
+        for (int64_t i = 0; i < n_trials; ++i) results[i].status = 3;
         return DCREG_OK;
     }
-    // The trials advance in lock-step, one batched launch per iteration and group.  With enough trials they are split into
-    // two groups that alternate on the device: while the kernels of one group run, the host takes steps 6-9 of the other
-    // (software pipeline over the two linearisation slots of the ctx), so the 6x6 solves cost no wall time.
-    struct Group { std::vector<int> live; std::vector<int32_t> ids; std::vector<double> Rb, tb; std::vector<dcreg_lin_out> outs; int it = 0; bool in_flight = false; };
-    // one warm-start state per trial: every trial bounds its search by its own previous neighbour sets, like a single run
-    {
-        const int rc0 = dcreg_reserve_warm_states(ctx, n_trials);
-        if (rc0 != DCREG_OK) return rc0;
+    if (cfg->max_iterations <= 0) {
+        for (int64_t i = 0; i < n_trials; ++i) {
+            dcreg::stateToMatrix(R0 + 9 * i, t0 + 3 * i, results[i].final_transform);
+            dcreg::poseError(cfg->gt_matrix, results[i].final_transform, &results[i].trans_error_m, &results[i].rot_error_deg);
+        }
+        return DCREG_OK;
     }
+    int n_slots = (int)std::min<int64_t>(n_trials, slots_wanted > 0 ? slots_wanted : 256);
+    n_slots = std::min(n_slots, 2 * 65535);
+    const int n_groups = n_slots >= 64 ? 2 : 1;
+    // one neighbour state per slot; without the memory for them the trials still run, every launch searching from scratch
+    bool have_states = dcreg_reserve_warm_states(ctx, n_slots) == DCREG_OK;
+    struct Slot { int64_t trial = -1; int it = 0; double R[9], t[3]; };
+    std::vector<Slot> slot((size_t)n_slots);
+    struct Group { std::vector<int> live; std::vector<int32_t> ids; std::vector<double> Rb, tb; std::vector<dcreg_lin_out> outs; bool in_flight = false; };
     Group grp[2];
-    const int n_groups = n_trials >= 64 ? 2 : 1;
-    for (int i = 0; i < n_trials; ++i) grp[n_groups == 2 ? (i & 1) : 0].live.push_back(i);
+    int64_t next_trial = 0, done = 0;
+    auto load = [&](int si) -> bool {                      // next trial in line -> slot si
+        if (next_trial >= n_trials) { slot[(size_t)si].trial = -1; return false; }
+        Slot &S = slot[(size_t)si];
+        S.trial = next_trial++; S.it = 0;
+        std::memcpy(S.R, R0 + 9 * S.trial, sizeof(S.R)); std::memcpy(S.t, t0 + 3 * S.trial, sizeof(S.t));
+        if (have_states) dcreg_reset_warm_state(ctx, si);
+        return true;
+    };
+    for (int si = 0; si < n_slots; ++si) load(si);
+    auto group_of = [&](int si) { return n_groups == 2 ? (si & 1) : 0; };
     double t_lin_ms = 0.0, t_host_ms = 0.0;
-    int n_steps = 0;
+    int64_t n_steps = 0;
     auto begin = [&](int gi) -> int {
         Group &G = grp[gi];
-        if (G.live.empty() || G.it >= cfg->max_iterations) return DCREG_OK;
+        G.live.clear();
+        for (int si = gi; si < n_slots; si += n_groups) if (slot[(size_t)si].trial >= 0) G.live.push_back(si);
+        if (G.live.empty()) return DCREG_OK;
         const int nl = (int)G.live.size();
         G.Rb.resize((size_t)nl * 9); G.tb.resize((size_t)nl * 3); G.outs.resize((size_t)nl); G.ids.resize((size_t)nl);
         for (int j = 0; j < nl; ++j) {
-            G.ids[(size_t)j] = (int32_t)G.live[(size_t)j];
-            std::memcpy(&G.Rb[(size_t)j * 9], &R[(size_t)G.live[(size_t)j] * 9], sizeof(double) * 9);
-            std::memcpy(&G.tb[(size_t)j * 3], &t[(size_t)G.live[(size_t)j] * 3], sizeof(double) * 3);
+            const Slot &S = slot[(size_t)G.live[(size_t)j]];
+            G.ids[(size_t)j] = have_states ? (int32_t)G.live[(size_t)j] : -1;
+            std::memcpy(&G.Rb[(size_t)j * 9], S.R, sizeof(S.R)); std::memcpy(&G.tb[(size_t)j * 3], S.t, sizeof(S.t));
         }
         const int rc = dcreg_linearize_batch_begin_warm(ctx, gi, nl, G.Rb.data(), G.tb.data(), G.ids.data(), &prm);
         G.in_flight = rc == DCREG_OK;
         return rc;
     };
-    auto finish = [&](int gi) -> int {          // wait for the group's results, take the host steps, compact the live set
+    auto finish = [&](int gi) -> int {          // wait for the group's results, take the host steps, refill the slots that ended
         Group &G = grp[gi];
         if (!G.in_flight) return DCREG_OK;
         const auto t_a = Clock::now();
@@ -274,18 +291,20 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
         if (rc != DCREG_OK) return rc;
         t_lin_ms += ms_since(t_a);
         const auto t_b = Clock::now();
-        const int nl = (int)G.live.size(), it = G.it;
+        const int nl = (int)G.live.size();
         // host steps 6-9 of every live trial are independent: spread them over host threads
-        std::vector<int> keep((size_t)nl, 0);
+        std::vector<uint8_t> ended((size_t)nl, 0);
         const int nthreads = std::max(1, std::min({omp_get_max_threads(), 32, nl / 8}));
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int j = 0; j < nl; ++j) {
-            const int id = G.live[(size_t)j];
-            dcreg_trial_result &tr = results[id];
+            Slot &S = slot[(size_t)G.live[(size_t)j]];
+            dcreg_trial_result &tr = results[S.trial];
             const dcreg_lin_out &lo = G.outs[(size_t)j];
-            if (lo.n_eff < 10) { tr.iterations = it + 1; tr.status = 1; continue; }
+            const int it = S.it;
+            ended[(size_t)j] = 1;
+            if (lo.n_eff < 10) { tr.iterations = it + 1; tr.status = 1; continue; }          // :1847-1854
             StepOut so;
-            const int st = host_step(lo, detection, handling, *cfg, &R[(size_t)id * 9], &t[(size_t)id * 3], so);
+            const int st = host_step(lo, detection, handling, *cfg, S.R, S.t, so);
             if (st == 2) { tr.iterations = it; tr.status = 2; continue; }
             tr.iterations = it + 1;
             tr.final_rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);
@@ -294,24 +313,35 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
             std::memcpy(tr.H_upper, lo.H_upper, sizeof(tr.H_upper));
             std::memcpy(tr.degenerate_mask, so.an.degenerate_mask, sizeof(tr.degenerate_mask));
             if (st == 1) { tr.converged = 1; continue; }
-            keep[(size_t)j] = 1;
+            S.it = it + 1;
+            if (S.it < cfg->max_iterations) ended[(size_t)j] = 0;
         }
-        std::vector<int> next;
-        next.reserve((size_t)nl);
-        for (int j = 0; j < nl; ++j) if (keep[(size_t)j]) next.push_back(G.live[(size_t)j]);
-        G.live.swap(next);
-        ++G.it;
+        for (int j = 0; j < nl; ++j) {
+            if (!ended[(size_t)j]) continue;
+            const int si = G.live[(size_t)j];
+            Slot &S = slot[(size_t)si];
+            dcreg_trial_result &tr = results[S.trial];
+            dcreg::stateToMatrix(S.R, S.t, tr.final_transform);
+            dcreg::poseError(cfg->gt_matrix, tr.final_transform, &tr.trans_error_m, &tr.rot_error_deg);   // :501-503
+            ++done;
+            load(si);
+        }
         t_host_ms += ms_since(t_b);
         ++n_steps;
         return DCREG_OK;
     };
-    auto has_work = [&](int gi) { return grp[gi].in_flight || (!grp[gi].live.empty() && grp[gi].it < cfg->max_iterations); };
+    auto has_work = [&](int gi) {
+        if (grp[gi].in_flight) return true;
+        for (int si = gi; si < n_slots; si += n_groups) if (slot[(size_t)si].trial >= 0) return true;
+        return false;
+    };
+    (void)group_of;
     int rc = begin(0);
-    while (rc == DCREG_OK && (has_work(0) || has_work(1))) {
-        if (!grp[1].in_flight && (rc = begin(1)) != DCREG_OK) break;   // queued behind group 0 (no-op for a single group)
-        if ((rc = finish(0)) != DCREG_OK) break;                       // host steps of group 0 overlap group 1's kernels
-        if (!grp[0].in_flight && (rc = begin(0)) != DCREG_OK) break;   // queued behind group 1
-        if ((rc = finish(1)) != DCREG_OK) break;                       // host steps of group 1 overlap group 0's kernels
+    while (rc == DCREG_OK && (has_work(0) || (n_groups == 2 && has_work(1)))) {
+        if (n_groups == 2 && !grp[1].in_flight && (rc = begin(1)) != DCREG_OK) break;   // queued behind group 0
+        if ((rc = finish(0)) != DCREG_OK) break;                                         // host steps of group 0 overlap group 1's kernel
+        if (!grp[0].in_flight && (rc = begin(0)) != DCREG_OK) break;                     // queued behind group 1
+        if (n_groups == 2 && (rc = finish(1)) != DCREG_OK) break;                        // host steps of group 1 overlap group 0's kernel
     }
     if (rc != DCREG_OK) {                                            // drain whatever is still queued
         for (int gi = 0; gi < 2; ++gi) if (grp[gi].in_flight) { grp[gi].outs.resize(grp[gi].live.size()); (void)dcreg_linearize_batch_end(ctx, gi, grp[gi].outs.data()); }
@@ -319,16 +349,33 @@ int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const d
     }
     const double total_ms = ms_since(t_total);
     if (std::getenv("DCREG_TRIALS_TIMING"))
-        std::fprintf(stderr, "[dcreg_icp_run_trials] %d group steps: wait for results %.1f us/step, host %.1f us/step, wall %.1f us per lock-step iteration\n",
-                     n_steps, 1e3 * t_lin_ms / std::max(n_steps, 1), 1e3 * t_host_ms / std::max(n_steps, 1),
-                     1e3 * total_ms / std::max(std::max(grp[0].it, grp[1].it), 1));
-    for (int i = 0; i < n_trials; ++i) {
-        dcreg_trial_result &tr = results[i];
-        dcreg::stateToMatrix(&R[(size_t)i * 9], &t[(size_t)i * 3], tr.final_transform);
-        dcreg::poseError(cfg->gt_matrix, tr.final_transform, &tr.trans_error_m, &tr.rot_error_deg);   // :501-503
-        tr.time_ms = total_ms / (double)n_trials;   // amortised: trials advance together
-    }
+        std::fprintf(stderr, "[dcreg_icp_run_trials] %lld trials in %d slots, %lld group steps: wait for results %.1f us/step, host %.1f us/step, wall %.1f us/step\n",
+                     (long long)n_trials, n_slots, (long long)n_steps, 1e3 * t_lin_ms / std::max<int64_t>(n_steps, 1),
+                     1e3 * t_host_ms / std::max<int64_t>(n_steps, 1), 1e3 * total_ms / std::max<int64_t>(n_steps, 1));
+    for (int64_t i = 0; i < n_trials; ++i) results[i].time_ms = total_ms / (double)n_trials;   // amortised: trials advance together
     return DCREG_OK;
+}
+
+int dcreg_icp_run_trials(dcreg_ctx *ctx, int n_trials, const double *R0, const double *t0, int detection, int handling,
+                         const dcreg_config *cfg, dcreg_trial_result *results) {
+    if (!ctx || !R0 || !t0 || !cfg || !results || n_trials < 0) return DCREG_E_INVALID;
+    if (n_trials == 0) return DCREG_OK;
+    return run_trials_core(ctx, n_trials, R0, t0, detection, handling, cfg, results, 0);
+}
+
+int dcreg_icp_run_montecarlo(dcreg_ctx *ctx, const double base_xyzrpy[6], uint64_t seed, int64_t first_trial, int64_t trial_stride,
+                             int64_t n_trials, double trans_amp, double rot_amp_rad, int detection, int handling,
+                             const dcreg_config *cfg, int slots, dcreg_trial_result *results) {
+    if (!ctx || !base_xyzrpy || !cfg || !results || n_trials < 0 || first_trial < 0 || trial_stride < 1) return DCREG_E_INVALID;
+    if (n_trials == 0) return DCREG_OK;
+    std::vector<double> R0((size_t)n_trials * 9), t0((size_t)n_trials * 3);
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n_trials; ++j) {
+        double T[16];
+        dcreg_trial_pose(base_xyzrpy, seed, first_trial + j * trial_stride, trans_amp, rot_amp_rad, T, nullptr);
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R0[(size_t)j * 9 + r * 3 + c] = T[r * 4 + c]; t0[(size_t)j * 3 + r] = T[r * 4 + 3]; }
+    }
+    return run_trials_core(ctx, n_trials, R0.data(), t0.data(), detection, handling, cfg, results, slots);
 }
 
 // Second engine: TestRunner::Point2PlaneICP (icp_test_runner.cpp:2064-2830), Pose6D state, LOAM Jacobian.
@@ -467,6 +514,13 @@ int dcreg_trial_pose(const double base_xyzrpy[6], uint64_t seed, int64_t k, doub
     if (pose_xyzrpy) std::memcpy(pose_xyzrpy, p, sizeof(p));
     return DCREG_OK;
 }
+
+int dcreg_set_host_threads(int n) {
+    if (n < 1) return DCREG_E_INVALID;
+    omp_set_num_threads(n);
+    return DCREG_OK;
+}
+int dcreg_get_host_threads(void) { return omp_get_max_threads(); }
 
 size_t dcreg_sizeof(const char *name) {
     if (!name) return 0;

@@ -116,6 +116,34 @@ def run_montecarlo(run_trials, base_pose, n_trials, seed, trans_amp, rot_amp_rad
     return allr, method_statistics(allr)
 
 
+def records_from_results(ks, results):
+    """[len(ks), REC] records from a sequence / ctypes array of dcreg_trial_result, without a Python loop over the fields."""
+    from . import api
+    n = len(ks)
+    if n == 0:
+        return np.zeros((0, REC))
+    arr = results if isinstance(results, np.ndarray) else np.frombuffer((api.TrialResult * n)(*results), dtype=np.dtype(api.TrialResult))
+    r = np.zeros((n, REC))
+    r[:, R_CONV], r[:, R_ITERS], r[:, R_TIME] = arr["converged"], arr["iterations"], arr["time_ms"]
+    r[:, R_TERR], r[:, R_RERR], r[:, R_RMSE], r[:, R_FIT] = arr["trans_error_m"], arr["rot_error_deg"], arr["final_rmse"], arr["final_fitness"]
+    r[:, R_CORR], r[:, R_STATUS], r[:, R_TRIAL] = arr["corr_num"], arr["status"], np.asarray(ks, np.float64)
+    r[:, R_T:R_T + 16] = arr["final_transform"].reshape(n, 16)
+    r[:, R_H:R_H + 21] = arr["H_upper"].reshape(n, 21)
+    r[:, R_MASK:R_MASK + 6] = arr["degenerate_mask"].reshape(n, 6)
+    return r
+
+
+def run_montecarlo_native(ctx, method, cfg, base_pose, n_trials, seed, trans_amp, rot_amp_rad, rank=0, world=1, dist=None, device="cpu",
+                          slots=0):
+    """The same experiment with this rank's whole share run by ONE call into the C++ engine (dcreg_icp_run_montecarlo: poses generated
+    there, trials batched continuously).  Returns (records [n_trials, REC] on every rank, stats)."""
+    mine = shard_indices(n_trials, rank, world)
+    res = ctx.icp_run_montecarlo(base_pose, seed, rank, world, len(mine), trans_amp, rot_amp_rad, method, cfg, slots=slots)
+    local = records_from_results(mine, res)
+    allr = gather_records(local, n_trials, dist, device)
+    return allr, method_statistics(allr)
+
+
 def main(argv=None):
     """The Monte-Carlo experiment end to end (BASELINE config 5): `python -m dcreg_amd.montecarlo --trials 5000` on one GPU, or
     `python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m dcreg_amd.montecarlo --trials 5000`
@@ -133,13 +161,18 @@ def main(argv=None):
     ap.add_argument("--base", default="0.2,0.8,0.5,0.1,0.1,2.0", help="base initial pose x,y,z [m], roll,pitch,yaw [deg] (paper run)")
     ap.add_argument("--radius", type=float, default=1.0)
     ap.add_argument("--max-iterations", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=256, help="trials in flight per GPU")
+    ap.add_argument("--host-threads", type=int, default=0, help="OpenMP threads of this rank's host steps (0 = its share of the usable CPUs)")
     ap.add_argument("--out", default=None, help="write {method: statistics} as JSON (rank 0)")
     a = ap.parse_args(argv)
 
     import torch
-    from . import api, Context
+    from . import api, Context, hostinfo
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    hostinfo.pin_rank(local, local_world)
+    # torch.distributed.run exports OMP_NUM_THREADS=1; the engine's host steps want this rank's share of the CPUs
+    api.set_host_threads(a.host_threads if a.host_threads > 0 else hostinfo.threads_per_rank(local_world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -156,9 +189,8 @@ def main(argv=None):
     out = {}
     for method in a.methods.split(","):
         t0 = time.perf_counter()
-        recs, stats = run_montecarlo(lambda T0s: ctx.icp_run_trials(T0s, method, cfg), base, a.trials, a.seed, a.trans_amp,
-                                     np.deg2rad(a.rot_amp_deg), rank=rank, world=world, dist=dist, device="cuda" if world > 1 else "cpu",
-                                     batch=a.batch)
+        recs, stats = run_montecarlo_native(ctx, method, cfg, base, a.trials, a.seed, a.trans_amp, np.deg2rad(a.rot_amp_deg), rank=rank,
+                                            world=world, dist=dist, device="cuda" if world > 1 else "cpu", slots=a.batch)
         el = time.perf_counter() - t0
         stats["wall_s"] = el
         stats["icp_iterations_per_s"] = float(recs[:, R_ITERS].sum()) / el

@@ -290,8 +290,10 @@ typedef struct dcreg_trial_result {
     int degenerate_mask[6];
 } dcreg_trial_result;
 
-/* n_trials independent ICP runs of the same cloud pair from different initial poses, advanced in
- * lock-step so every iteration of all live trials is ONE batched launch. */
+/* n_trials independent ICP runs of the same cloud pair from different initial poses (the num_runs loop of runMethod) as a
+ * continuously refilled batch: up to 256 trials are in flight, every iteration of a group of them is ONE batched launch, and
+ * a trial that ends hands its slot to the next one in line at once.  Each trial is bitwise the single run (dcreg_icp_run) of
+ * its pose. */
 int dcreg_icp_run_trials(dcreg_ctx *, int n_trials, const double *R0_9, const double *t0_3, int detection,
                          int handling, const dcreg_config *, dcreg_trial_result *results);
 
@@ -302,6 +304,18 @@ int dcreg_icp_run_trials(dcreg_ctx *, int n_trials, const double *R0_9, const do
  * = Pose6D2Matrix (utils.hpp:452-460); pose_xyzrpy (may be NULL) receives the perturbed six numbers. */
 int dcreg_trial_pose(const double base_xyzrpy[6], uint64_t seed, int64_t k, double trans_amp, double rot_amp_rad, double T[16],
                      double pose_xyzrpy[6]);
+
+/* The Monte-Carlo experiment of one rank: trials k = first_trial + j * trial_stride, j = 0 .. n_trials - 1 (rank r of w: first_trial
+ * = r, stride = w), initial poses from dcreg_trial_pose, run as dcreg_icp_run_trials does with `slots` trials in flight (0 = 256).
+ * results[j] belongs to trial first_trial + j * trial_stride. */
+int dcreg_icp_run_montecarlo(dcreg_ctx *, const double base_xyzrpy[6], uint64_t seed, int64_t first_trial, int64_t trial_stride,
+                             int64_t n_trials, double trans_amp, double rot_amp_rad, int detection, int handling,
+                             const dcreg_config *, int slots, dcreg_trial_result *results);
+
+/* host threads the batched engines may use for the per-trial 6x6 steps (OpenMP; the reference hard-codes 8, :1714).  Launchers
+ * that pin OMP_NUM_THREADS=1 (torch.distributed.run) should set this to the CPUs the rank really owns. */
+int dcreg_set_host_threads(int n);
+int dcreg_get_host_threads(void);
 
 /* calculatePointToPointError (utils.hpp:538-589): aligned = T * source (float), both directions on the GPU */
 int dcreg_p2p_error(dcreg_ctx *, const double T[16], double error_threshold, double *rmse, double *fitness,

@@ -3,8 +3,8 @@ wave-synchronous cost model, without a GPU.  Used to design the ring walk; usage
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as h
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h
 import emul
 from oracle import pyoracle as po
 

@@ -4,8 +4,8 @@ correspondence set flips on a 1e-16 perturbation can legitimately diverge late; 
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as h
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h
 import dcreg_amd
 from dcreg_amd import api
 from oracle import pyoracle as po

@@ -4,8 +4,8 @@ H / g to 1e-8.  usage: fuzz_parity.py [n_cases] [seed]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as h
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h
 import dcreg_amd
 from dcreg_amd import api
 from oracle import pyoracle as po

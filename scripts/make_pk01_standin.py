@@ -5,14 +5,14 @@
     gpurun_out/pk01_standin/parkinglot_raw_2415_frame.pcd   one 8 k-point frame in the sensor frame (sigma = 2 cm)
 
 The reference's real pair is not in its repository (README.md:69, Google Drive).  With the real files in that folder the
-same YAML runs unchanged.  Generator: tests/helpers.py scene_parkinglot (numpy default_rng, fixed seed).
+same YAML runs unchanged.  Generator: dcreg_amd/scenes.py scene_parkinglot (numpy default_rng, fixed seed).
 Usage: python scripts/make_pk01_standin.py [out_dir] [n_frame]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as h  # noqa: E402
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h  # noqa: E402
 
 
 def main(out_dir=None, n_frame=8000):

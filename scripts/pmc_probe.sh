@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: one rocprofv3 --pmc pass of the one-pair bench loop with the counters given on the command line; prints the mean per
-# dispatch of k_linearize.  usage: pmc_probe.sh <workload> COUNTER [COUNTER ...]
+# dispatch of k_lin.  usage: pmc_probe.sh <workload> COUNTER [COUNTER ...]
 WL=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pmc_probe; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -11,7 +11,7 @@ f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(list)
 for fn in f:
     for r in csv.DictReader(open(fn)):
-        if "k_linearize" in r["Kernel_Name"]:
+        if "k_lin" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print("%-28s mean %.4g  (n=%d)" % (k, sum(v) / len(v), len(v)))

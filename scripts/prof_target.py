@@ -2,8 +2,8 @@
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as h
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h
 import dcreg_amd
 from dcreg_amd import api
 

@@ -13,12 +13,12 @@ import csv, glob, sys, collections
 O = sys.argv[1]
 for fn in glob.glob(O + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "k_linearize" in r["Name"]:
+        if "k_lin" in r["Name"]:
             print("trace:", r["Name"][:40], "calls", r["Calls"], "avg ns", r["AverageNs"], "min", r["MinNs"], "max", r["MaxNs"])
 acc = collections.defaultdict(list)
 for fn in glob.glob(O + "/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "k_linearize" in r["Kernel_Name"]:
+        if "k_lin" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print("pmc: %-20s mean per launch %.4g (n=%d)" % (k, sum(v) / len(v), len(v)))

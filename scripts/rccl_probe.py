@@ -1,12 +1,12 @@
 """GPU box probe: dcreg_comm_init with a communicator of one rank, with and without torch in the process."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 if "torch" in sys.argv:
     import torch
     print("torch", torch.__version__, torch.cuda.is_available())
 import numpy as np
-import helpers as h
+from dcreg_amd import scenes as h
 from dcreg_amd import api
 c = api.Context(0)
 pts = h.cylinder_cloud()

@@ -3,9 +3,9 @@ its starting level and nothing may hang."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
-import helpers as h
+from dcreg_amd import scenes as h
 import dcreg_amd
 from dcreg_amd import api
 

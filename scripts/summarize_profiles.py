@@ -11,7 +11,7 @@ def one(pattern):
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()[:60]
 
-ALL_LIN = "dcreg::k_linearize (all instantiations)"
+ALL_LIN = "dcreg::k_lin (all instantiations)"
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
@@ -32,7 +32,7 @@ if kt:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(kt)):
         agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        if "k_linearize" in r["Kernel_Name"]:        # the launches of a run use several instantiations (warm-bound form): one row for all
+        if "k_lin" in r["Kernel_Name"]:        # the launches of a run use several instantiations (warm-bound form): one row for all
             agg[ALL_LIN].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     md += ["## Kernel trace (ns)", "", "| kernel | calls | avg | min | max | total |", "|---|---|---|---|---|---|"]
     ks = {}
@@ -55,13 +55,13 @@ def counters(sub):
     if f:
         for r in csv.DictReader(open(f)):
             res[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            if "k_linearize" in r["Kernel_Name"]:
+            if "k_lin" in r["Kernel_Name"]:
                 res[ALL_LIN][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return res
 pm = {}
 for sub in ("fetch", "write", "sq1", "sq2", "tcc"):
     for k, v in counters(sub).items():
-        if "k_linearize" in k or "k_finalize" in k:
+        if "k_lin" in k or "k_finalize" in k:
             for cn, vals in v.items():
                 pm.setdefault(k, {})[cn] = sum(vals) / len(vals)
 out["pmc_per_dispatch"] = pm
@@ -71,7 +71,7 @@ if pm:
         md.append("**%s**" % k)
         md.append("")
         md += ["| counter | value |", "|---|---|"] + ["| %s | %.4g |" % (a, b) for a, b in sorted(v.items())] + [""]
-    lin = pm.get(ALL_LIN) or next((v for k, v in pm.items() if "k_linearize" in k), None)     # mean over ALL launches of the run
+    lin = pm.get(ALL_LIN) or next((v for k, v in pm.items() if "k_lin" in k), None)     # mean over ALL launches of the run
     if lin and "FETCH_SIZE" in lin:
         fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
         raw = (fetch_kb + write_kb) * 1024.0
@@ -80,19 +80,27 @@ if pm:
                           "note": "FETCH_SIZE/WRITE_SIZE are KB at the L2<->fabric boundary (Infinity-Cache hits included). gfx950 "
                                   "under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM); this kernel's reads are 16-byte "
                                   "gathers + 4-byte table reads, for which the factor is uncalibrated: both figures are given."}
-        md += ["## HBM-side traffic of k_linearize per launch", "",
+        md += ["## HBM-side traffic of k_lin per launch", "",
                "FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB -> %.2f MB raw, %.2f MB with the guide's x2 read correction." % (fetch_kb, write_kb, raw / 1e6, corr / 1e6), ""]
     if lin and "SQ_WAVES" in lin:
         w = lin["SQ_WAVES"]
-        md += ["## Per-wave instruction mix of k_linearize", "",
+        md += ["## Per-wave instruction mix of k_lin", "",
                "waves %.0f; per wave: VALU %.0f, SALU %.0f, LDS %.0f, VMEM_RD %.0f; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (
                    w, lin.get("SQ_INSTS_VALU", 0) / w, lin.get("SQ_INSTS_SALU", 0) / w, lin.get("SQ_INSTS_LDS", 0) / w,
                    lin.get("SQ_INSTS_VMEM_RD", 0) / w, lin.get("SQ_WAIT_ANY", 0) / max(lin.get("SQ_WAVE_CYCLES", 1), 1)), ""]
         out["per_wave"] = {"valu": lin.get("SQ_INSTS_VALU", 0) / w, "salu": lin.get("SQ_INSTS_SALU", 0) / w}
         # wave-level VALU instructions of one launch -> the VALU-issue floor bench.py prices the kernel against
         out["pmc"] = {"SQ_INSTS_VALU_per_launch": lin.get("SQ_INSTS_VALU", 0), "SQ_WAVES_per_launch": w}
-        floor_us = lin.get("SQ_INSTS_VALU", 0) * 4.0 / 1024 / 2.4e9 * 1e6
-        md += ["VALU-issue floor of one launch: %.3g wave instructions x 4 cycles / 1024 SIMDs / 2.4 GHz = %.1f us" % (lin.get("SQ_INSTS_VALU", 0), floor_us), ""]
+        mixf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_mix.json")))
+        cyc = json.load(open(mixf[-1]))["mean_cycles_per_valu_w8"] if mixf else 2.0
+        floor_us = lin.get("SQ_INSTS_VALU", 0) * cyc / 1024 / 2.4e9 * 1e6
+        md += ["VALU-issue floor of one launch: %.3g wave instructions x %.2f cycles (saturated issue cost of the kernel's instruction mix, "
+               "scripts/microbench + scripts/asm_mix.py) / 1024 SIMDs / 2.4 GHz = %.1f us" % (lin.get("SQ_INSTS_VALU", 0), cyc, floor_us), ""]
+        if "SQ_ACTIVE_INST_VALU" in lin and lin.get("SQ_INSTS_VALU", 0) > 0:
+            md += ["Measured: SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU = %.2f cycles per VALU instruction in this run; VALU busy = SQ_ACTIVE_INST_VALU / "
+                   "SQ_WAVE_CYCLES x waves per SIMD ... SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.3f" % (
+                       4.0 * lin["SQ_ACTIVE_INST_VALU"] / lin["SQ_INSTS_VALU"], lin["SQ_ACTIVE_INST_VALU"] / max(lin.get("SQ_BUSY_CYCLES", 1), 1)), ""]
+            out["pmc"]["cycles_per_valu_measured"] = 4.0 * lin["SQ_ACTIVE_INST_VALU"] / lin["SQ_INSTS_VALU"]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", "%s_%s.md" % (tag, wl)), "w").write("\n".join(md) + "\n")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, wl)), "w"), indent=1)

@@ -2,8 +2,8 @@
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers as h
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h
 
 def spread21(v):
     v = v.astype(np.uint64) & np.uint64(0x1FFFFF)

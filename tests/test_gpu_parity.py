@@ -370,6 +370,36 @@ def test_montecarlo_driver_on_gpu(ctx, cyl):
             assert recs[k, mc.R_CORR] == ologs[-1].n_eff
 
 
+def test_native_montecarlo_refills_slots_and_equals_single_runs(ctx, cyl):
+    """dcreg_icp_run_montecarlo (poses generated in C++, `slots` trials in flight, a finished trial's slot - and its neighbour state,
+    marked empty - taken over by the next trial at once): 41 trials through 6, 64 and 256 slots, as two interleaved rank shares, and
+    through the Python-side driver give the same records bit for bit; each trial is bitwise the single run of its pose."""
+    from dcreg_amd import montecarlo as mc
+    pts, _ = cyl
+    ctx.set_target(pts, 1.0)
+    ctx.set_source(pts)
+    cfg = _cfg(True, max_iterations=14)
+    base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+    n, seed, ta, ra = 41, 11, 0.4, h.deg2rad(1.5)
+    ref, rstats = mc.run_montecarlo(lambda T0s: ctx.icp_run_trials(T0s, "Ours", cfg), base, n, seed=seed, trans_amp=ta, rot_amp_rad=ra, batch=256)
+    cols = [c for c in range(mc.REC) if c != mc.R_TIME]
+    for slots in (6, 64, 256):
+        recs, stats = mc.run_montecarlo_native(ctx, "Ours", cfg, base, n, seed, ta, ra, slots=slots)
+        assert np.array_equal(recs[:, cols], ref[:, cols]), slots
+        assert {k: v for k, v in stats.items() if "time" not in k} == {k: v for k, v in rstats.items() if "time" not in k}
+    halves = [mc.records_from_results(mc.shard_indices(n, r, 2), ctx.icp_run_montecarlo(base, seed, r, 2, len(mc.shard_indices(n, r, 2)), ta, ra, "Ours", cfg, slots=8))
+              for r in (0, 1)]
+    both = np.concatenate(halves)
+    both = both[np.argsort(both[:, mc.R_TRIAL])]
+    assert np.array_equal(both[:, cols], ref[:, cols])
+    assert 0 < rstats["converged_runs"] and len(set(ref[:, mc.R_ITERS])) > 2          # trials of different lengths: slots did change hands
+    for k in (0, 5, 17, 40):
+        res, logs = ctx.icp_run(mc.trial_pose(base, k, seed, ta, ra), "Ours", cfg)
+        T = ref[k, mc.R_T:mc.R_T + 16].reshape(4, 4)
+        assert ref[k, mc.R_ITERS] == res.iterations and ref[k, mc.R_CONV] == res.converged
+        assert np.array_equal(T[:3, :3].reshape(9), np.array(res.R[:])) and np.array_equal(T[:3, 3], np.array(res.t[:]))
+
+
 def test_sharded_engine_plumbing(ctx, cyl):
     """dcreg_icp_run_sharded: with an identity reducer it IS dcreg_icp_run; with a reducer that adds a second, identical
     rank (row doubled, twice the source points) the unregularised update (2H)^-1 (2g) and the fitness are unchanged."""
