@@ -290,6 +290,9 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
         float ro = (float)(p->search_radius * (1.0 + 1e-5));
         if ((double)ro < p->search_radius * (1.0 + 1e-5)) ro = std::nextafterf(ro, INFINITY);
         a.cert_r_out = ro;
+        float ri = (float)(p->search_radius * (1.0 - 1e-5));
+        if ((double)ri > p->search_radius * (1.0 - 1e-5)) ri = std::nextafterf(ri, 0.0f);
+        a.cert_r_in = ri;
     }
     a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm;
     a.w_slope = p->weight_slope; a.w_min = p->weight_min; a.use_wd = p->use_weight_derivative;

@@ -122,12 +122,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t c
 
 // ---------------------------------------------------------------- the linearisation kernel
 // One linearisation (steps 1-5 of an iteration, icp_test_runner.cpp:1714-1915) of a pose is ONE launch of k_lin, one thread per source
-// point: transform; if the point's state holds a certificate (search.hpp kStateRows) that is still good at the new position, no
-// search - otherwise the exact 6-NN search (bounded by the old neighbours when there are some), a new certificate, the state update;
-// then, for every point alike, gather the known neighbours, order them at the new position, plane fit, gates, row; reduction.
-// A wave searches only if one of its 64 points needs it: on a settled trajectory almost none does.  The rows are built by the same
-// code from the same exact neighbour sets in the same lane order whether or not a point was searched, and the block / chunk / pose
-// sums take them in index order: the sums do not depend on the history of the state.
+// point: transform, then as little as the point's state (search.hpp kStateRows) allows -
+//   level 1  no certificate, or the point has left its certificate's radius: exact 6-NN search (bounded by the old neighbours when
+//            there are some), new certificate;
+//   level 2  the set certificate holds but the neighbour ORDER may have changed: gather the known neighbours, order them at the new
+//            position, radius gate, plane fit, neighbour-only gates, new fit certificate;
+//   level 3  the fit certificate holds too: the stored plane;
+// and for every point alike residual, weight, weight gate, row from the plane; reduction.  A wave runs a level only if one of its 64
+// points needs it: on a settled trajectory almost none needs more than level 3, i.e. 72 B of state and point per source point and
+// no gather at all.  Every level reproduces bitwise what a fresh search + fit at this pose gives, the rows are built by the same code
+// in the same lane order, and the block / chunk / pose sums take them in index order: the sums do not depend on the state's history.
 // (Measured alternative, round 3: certificates tested by a lean search-free kernel that puts the points to search on compacted work
 // lists for two follow-up kernels - 38 us instead of 43.5 us for the settled 1 M launch, but the follow-up kernels cost 10 us of
 // stream time even when the lists are empty and a whole-run bench of 9.8 k instead of 11.4 k it/s: profiles/r03_ablation.md.)
@@ -319,57 +323,116 @@ static __global__ __launch_bounds__(kBlock, 4) void k_lin(const float4 *__restri
     uint8_t flag = 0;
     const bool have_q = i < n_src;
     const bool keep = a.state != nullptr && P.state != kNoIdx;              // the pose owns a state
-    const bool old = keep && P.fresh == 0u;                                 // ... that holds the results of earlier searches
+    const bool old = keep && P.fresh == 0u;                                 // ... that holds the results of earlier launches
     const bool CERT = old && a.use_cert != 0;                               // ... whose certificates are to be used (uniform)
-    uint32_t *st = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride : nullptr;
+    uint32_t *st = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride + i : nullptr;
+    const size_t ss = a.state_stride;
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t pos6[6], cert = kCertSearch, q0[3] = {0u, 0u, 0u};
-    const bool rd = old && have_q && (CERT || a.warm != 0);
+    // what the fast path needs, in one batch of loads: certificate, reference position, fit word, plane (56 B + the 16 B of the point)
+    uint32_t cert = kCertSearch, fitw = kFitNone, q0[3] = {0u, 0u, 0u}, pw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (CERT && have_q) {
+        cert = st[6 * ss]; fitw = st[10 * ss];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) pos6[j] = rd ? st[(size_t)j * a.state_stride + i] : kNoIdx;
-    if (CERT && old && have_q) {
-        cert = st[(size_t)6 * a.state_stride + i];
+        for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * ss];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * a.state_stride + i];
+        for (int k = 0; k < 8; ++k) pw[k] = st[(size_t)(11 + k) * ss];
     }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
-    bool need = have_q;
-    if (CERT) need = have_q && !cert_holds(cert, __uint_as_float(q0[0]), __uint_as_float(q0[1]), __uint_as_float(q0[2]), qx, qy, qz);
+    const float q0x = __uint_as_float(q0[0]), q0y = __uint_as_float(q0[1]), q0z = __uint_as_float(q0[2]);
+    // three levels: (1) the set certificate fails -> search; (2) it holds but the fit certificate does not -> gather the known
+    // neighbours, order, fit; (3) both hold -> the stored plane.  OUT certificates: nothing to do at all.
+    const bool need = have_q && !(CERT && cert_holds(cert, q0x, q0y, q0z, qx, qy, qz));
+    bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
-    const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
-    if (need_mask != 0ull) {
-        if (a.search_count && (threadIdx.x & 63) == 0)       // 64 counters on lines of their own (kCounterStride): see there
-            atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)__builtin_popcountll(need_mask));
-        Set6 s6;
-        uint32_t c2;
-        lin_search6(g, runs[wave], a, need, old && a.warm != 0, pos6, qx, qy, qz, s6, c2);
-        if (need) {
-            cert = c2;
+    KnnResult<5> nn;
+    Fit fit;
+    uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
+    const bool level3 = have_q && !need && !refit && !cert_is_out(cert);
+    auto stored_plane = [&](const uint32_t (&w)[8]) {
+        gate = (uint8_t)(fitw & 3u);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) pos6[j] = s6.pos[j];
-            pos6[5] = kNoIdx;                      // (the search has just put the set in order: five are enough for this launch's row)
-            if (keep) {
+        for (int k = 0; k < 4; ++k) fit.plane[k] = __longlong_as_double((long long)(((unsigned long long)w[2 * k + 1] << 32) | w[2 * k]));
+    };
+    if (!wave_any(need || refit)) {
+        // the whole wave is at level 3 (or OUT): the plane words loaded up front are all it needs.  (They are consumed HERE and not
+        // below: kept alive across the search they would cost a dozen registers at its peak, i.e. scratch spills; the waves that do
+        // search load them a second time afterwards - from the cache.)
+        if (level3) stored_plane(pw);
+    } else {
+        uint32_t pos6[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) st[(size_t)j * a.state_stride + i] = s6.pos[j];
-                st[(size_t)6 * a.state_stride + i] = c2;
-                st[(size_t)7 * a.state_stride + i] = __float_as_uint(qx); st[(size_t)8 * a.state_stride + i] = __float_as_uint(qy);
-                st[(size_t)9 * a.state_stride + i] = __float_as_uint(qz);
+        for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
+        const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
+        if (need_mask != 0ull) {
+            if (a.search_count && (threadIdx.x & 63) == 0)       // 64 counters on lines of their own (kCounterStride): see there
+                atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)__builtin_popcountll(need_mask));
+            const bool warm = old && a.warm != 0;
+            if (warm && need) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             }
-            stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+            Set6 s6;
+            uint32_t c2;
+            lin_search6(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
+            if (need) {
+                cert = c2;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
+                if (keep) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = s6.pos[j];
+                }
+                stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+            }
+        }
+        // level 2 for the lanes that were searched and the lanes whose order may have changed
+        const bool set = have_q && !cert_is_out(cert);
+        const bool fitnow = set && (need || refit);
+        if (wave_any(fitnow)) {
+            // a SET6 certificate says nothing about which five of the six are nearest: the fit certificate must then cover the gap
+            // between the 5th and the 6th itself, i.e. the fit works on all six
+            const bool use6 = fitnow && cert_is_set6(cert);
+            const bool six = wave_any(use6);
+            if (fitnow && !need) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) pos6[j] = (j < 5 || use6) ? st[(size_t)j * ss] : kNoIdx;
+            }
+            if (!use6) pos6[5] = kNoIdx;
+            if (fitnow) {
+                const uint8_t in_r = fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit);
+                gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
+                if (keep) {                         // the new reference position, the certificate as seen from there, the fit
+                    if (!need)                      // (the old reference position is read again: three registers less across the search)
+                        cert = cert_rebased(cert, __uint_as_float(st[7 * ss]), __uint_as_float(st[8 * ss]), __uint_as_float(st[9 * ss]), qx, qy, qz);
+                    st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
+                    st[10 * ss] = fit.word;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long b = (unsigned long long)__double_as_longlong(fit.plane[k]);
+                        st[(size_t)(11 + 2 * k) * ss] = (uint32_t)b; st[(size_t)(12 + 2 * k) * ss] = (uint32_t)(b >> 32);
+                    }
+                }
+            }
+        }
+        if (level3) {                               // the lanes of this wave that needed neither: their stored plane, loaded again
+            uint32_t w2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w2[k] = st[(size_t)(11 + k) * ss];
+            fitw = st[10 * ss];
+            stored_plane(w2);
+        }
+        if (!set && need && keep) {                 // searched and found OUT: certificate and reference position, no fit
+            st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
+            st[10 * ss] = kFitNone;
         }
     }
-    // rows: the queries with a SET certificate gather their neighbours - searched a moment ago or known - the same code for both
-    KnnResult<5> nn;
     double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
-    {
-        const bool set = have_q && !cert_is_out(cert);
-        const bool use6 = CERT && !need && cert_is_set6(cert);
-        const bool six = CERT && wave_any(set && use6);
-        if (!use6) pos6[5] = kNoIdx;
-        if (set) flag = row_from_set<FAST>(g, P, a, s4, qx, qy, qz, pos6, six, nn, row, nrm, r_pt, s_pt);
+    if (have_q) {
+        if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
+        else flag = gate == 255 ? (uint8_t)0 : gate;
     }
-    if (MODE == 1 && have_q) {
+    if (MODE == 1 && have_q) {                      // (debug launches search and fit every point: nn is this launch's list)
         const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {        // the neighbour list is defined for queries that pass the radius gate (:1726)

@@ -80,7 +80,8 @@ struct PoseArg {
 //                   bound): within s metres of q0 the query fails the radius gate (:1726) and nothing needs to be loaded at all.
 // Nothing of a state changes between two searches of a query, and the test is on the two stored float positions themselves (their
 // difference is exact), so neither the length of a trajectory nor the rounding of the float store wears a certificate down.
-constexpr int kStateRows = 10;
+//                                 row 10: the FIT word, rows 11-18: the plane of the last fit (four doubles as eight words): FitCert below
+constexpr int kStateRows = 19;
 constexpr uint32_t kCertSearch = 0xFFFFFFFFu;      // (a NaN: no certificate)
 
 struct LinArgs {
@@ -88,6 +89,7 @@ struct LinArgs {
     float radius_sq_f;            // the SEARCH bound: smallest float above (R (1 + cert_margin))^2 - searches cover a little more than
                                   // the gate radius so that "5th neighbour beyond R" can be certified with some slack
     float cert_r_out;             // R (1 + 1e-5), rounded up: OUT certificates measure from here
+    float cert_r_in;              // R (1 - 1e-5), rounded down: what the 5th neighbour must stay below for the radius gate to hold
     double max_thick_sq, min_norm, w_slope, w_min;
     int use_wd;
     int max_ring;                 // rings needed to cover the search bound
@@ -1140,23 +1142,12 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
     cert = make_cert(st, a);
 }
 
-// Steps 3-5 for one query with its neighbour set (icp_test_runner.cpp:1727-1812, 1863-1907): plane fit, gates, weight,
-// Jacobian row.  row = [A0..A5, b, r]: the weighted Jacobian row, the right-hand side entry and the residual; it must be
-// zero on entry and stays zero unless the point is effective (flag 1).  The 31 sums of the linearisation are the products
-// of this row with itself, added over the points (row_products below; on the device the MFMA reduction of kernels.hpp),
-// plus two counts: effective points (flag 1) and points that passed the radius gate (flag != 0, :1731).  Returns the gate
-// flag (dcreg_lin_debug::flag); nrm/r_out/s_out receive the plane normal, residual and weight once they exist (flags 1, 4).
+// Steps 3-4a for one query with its ordered neighbour set (icp_test_runner.cpp:1727-1773): plane fit and the two gates that depend on
+// the neighbours alone.  plane = {a, b, c, d} of a x + b y + c z + d = 0 with |(a,b,c)| = 1.  Returns 0 (ok), 2 (|x| < min_normal_norm,
+// :1752) or 3 (plane thickness, :1773).  The plane is a function of the five points and their ORDER only - not of the query -, which
+// is what lets a later linearisation reuse it (FitCert below).
 template <bool FASTMATH>
-DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4, const PointQuery &q, const KnnResult<5> &nn,
-                            double (&row)[8], double (&nrm)[3], double &r_out, double &s_out) {
-    float sxf = s4.x, syf = s4.y, szf = s4.z;
-#if DCREG_ON_DEVICE
-    asm volatile("" : "+v"(sxf), "+v"(syf), "+v"(szf));   // as below for the query: re-convert instead of keeping doubles alive
-#endif
-    const double px = sxf, py = syf, pz = szf;
-    const bool have5 = q.reach && nn.full;
-    const bool in_radius = have5 && (double)nn.d2[4] < a.radius_sq;      // :1726
-    if (!in_radius) return 0;
+DCREG_DEVFN uint8_t plane_of_set(const LinArgs &a, const KnnResult<5> &nn, double (&plane)[4]) {
     double nqx[5], nqy[5], nqz[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) { nqx[j] = nn.pt[j].x; nqy[j] = nn.pt[j].y; nqz[j] = nn.pt[j].z; }
@@ -1164,6 +1155,7 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
     if (FASTMATH) plane_fit_qr_fast(nqx, nqy, nqz, x); else plane_fit_qr(nqx, nqy, nqz, x);
     const double ps2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     const double ps = FASTMATH ? fast_sqrt(ps2) : sqrt(ps2);
+    plane[0] = plane[1] = plane[2] = plane[3] = 0.0;
     if (ps < a.min_norm) return 2;                                          // :1752
     const double pd = FASTMATH ? fast_rcp(ps) : 1.0 / ps;
     const double pa = x[0] * pd, pb = x[1] * pd, pc = x[2] * pd;
@@ -1174,13 +1166,27 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
         d *= d;
         maxd = d > maxd ? d : maxd;
     }
+    plane[0] = pa; plane[1] = pb; plane[2] = pc; plane[3] = pd;
     if (!(maxd < a.max_thick_sq)) return 3;                                 // :1773
-    // (the float -> double conversions are redone here on purpose: the cell lookup converted the same floats before the
-    // search, and keeping those three doubles alive across it costs six VGPRs at the register peak, i.e. scratch spills)
-    float qxf = q.qx, qyf = q.qy, qzf = q.qz;
+    return 0;
+}
+
+// Steps 4b-5 for one query and its plane (icp_test_runner.cpp:1774-1812, 1863-1907): residual, weight, weight gate, float stores,
+// Jacobian row.  row = [A0..A5, b, r]: the weighted Jacobian row, the right-hand side entry and the residual; it must be zero on
+// entry and stays zero unless the point is effective (flag 1).  The 31 sums of the linearisation are the products of this row with
+// itself, added over the points (row_products below; on the device the MFMA reduction of kernels.hpp), plus two counts: effective
+// points (flag 1) and points that passed the radius gate (flag != 0, :1731).  Returns flag 1 or 4; nrm / r_out / s_out receive the
+// plane normal, residual and weight.
+template <bool FASTMATH>
+DCREG_DEVFN uint8_t row_of_plane(const PoseArg &P, const LinArgs &a, const float4 &s4, float qxf, float qyf, float qzf, const double (&plane)[4],
+                                 double (&row)[8], double (&nrm)[3], double &r_out, double &s_out) {
+    float sxf = s4.x, syf = s4.y, szf = s4.z;
 #if DCREG_ON_DEVICE
+    asm volatile("" : "+v"(sxf), "+v"(syf), "+v"(szf));   // re-convert instead of keeping doubles alive across the search
     asm volatile("" : "+v"(qxf), "+v"(qyf), "+v"(qzf));
 #endif
+    const double px = sxf, py = syf, pz = szf;
+    const double pa = plane[0], pb = plane[1], pc = plane[2], pd = plane[3];
     const double r = pa * (double)qxf + pb * (double)qyf + pc * (double)qzf + pd;   // :1774
     double s = 1.0 - a.w_slope * fabs(r);                                   // :1776
     s = s < 0.0 ? 0.0 : s;
@@ -1221,14 +1227,25 @@ DCREG_DEVFN uint8_t lin_row(const PoseArg &P, const LinArgs &a, const float4 &s4
     return 1;
 }
 
-// Steps 2b-5 for a query whose nearest-five SET is known - exactly (five positions; six = false or this lane's pos[5] = kNoIdx) or as
+// What a query keeps of its last plane fit (state rows 10-18): the plane, and a FIT word = a float s >= 0 (bit pattern) whose two
+// lowest mantissa bits hold the outcome of the neighbour-only gates (0 ok, 2, 3): while the query stays within s metres of q0,
+//   * the ORDER of its neighbour set cannot change (s <= half the smallest gap between consecutive neighbour distances), so the plane
+//     fit - a function of the ordered points alone - would come out bitwise the same, gates included, and
+//   * the 5th neighbour stays inside the search radius (s <= R - a4), so the radius gate (:1726) still passes:
+// such a linearisation needs neither the neighbours nor the fit - it evaluates residual, weight and row on the stored plane.
+// kFitNone (a NaN): nothing stored.
+constexpr uint32_t kFitNone = 0xFFFFFFFFu;
+struct Fit { double plane[4]; uint32_t word; };
+
+// Steps 2b-4a for a query whose nearest-five SET is known - exactly (five positions; six = false or this lane's pos[5] = kNoIdx) or as
 // "the five nearest of these six" (SET6 certificate): gather the points, recompute the float distances from the query's current
 // position, put them into the canonical (distance, original index) order - the first five are bitwise the result list of a fresh
-// search at this pose - and build the row.  `six` is uniform over the wave; `nn` receives the ordered five (debug dumps).
+// search at this pose -, radius gate, plane fit, neighbour-only gates, and the fit word that says how far this all stays valid.
+// `six` is uniform over the wave; `nn` receives the ordered five (debug dumps).  Returns 0 (radius gate failed: no plane), else 1 with
+// fit.word's gate bits set.
 template <bool FASTMATH>
-DCREG_DEVFN uint8_t row_from_set(const GridDev &g, const PoseArg &P, const LinArgs &a, const float4 &s4, float qx, float qy, float qz,
-                                 const uint32_t (&pos)[6], bool six, KnnResult<5> &nn, double (&row)[8], double (&nrm)[3], double &r_out,
-                                 double &s_out) {
+DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, const uint32_t (&pos)[6], bool six,
+                                 KnnResult<5> &nn, Fit &fit) {
     float d2[6];
     float4 pt[6];
     const bool use6 = six && pos[5] != kNoIdx;
@@ -1258,9 +1275,35 @@ DCREG_DEVFN uint8_t row_from_set(const GridDev &g, const PoseArg &P, const LinAr
 #pragma unroll
     for (int j = 0; j < 5; ++j) { nn.d2[j] = d2[j]; nn.pt[j] = pt[j]; nn.idx[j] = __float_as_uint(pt[j].w); nn.pos[j] = 0u; }
     nn.full = true; nn.n_eval = 0; nn.n_shell = 0;
-    PointQuery q;
-    q.qx = qx; q.qy = qy; q.qz = qz; q.reach = true;
-    return lin_row<FASTMATH>(P, a, s4, q, nn, row, nrm, r_out, s_out);
+    fit.word = 0u;                                                               // (s = 0: nothing to reuse)
+    fit.plane[0] = fit.plane[1] = fit.plane[2] = fit.plane[3] = 0.0;
+    if (!((double)d2[4] < a.radius_sq)) return 0;                                // :1726
+    const uint8_t gate = plane_of_set<FASTMATH>(a, nn, fit.plane);
+    // how far the ordered list - and the radius gate - hold: half the smallest gap between consecutive distances (among the five, and
+    // up to the sixth when the set is "five of these six"), and the room of the fifth below the radius; 2e-6 relative margins on the
+    // float distances as in make_cert.  (A pair of equal distances gives 0: such a query is refitted every time.)
+    float sd[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sd[j] = sqrt_approx(d2[j]);
+    float s = a.cert_r_in - sd[4] * 1.000002f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = fminf(s, 0.5f * (sd[j + 1] * 0.999998f - sd[j] * 1.000002f));
+    if (use6) s = fminf(s, 0.5f * (sd[5] * 0.999998f - sd[4] * 1.000002f));
+    fit.word = (__float_as_uint(fmaxf(s, 0.f)) & ~3u) | (uint32_t)gate;
+    return 1;
+}
+DCREG_DEVFN bool fit_holds(uint32_t word, float q0x, float q0y, float q0z, float qx, float qy, float qz) {
+    const float dx = qx - q0x, dy = qy - q0y, dz = qz - q0z;
+    const float m2 = (dx * dx + dy * dy + dz * dz) * 1.00001f;
+    const float s = __uint_as_float(word & ~3u);                    // kFitNone is a NaN: the comparison below is false
+    return m2 < s * s;
+}
+// the certificate of the last search, re-based on the query's present position q (inside it): what is left of its radius there
+DCREG_DEVFN uint32_t cert_rebased(uint32_t cert, float q0x, float q0y, float q0z, float qx, float qy, float qz) {
+    const float dx = qx - q0x, dy = qy - q0y, dz = qz - q0z;
+    const float m = sqrt_approx(dx * dx + dy * dy + dz * dz) * 1.00001f;
+    const float s = fmaxf(__uint_as_float(cert & 0x7FFFFFFEu) - m, 0.f) * 0.9999998f;
+    return (__float_as_uint(s) & 0x7FFFFFFEu) | (cert & 0x80000001u);
 }
 
 // The 31 sums' contribution of one point, from its row and flag: [0..20] upper triangle of A A^T (row-major), [21..26]

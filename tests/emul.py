@@ -129,7 +129,7 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
     n = source.n
     fresh = source.state is None or source.prev_index is not index      # a new target voids positions and certificates
     if warm and fresh:
-        source.state = np.full(10 * source.stride, 0xA5A5A5A5, np.uint32)      # garbage on purpose: a fresh state is never read
+        source.state = np.full(19 * source.stride, 0xA5A5A5A5, np.uint32)      # garbage on purpose: a fresh state is never read
         source.prev_pose, source.prev_index = None, index
     state = source.state if warm else None
     R = np.ascontiguousarray(R, np.float64).reshape(9)
@@ -157,7 +157,7 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
         source.prev_pose = pose
     source.searched = int(counts[0])
     res = {"H_upper": out[:21].copy(), "g": out[21:27].copy(), "sum_r2": out[27], "sum_b2": out[28], "n_eff": int(round(out[29])),
-           "n_pt": int(round(out[30])), "searched": int(counts[0]), "plan": "cert" if certify else "full"}
+           "n_pt": int(round(out[30])), "searched": int(counts[0]), "fitted": int(counts[1]), "plan": "cert" if certify else "full"}
     res.update(keep)
     if stats:
         res["stats"] = st

@@ -193,7 +193,8 @@ struct EmuLinParams {
 //             1 = k_rows / k_search_list / k_rows<LISTED>: test every certificate at the query's new position, search only the
 //                 queries whose certificate does not hold there
 // out32: 21 H + 6 g + sum r^2 + sum b^2 + n_eff + n_pt.  Per-point outputs may be null.  stats: [n][8] counters
-// {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}; counts[0] = queries searched.
+// {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}; counts[0] = queries searched, [1] = queries refitted.
+// nn_idx of a query that passed the radius gate on its stored plane (no list rebuilt in this launch) is -2.
 int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_t n, const double R[9], const double t[3],
                   const EmuLinParams *p, uint32_t *state, int64_t stride, int fresh, int certify, int warm,
                   double *out32, int32_t *nn_idx, float *nn_d2,
@@ -211,6 +212,9 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         float ro = (float)(p->search_radius * (1.0 + 1e-5));
         if ((double)ro < p->search_radius * (1.0 + 1e-5)) ro = std::nextafterf(ro, INFINITY);
         a.cert_r_out = ro;
+        float ri = (float)(p->search_radius * (1.0 - 1e-5));
+        if ((double)ri > p->search_radius * (1.0 - 1e-5)) ri = std::nextafterf(ri, 0.0f);
+        a.cert_r_in = ri;
     }
     a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm; a.w_slope = p->weight_slope; a.w_min = p->weight_min;
     a.use_wd = p->use_weight_derivative;
@@ -229,7 +233,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     double tot[31];
     for (double &v : tot) v = 0.0;
     threadIdx.x = 0;
-    int64_t n_searched = 0;
+    int64_t n_searched = 0, n_fitted = 0;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t oi = order ? order[i] : (uint32_t)i;
         const float4 s4{src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], __uint_as_float(oi)};
@@ -237,52 +241,67 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         if (trace) { emu_trace.buf = trace + (size_t)i * (size_t)trace_cap_per_query; emu_trace.cap = (uint32_t)trace_cap_per_query - 1; emu_trace.n = 0; }
         float qx, qy, qz;
         body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
-        uint32_t cert = kCertSearch, pos6[6];
+        uint32_t cert = kCertSearch, fitw = kFitNone, pos6[6];
         for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
         const bool old = state && !fresh;
-        bool need = true;
-        if (certify) {                           // k_rows<LISTED = false>: does the certificate hold here?
-            cert = state[(size_t)6 * stride + i];
-            need = !cert_holds(cert, __uint_as_float(state[(size_t)7 * stride + i]), __uint_as_float(state[(size_t)8 * stride + i]),
-                               __uint_as_float(state[(size_t)9 * stride + i]), qx, qy, qz);
+        uint32_t *st = state ? state + i : nullptr;
+        const size_t ss = (size_t)stride;
+        float q0x = 0.f, q0y = 0.f, q0z = 0.f;
+        if (certify) {                           // what the fast path reads
+            cert = st[6 * ss]; fitw = st[10 * ss];
+            q0x = __uint_as_float(st[7 * ss]); q0y = __uint_as_float(st[8 * ss]); q0z = __uint_as_float(st[9 * ss]);
         }
-        if (old && (certify || warm)) for (int j = 0; j < 6; ++j) pos6[j] = state[(size_t)j * stride + i];
+        const bool need = !(certify && cert_holds(cert, q0x, q0y, q0z, qx, qy, qz));                 // level 1: search
+        const bool refit = !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);   // level 2: gather, order, fit
         Set6 s6{};
-        if (need) {                              // k_search_list / k_full
+        if (need) {
+            if (old && warm) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             uint32_t c2;
-            uint32_t bpos[6];
-            for (int j = 0; j < 6; ++j) bpos[j] = warm ? pos6[j] : kNoIdx;
-            lin_search6(g, runs, a, true, warm && old, bpos, qx, qy, qz, s6, c2);
+            lin_search6(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
             cert = c2;
             for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
-            if (state) {
-                for (int j = 0; j < 6; ++j) state[(size_t)j * stride + i] = s6.pos[j];
-                state[(size_t)6 * stride + i] = c2;
-                state[(size_t)7 * stride + i] = __float_as_uint(qx); state[(size_t)8 * stride + i] = __float_as_uint(qy); state[(size_t)9 * stride + i] = __float_as_uint(qz);
-            }
+            if (state) for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = s6.pos[j];
             ++n_searched;
         }
         if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
-        double row[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
-        uint8_t fl = 0;
+        double row[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss_ = 0.0;
+        uint8_t fl = 0, gate = 255;
         KnnResult<5> nn{};
-        if (!cert_is_out(cert)) {                // SET5 / SET6: rows from the known positions (k_rows; k_full after a search takes five)
-            uint32_t pos[6];
-            for (int j = 0; j < 6; ++j) pos[j] = pos6[j];
-            const bool six = !need && cert_is_set6(cert);
-            if (!six) pos[5] = kNoIdx;
-            fl = p->fast_plane_fit ? row_from_set<true>(g, P, a, s4, qx, qy, qz, pos, six, nn, row, nrm, rr, ss)
-                                   : row_from_set<false>(g, P, a, s4, qx, qy, qz, pos, six, nn, row, nrm, rr, ss);
+        Fit fit{};
+        const bool set = !cert_is_out(cert);
+        const bool fitnow = set && (need || refit);
+        if (fitnow) {
+            const bool six = cert_is_set6(cert);      // (then the fit certificate has to cover the 5th / 6th gap itself)
+            if (!need) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
+            if (!six) pos6[5] = kNoIdx;
+            const uint8_t in_r = p->fast_plane_fit ? fit_from_set<true>(g, a, qx, qy, qz, pos6, six, nn, fit) : fit_from_set<false>(g, a, qx, qy, qz, pos6, six, nn, fit);
+            gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
+            if (state) {
+                if (!need) cert = cert_rebased(cert, q0x, q0y, q0z, qx, qy, qz);
+                st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
+                st[10 * ss] = fit.word;
+                for (int k = 0; k < 4; ++k) { uint64_t b; std::memcpy(&b, &fit.plane[k], 8); st[(size_t)(11 + 2 * k) * ss] = (uint32_t)b; st[(size_t)(12 + 2 * k) * ss] = (uint32_t)(b >> 32); }
+            }
+            ++n_fitted;
+        } else if (set) {                        // level 3: the stored plane
+            gate = (uint8_t)(fitw & 3u);
+            for (int k = 0; k < 4; ++k) { const uint64_t b = ((uint64_t)st[(size_t)(12 + 2 * k) * ss] << 32) | st[(size_t)(11 + 2 * k) * ss]; std::memcpy(&fit.plane[k], &b, 8); }
+        } else if (need && state) {
+            st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
+            st[10 * ss] = kFitNone;
         }
+        if (gate == 0) fl = p->fast_plane_fit ? row_of_plane<true>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, rr, ss_) : row_of_plane<false>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, rr, ss_);
+        else fl = gate == 255 ? 0 : gate;
+        const bool listed = fitnow;              // the neighbour list exists only where it was rebuilt in this launch
         row_products(row, fl, acc);
         for (int j = 0; j < 31; ++j) tot[j] += acc[j];
-        if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = fl != 0 ? (int32_t)nn.idx[j] : -1;
-        if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = fl != 0 ? nn.d2[j] : INFINITY;
+        if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = (fl != 0 && listed) ? (int32_t)nn.idx[j] : (fl != 0 ? -2 : -1);
+        if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = (fl != 0 && listed) ? nn.d2[j] : INFINITY;
         if (flag_out) flag_out[oi] = fl;
         if (fl == 1 || fl == 4) {
             if (normal) { normal[3 * (size_t)oi] = nrm[0]; normal[3 * (size_t)oi + 1] = nrm[1]; normal[3 * (size_t)oi + 2] = nrm[2]; }
             if (r_out) r_out[oi] = rr;
-            if (s_out) s_out[oi] = ss;
+            if (s_out) s_out[oi] = ss_;
         }
         if (stats) {
             uint32_t *s = stats + 8 * (size_t)i;      // in processing order (the wave model groups consecutive queries)
@@ -292,7 +311,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     }
     for (int j = 0; j < 31; ++j) out32[j] = tot[j];
     out32[31] = 0.0;
-    if (counts) counts[0] = n_searched;
+    if (counts) { counts[0] = n_searched; counts[1] = n_fitted; }
     return 0;
 }
 
