@@ -72,10 +72,10 @@ struct PoseArg {
 //     SET5 (sign 0, low bit 0): while the query stays within s metres of q0 its 5-nearest SET cannot change: s = (a5 - a4) / 2 of
 //                   the 5th / 6th neighbour distances a4 / a5 at q0.  A linearisation at a pose that keeps it there needs no search:
 //                   it gathers the 5 points, recomputes the five float distances and sorts them - bitwise what a fresh search returns.
-//     SET6 (sign 0, low bit 1): the same one neighbour further out - within s = (a6 - a5) / 2 metres the SIX nearest are the six
-//                   known points (a6 = a lower bound of the 7th neighbour's distance, which the search gets for free: what it looked
-//                   at and did not keep, and the pruning radius it never looked beyond): gather 6, sort, take the first five.  The
-//                   gaps a5 - a4 and a6 - a5 are independent, so the better of the two certificates fails quadratically less often.
+//     SET6 (sign 0, low bit 1): within s = (a6 - a4) / 2 metres the five nearest are AMONG the six known points (a6 = a lower
+//                   bound of the 7th neighbour's distance, which the search gets almost for free: what it looked at and did not keep,
+//                   and the pruning radius it never looked beyond): gather 6, sort, take the first five.  Two neighbour gaps
+//                   instead of one: such a certificate fails quadratically less often.
 //     OUT (sign 1): the 5th neighbour was beyond the search radius by s metres (or not found at all inside the slightly larger search
 //                   bound): within s metres of q0 the query fails the radius gate (:1726) and nothing needs to be loaded at all.
 // Nothing of a state changes between two searches of a query, and the test is on the two stored float positions themselves (their
@@ -117,9 +117,9 @@ struct HeapExact {
     uint32_t pos[K];
     uint32_t n_eval;     // candidates evaluated (statistics only; dead code unless read)
     uint32_t n_shell;    // outermost shell scanned
-    float infl;          // the walk prunes at worst_d2() = K-th best x infl (>= 1): everything it never looked at is at least that far
-    DCREG_DEVFN void init(float bound_f, float infl_ = 1.f) {
-        infl = infl_;
+    float infl, cap;     // the walk prunes at worst_d2() = inflated(K-th best): see HeapFast
+    DCREG_DEVFN void init(float bound_f, float infl_ = 1.f, float cap_ = __builtin_inff()) {
+        infl = infl_; cap = cap_;
         const uint64_t bound = ((uint64_t)__float_as_uint(bound_f) << 32) | 0xFFFFFFFFull;
 #pragma unroll
         for (int i = 0; i < K; ++i) { key[i] = bound; pos[i] = kNoIdx; }
@@ -140,7 +140,7 @@ struct HeapExact {
             }
         }
     }
-    DCREG_DEVFN float worst_d2() const { return __uint_as_float((uint32_t)(key[K - 1] >> 32)) * infl; }
+    DCREG_DEVFN float worst_d2() const { const float d = __uint_as_float((uint32_t)(key[K - 1] >> 32)); return fmaxf(d, fminf(d * infl, cap)); }
     DCREG_DEVFN float dist(int j) const { return __uint_as_float((uint32_t)(key[j] >> 32)); }
     DCREG_DEVFN bool full() const { return pos[K - 1] != kNoIdx; }
 };
@@ -164,10 +164,13 @@ struct HeapFast {
     uint32_t pos[K];
     float outside_min;   // smallest d2 among all points seen that are not in the heap
     uint32_t n_eval, n_shell;
-    float infl;          // the walk prunes at worst_d2() = K-th best x infl (>= 1): everything it never looked at is at least that far,
-                         // everything it looked at and did not keep is in outside_min - together a lower bound for the (K+1)-th neighbour
-    DCREG_DEVFN void init(float bound_f, float infl_ = 1.f) {
-        infl = infl_;
+    float infl, cap;     // the walk prunes at worst_d2() = max(d, min(d x infl, cap)) of the K-th best squared distance d: a small ball
+                         // (a query among its neighbours) is searched a little beyond what exactness needs, a large one is not -
+                         // continuous and non-decreasing in d, so everything the walk never looked at is at least worst_d2() away at
+                         // the end; everything it looked at and did not keep is in outside_min - together a lower bound for the
+                         // (K+1)-th neighbour
+    DCREG_DEVFN void init(float bound_f, float infl_ = 1.f, float cap_ = __builtin_inff()) {
+        infl = infl_; cap = cap_;
 #pragma unroll
         for (int i = 0; i < K; ++i) { d[i] = bound_f; pos[i] = kNoIdx; }
         outside_min = __builtin_inff();
@@ -264,7 +267,7 @@ struct HeapFast {
             d[0] = fminf(d[0], d2);
         }
     }
-    DCREG_DEVFN float worst_d2() const { return d[K - 1] * infl; }
+    DCREG_DEVFN float worst_d2() const { return fmaxf(d[K - 1], fminf(d[K - 1] * infl, cap)); }
     DCREG_DEVFN float dist(int j) const { return d[j]; }
     DCREG_DEVFN bool full() const { return pos[K - 1] != kNoIdx; }
     // a point outside the heap ties with the K-th best: the set may depend on the index tie-break
@@ -373,8 +376,8 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
 // the ball covers the search radius.
 template <class H>
 DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, H &hp, float infl = 1.f) {   // max_ring < 0: unbounded
-    hp.init(bound_f, infl);
+                                           int max_ring, H &hp, float infl = 1.f, float cap = __builtin_inff()) {   // max_ring < 0: unbounded
+    hp.init(bound_f, infl, cap);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)max_ring + 1.0;
     if (max_ring >= 0) {
@@ -1060,9 +1063,9 @@ struct Set6 {
 // 5th and 6th best distances are equal floats; then - lattices, duplicated points - the 64-bit-key search (distance, original index)
 // is run for this lane and its first five entries are the canonical set.  (A tie between the 6th best and a point outside does not
 // matter: neither belongs to the five, and both are at the distance the certificate uses.)
-DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, Set6 &out) {
+DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, float cap, Set6 &out) {
     HeapFast<6> hf;
-    knn_search<HeapFast<6>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl);
+    knn_search<HeapFast<6>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap);
     out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
@@ -1088,8 +1091,11 @@ DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, floa
 DCREG_DEVFN uint32_t make_cert(const Set6 &s, const LinArgs &a) {
     const float a4 = sqrt_approx(s.d2[4]), a5 = sqrt_approx(s.d2[5]), a6 = sqrt_approx(s.lb7);
     const float s_out = a4 * 0.999998f - a.cert_r_out;                                          // > 0: the 5th neighbour is beyond the gate radius
+    // SET5: the five nearest stay the five nearest while a4 + m < a5 - m.  SET6: the five nearest stay AMONG the six known points
+    // while a4 + m < a6 - m (the fifth smallest of the six new distances is at most a4 + m, everything else at least a6 - m): two
+    // gaps instead of one - whenever a sixth neighbour is known this is the larger radius
     const float s5 = s.pos[4] != kNoIdx ? 0.5f * (a5 * 0.999998f - a4 * 1.000002f) : -1.f;
-    const float s6 = s.pos[5] != kNoIdx ? 0.5f * (a6 * 0.999998f - a5 * 1.000002f) : -1.f;
+    const float s6 = s.pos[5] != kNoIdx ? 0.5f * (a6 * 0.999998f - a4 * 1.000002f) : -1.f;
     if (s_out > 0.f && s_out >= fmaxf(s5, s6)) return __float_as_uint(s_out) | 0x80000000u;
     // (clearing / setting the lowest mantissa bit moves s by at most one ulp: rounded down where it matters)
     if (s6 > s5) return (__float_as_uint(fmaxf(s6 * 0.9999998f, 0.f)) & ~1u) | 1u;
@@ -1127,10 +1133,10 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
     float bound = a.radius_sq_f;
     if (warm && oldpos[5] != kNoIdx) bound = warm_bound6(g, oldpos, qx, qy, qz, bound);
     // a search whose ball is small (the query sits among its neighbours: the regime in which certificates get used) looks a little
-    // further than it must - bound and pruning distance inflated alike, so that what lies beyond is a useful lower bound for the 7th
-    // neighbour; a search over many cells (a query far from the surface it belongs to) is expensive enough as it is
-    float infl = 1.f;
-    if (bound <= a.infl_max_d2) { infl = a.prune_infl; bound = fminf(bound * infl, a.radius_sq_f); }
+    // further than it must - bound and pruning distance inflated alike (HeapFast::worst_d2), so that what lies beyond is a useful
+    // lower bound for the 7th neighbour; a search over many cells (a query far from the surface it belongs to) is expensive enough
+    const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
+    bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)a.max_ring + 1.0;
     // a query farther than max_ring cells from the grid has no neighbour inside the search bound
@@ -1138,7 +1144,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
     st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;
-    if (reach) search6(g, runs, qx, qy, qz, bound, a.max_ring, infl, st);
+    if (reach) search6(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st);
     cert = make_cert(st, a);
 }
 
