@@ -309,8 +309,8 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     c->last_max_ring = k;
     a.euler = p->parameterization == DCREG_PARAM_EULER ? 1 : 0;
     if (p->parameterization != DCREG_PARAM_SO3 && p->parameterization != DCREG_PARAM_EULER) { c->fail("unknown parameterization"); return DCREG_E_INVALID; }
-    for (double &v : a.dR) v = 0.0;
-    if (a.euler) {   // derivatives of R = Rz(yaw) Ry(pitch) Rx(roll) (Pose6D2Matrix, utils.hpp:452-460)
+    a.dR = nullptr;
+    if (a.euler) {   // derivatives of R = Rz(yaw) Ry(pitch) Rx(roll) (Pose6D2Matrix, utils.hpp:452-460), handed over in device memory
         const double cr = std::cos(p->euler_rpy[0]), sr = std::sin(p->euler_rpy[0]);
         const double cp = std::cos(p->euler_rpy[1]), sp = std::sin(p->euler_rpy[1]);
         const double cy = std::cos(p->euler_rpy[2]), sy = std::sin(p->euler_rpy[2]);
@@ -322,7 +322,15 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j]; T[i * 3 + j] = s; }
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * C3[k * 3 + j]; out[i * 3 + j] = s; }
         };
-        mul3(Rz, Ry, dRx, a.dR); mul3(Rz, dRy, Rx, a.dR + 9); mul3(dRz, Ry, Rx, a.dR + 18);
+        if (!c->h_euler) {
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_euler, 27 * sizeof(double), hipHostMallocDefault));
+            HIP_TRY(c, hipMalloc((void **)&c->d_euler, 27 * sizeof(double)));
+        }
+        // (the staging block is reused: the launches of the Euler engine are blocking calls, one at a time)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        mul3(Rz, Ry, dRx, c->h_euler); mul3(Rz, dRy, Rx, c->h_euler + 9); mul3(dRz, Ry, Rx, c->h_euler + 18);
+        HIP_TRY(c, hipMemcpyAsync(c->d_euler, c->h_euler, 27 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        a.dR = c->d_euler;
     }
     return DCREG_OK;
 }
@@ -745,6 +753,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)dcreg_linearize_gate_abort(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->h_gate) (void)hipHostFree(c->h_gate);
+    if (c->h_euler) (void)hipHostFree(c->h_euler);
+    if (c->d_euler) (void)hipFree(c->d_euler);
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,

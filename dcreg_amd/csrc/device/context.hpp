@@ -70,6 +70,7 @@ struct dcreg_ctx {
     size_t state_batch_stride = 0;
     int64_t n_batch_states = 0;
     std::vector<uint8_t> batch_state_valid;
+    double *h_euler = nullptr, *d_euler = nullptr;     // Euler engine: the 27 derivative entries of a launch (LinArgs::dR)
     unsigned long long *d_search_count = nullptr;      // option "count_searches": points searched since the last reset
 
     // build scratch

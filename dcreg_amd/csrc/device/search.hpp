@@ -103,7 +103,8 @@ struct LinArgs {
     uint32_t state_stride;
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
-    double dR[27];                // euler: dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll), row-major
+    const double *dR;             // euler: 27 doubles in device memory - dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll),
+                                  // row-major (behind a pointer: as a member the 54 words would be hoisted into registers for every launch)
 };
 
 // ---------------------------------------------------------------- k-NN heaps (sorted, K entries)

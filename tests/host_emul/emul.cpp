@@ -224,7 +224,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     a.warm = warm;
     a.prune_infl = (float)((1.0 + p->cert_inflate) * (1.0 + p->cert_inflate));
     a.infl_max_d2 = (float)(4.0 * g.h * g.h);
-    a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0;
+    a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0; a.dR = nullptr;
     PoseArg P{};
     std::memcpy(P.R, R, sizeof(P.R)); std::memcpy(P.t, t, sizeof(P.t));
     P.state = state ? 0u : kNoIdx; P.fresh = fresh ? 1u : 0u;
