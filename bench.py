@@ -435,6 +435,10 @@ def concurrent_pairs(P0, D, args, steps, warmup):
 def dry_run(args, D):
     """DCREG_BENCH_DRYRUN=1 (CPU test hook): the launcher, rendezvous, fence, max-over-ranks and gather paths with a
     synthetic per-rank record instead of device work.  Prints a line marked "dry_run": true that is NOT a measurement."""
+    from dcreg_amd import api, hostinfo
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(D.world)))
+    want = hostinfo.threads_per_rank(local_world)
+    got = api.set_host_threads(want)                 # (overrides the OMP_NUM_THREADS=1 torch.distributed.run exports)
     times = []
     for _ in range(2):
         D.fence()
@@ -442,10 +446,11 @@ def dry_run(args, D):
         time.sleep(0.01 * (1 + D.rank))
         D.fence()
         times.append(D.max_over_ranks(time.perf_counter() - t0))
-    recs = D.gather_rows([float(D.rank), float(100 + D.rank), 0.0, 0.0])
+    recs = D.gather_rows([float(D.rank), float(100 + D.rank), float(got), 0.0])
     if D.rank == 0:
         print(json.dumps({"dry_run": True, "metric": "ICP iterations/sec", "value": None, "n_gpus": D.world, "steps": args.steps,
                           "warmup": args.warmup, "rank_seeds": [int(r[1]) for r in recs], "ranks": [int(r[0]) for r in recs],
+                          "host_threads": [int(r[2]) for r in recs], "host_threads_per_rank": want,
                           "block_times_s": times}), flush=True)
     D.close()
 

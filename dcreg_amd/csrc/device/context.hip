@@ -594,12 +594,13 @@ static int wait_rows(dcreg_ctx *c, LinSlot &S) {
     using Clk = std::chrono::steady_clock;
     Clk::time_point t0;
     bool clocked = false;
+    const uint64_t every = c->opt_wait_seconds < 1.0 ? ((1ull << 6) - 1) : ((1ull << 20) - 1);      // (sub-second patience: tests of this path)
     for (size_t i = 0; i < S.n_rows; ++i) {
         volatile unsigned long long *flag = (volatile unsigned long long *)(S.h_out + i * kSlots + 31);
         uint64_t spins = 0;
         while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) {
             __builtin_ia32_pause();
-            if ((++spins & ((1ull << 20) - 1)) != 0) continue;
+            if ((++spins & every) != 0) continue;
             if (!clocked) { t0 = Clk::now(); clocked = true; continue; }
             if (std::chrono::duration<double>(Clk::now() - t0).count() < c->opt_wait_seconds) continue;
             if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);      // nothing may wait behind us while we drain the stream

@@ -10,6 +10,7 @@
 #include <cstdio>
 
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include <hip/hip_runtime.h>
@@ -27,6 +28,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;        // what went wrong while loading (the loader's message of the first failed dlopen, captured at once: dlerror()
+                            // clears itself when read and is overwritten by the next attempt)
     bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather && GetErrorString; }
 };
 
@@ -35,26 +38,37 @@ struct RcclApi {
 // to the HIP runtime THIS library is bound to - found by asking the loader where hipMalloc lives.
 RcclApi &rccl() {
     static RcclApi api;
-    if (api.handle) return api;
-    std::string dir;
-    Dl_info info;
-    if (dladdr((void *)static_cast<hipError_t (*)(void **, size_t)>(&hipMalloc), &info) && info.dli_fname) {
-        dir = info.dli_fname;
-        const size_t slash = dir.rfind('/');
-        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
-    }
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    if (!dir.empty())
-        for (const char *n : names) { api.handle = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL); if (api.handle) break; }
-    if (!api.handle) for (const char *n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.handle) break; }
-    if (!api.handle) return api;
-    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
-    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
-    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
-    api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
-    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+    static std::once_flag once;         // (dcreg_icp_run_many runs one host thread per ctx: the first users may arrive together)
+    std::call_once(once, [] {
+        std::string dir;
+        Dl_info info;
+        if (dladdr((void *)static_cast<hipError_t (*)(void **, size_t)>(&hipMalloc), &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            const size_t slash = dir.rfind('/');
+            dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+        }
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        auto attempt = [&](const std::string &path) {
+            if (api.handle) return;
+            api.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { const char *e = dlerror(); if (api.why.empty()) api.why = e ? e : "dlopen failed"; }
+        };
+        if (!dir.empty()) for (const char *n : names) attempt(dir + n);
+        for (const char *n : names) attempt(n);
+        if (!api.handle) return;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))dlsym(api.handle, "ncclAllGather");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+        if (!api.ok()) api.why = "librccl was loaded but lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllGather / GetErrorString";
+    });
     return api;
 }
+
+// ncclCommInitRank prints a version banner on stdout; stdout belongs to the caller (bench.py prints exactly one JSON line there), so
+// file descriptor 1 points at stderr while it runs.  Descriptors are process-wide: one initialisation at a time.
+std::mutex g_init_mutex;
 
 }  // namespace
 
@@ -92,20 +106,22 @@ int dcreg_comm_init(dcreg_ctx *c, const void *id128, int rank, int world) {
     if (!c) return DCREG_E_INVALID;
     if (!id128 || world < 1 || rank < 0 || rank >= world) { c->fail("invalid communicator arguments"); return DCREG_E_INVALID; }
     RcclApi &A = rccl();
-    if (!A.ok()) { c->fail("RCCL is not available (dlopen librccl.so.1 failed: %s)", dlerror() ? dlerror() : "symbols missing"); return DCREG_E_DEVICE; }
+    if (!A.ok()) { c->fail("RCCL is not available (%s)", A.why.empty() ? "librccl.so.1 not found" : A.why.c_str()); return DCREG_E_DEVICE; }
     (void)dcreg_comm_destroy(c);
     if (hipSetDevice(c->device) != hipSuccess) { c->fail("hipSetDevice failed"); return DCREG_E_DEVICE; }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     ncclComm_t comm = nullptr;
-    // RCCL prints a version banner on stdout during the first initialisation; stdout belongs to the caller (bench.py prints
-    // exactly one JSON line there), so the banner is sent to stderr
-    std::fflush(stdout);
-    const int saved = dup(1);
-    if (saved >= 0) (void)dup2(2, 1);
-    const ncclResult_t r = A.CommInitRank(&comm, world, id, rank);
-    std::fflush(stdout);
-    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+    ncclResult_t r;
+    {
+        std::lock_guard<std::mutex> lock(g_init_mutex);
+        std::fflush(stdout);
+        const int saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+        r = A.CommInitRank(&comm, world, id, rank);
+        std::fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+    }
     if (r != ncclSuccess) { c->fail("ncclCommInitRank failed: %s", A.GetErrorString(r)); return DCREG_E_DEVICE; }
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
     const size_t row = 32 * sizeof(double);

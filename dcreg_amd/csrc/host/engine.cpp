@@ -159,7 +159,9 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
         if (piped && st != 1 && it + 1 < cfg->max_iterations) {
             // the pose of the next linearisation exists: let the device go before the bookkeeping below
             if (queued) rc = dcreg_linearize_gate_open(ctx, R, t);                       // the queued launch starts now
-            else rc = dcreg_linearize_batch_begin(ctx, slot ^ 1, 1, R, t, &prm);         // (queueing ahead had failed)
+            // (no launch waits: queueing ahead had failed, or the wait for this iteration's result ran out of patience and called the
+            // queued launch off before draining the stream - context.hip wait_rows)
+            if (!queued || rc == DCREG_E_STATE) rc = dcreg_linearize_batch_begin(ctx, slot ^ 1, 1, R, t, &prm);
             queued = false;
             if (rc != DCREG_OK) return rc;
             slot ^= 1;

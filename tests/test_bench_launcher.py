@@ -39,6 +39,19 @@ def test_self_spawn_two_ranks_dry_run():
     assert all(t >= 0.02 for t in j["block_times_s"])                 # max over ranks: rank 1 sleeps twice as long as rank 0
 
 
+@pytest.mark.timeout(600)
+def test_self_spawn_eight_ranks_dry_run():
+    """The shape the driver's scaling run has - `python bench.py --gpus 8` on one node: eight ranks rendezvous on 127.0.0.1, fence,
+    take the max over ranks and gather one record each; every rank gets its own scan-pair seed and its share of the host's CPUs."""
+    p = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5"], {"DCREG_BENCH_DRYRUN": "1", "DCREG_BENCH_BACKEND": "gloo"}, timeout=550)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _json_line(p)
+    assert j["dry_run"] is True and j["n_gpus"] == 8
+    assert j["ranks"] == list(range(8)) and j["rank_seeds"] == [100 + r for r in range(8)]
+    assert all(t >= 0.08 for t in j["block_times_s"])                 # max over ranks: rank 7 sleeps 8 x 10 ms
+    assert j["host_threads_per_rank"] >= 1 and len(set(j["host_threads"])) == 1 and j["host_threads"][0] == j["host_threads_per_rank"]
+
+
 def test_refuses_a_job_it_cannot_run():
     import torch
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:

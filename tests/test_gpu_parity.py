@@ -655,6 +655,29 @@ def test_certificates_only_spare_searches(cyl):
     assert a[8]["points_searched"] < 0.75 * a[8]["points"] and a[9]["points_searched"] < 0.75 * a[9]["points"]      # (25 iterations from 0.4 m / 3 deg off)
 
 
+def test_a_wait_that_runs_out_of_patience_is_harmless(cyl):
+    """"wait_seconds": when a result has not arrived after that long, the waiting host calls off the launch queued behind it (a gate
+    that would otherwise wait for this very thread), drains the stream to surface a device fault, and carries on when the result is
+    there after all (a slow but healthy launch).  With no patience at all every wait of the pipelined engine takes that path: the run
+    must come out bitwise as usual, and the context must stay usable."""
+    tgt = cyl[0]
+    src = tgt[::2]
+    T0 = h.pose6d_matrix(0.3, -0.2, 0.1, h.deg2rad(2.0), h.deg2rad(-1.0), h.deg2rad(3.0))
+    cfg = api.default_config(search_radius=1.0, max_iterations=12, CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0)
+    got = []
+    for patience in (30.0, 1e-9):
+        c = api.Context(0)
+        c.set_option("wait_seconds", patience); c.set_target(tgt, 1.0); c.set_source(src)
+        res, logs = c.icp_run(T0, "Ours", cfg)
+        res2, _ = c.icp_run(T0, "Ours", cfg)
+        lin = c.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(1.0, 1))
+        got.append((res.iterations, np.array(res.R[:]), np.array(res.t[:]), np.array(res2.R[:]), [np.array(L.H_upper[:]) for L in logs], lin["H_upper"]))
+        c.close()
+    a, b = got
+    assert a[0] == b[0] == 12 and all(np.array_equal(a[k], b[k]) for k in (1, 2, 3, 5))
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+
+
 def test_far_from_the_origin_and_very_dense_cells(ctx):
     """Coordinates ~1e5 m from the origin (float spacing 8 mm: heavy quantisation, exact ties, cell arithmetic in double) and a cloud
     whose 60 k points sit in a 2 cm cube (runs of tens of thousands of points per cell): exact k-NN and a linearisation vs the oracle."""

@@ -113,3 +113,69 @@ def test_two_rank_gather_equals_single_process():
         assert np.array_equal(np.delete(recs, mc.R_TIME, 1), np.delete(single_recs, mc.R_TIME, 1))
         assert stats == single_stats
     assert 0 < single_stats["converged_runs"] <= N_TRIALS
+
+
+def _worker8(rank, world, port, q):
+    """The native driver's data path without a GPU: shard, per-rank records (synthetic: a function of the trial id), gather, statistics."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 45                                            # not a multiple of 8: ragged shards, padded blocks in the gather
+    mine = mc.shard_indices(n, rank, world)
+    local = np.zeros((len(mine), mc.REC))
+    local[:, mc.R_TRIAL] = mine
+    local[:, mc.R_ITERS] = 3 + mine % 5
+    local[:, mc.R_CONV] = mine % 2
+    local[:, mc.R_TERR] = 0.01 * mine
+    for j, k in enumerate(mine):
+        local[j, mc.R_T:mc.R_T + 16] = mc.trial_pose(BASE, int(k), 99, 0.3, 0.01).reshape(16)      # every rank draws trial k's pose itself
+    allr = mc.gather_records(local, n, dist, "cpu")
+    q.put((rank, allr, mc.method_statistics(allr)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_of_eight_shards_cover_and_gather():
+    """8 ranks (the node the scaling curve is for): k = rank mod 8 covers every trial exactly once, the padded fixed-size blocks
+    gather into one table ordered by trial on EVERY rank, seeds depend on the trial only."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    q = ctx.Queue()
+    world = 8
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cover = np.concatenate([mc.shard_indices(45, r, world) for r in range(world)])
+    assert sorted(cover.tolist()) == list(range(45))
+    ref = sorted(got)[0][1]
+    assert np.array_equal(ref[:, mc.R_TRIAL], np.arange(45)) and np.array_equal(ref[:, mc.R_ITERS], 3 + np.arange(45) % 5)
+    for k in (0, 7, 44):
+        assert np.array_equal(ref[k, mc.R_T:mc.R_T + 16].reshape(4, 4), mc.trial_pose(BASE, k, 99, 0.3, 0.01))
+    for rank, allr, stats in got:
+        assert np.array_equal(allr, ref) and stats["total_runs"] == 45 and stats["converged_runs"] == 22
+
+
+def test_host_share_of_a_rank():
+    """hostinfo: a rank's OpenMP team is its share of the CPUs the container may really use (cgroup quota and affinity, not the machine's
+    hardware threads), and dcreg_set_host_threads overrides the OMP_NUM_THREADS=1 a launcher exports."""
+    from dcreg_amd import api, hostinfo
+    n = hostinfo.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    q = hostinfo.cgroup_cpu_quota()
+    assert q is None or n <= max(1, int(q))
+    assert hostinfo.threads_per_rank(1) == min(32, n) and hostinfo.threads_per_rank(8) == max(1, min(32, n // 8))
+    assert hostinfo.threads_per_rank(10 ** 6) == 1
+    before = api.load().dcreg_get_host_threads()
+    try:
+        assert api.set_host_threads(3) == 3 and api.load().dcreg_get_host_threads() == 3
+        with pytest.raises(api.DcregError):
+            api.set_host_threads(0)
+    finally:
+        api.set_host_threads(max(before, 1))
