@@ -392,7 +392,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     int rc = make_lin_args(c, p, a);
     if (rc) return rc;
     if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
-    const uint32_t nbx = blocks_for(c->n_src, kBlock);
+    const uint32_t nbx = blocks_for(c->n_src, kLinBlock);
     if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
     const bool fused = (n_poses == 1);
@@ -539,7 +539,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
-    hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
+    hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
                        S.d_partials, nbx, fin, dd, abort_flag)
         if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
@@ -551,7 +551,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (le != hipSuccess) return bail("linearisation kernel launch", le);
     }
     if (!fused) {
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)n_poses), dim3(kLinBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq);
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) return bail("k_finalize launch", le);
     }

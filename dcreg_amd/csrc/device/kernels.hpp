@@ -172,26 +172,27 @@ __device__ __forceinline__ void st_system(double *p, double v) {
 }
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// sum of `count` (<= kChunk) rows of kSlots doubles, fixed order: lane group g adds rows g, g+8, ... then the 8 group
-// sums are added in order.  All 256 threads call; threads < 31 return the total of their slot.
+// sum of `count` (<= kChunk) rows of kSlots doubles, fixed order: lane group g (of G = kLinBlock / 32) adds rows g, g + G, ... then the
+// G group sums are added in order.  All kLinBlock threads call; threads < 31 return the total of their slot.
 __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t count, double (*sm)[kSlots]) {
+    constexpr int G = kLinBlock / 32;               // lane groups of 32: one slot each
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    double v[kChunk / 8];
+    double v[kChunk / G];
 #pragma unroll
-    for (int u = 0; u < kChunk / 8; ++u) {
-        const uint32_t r = (uint32_t)grp + 8u * u;
+    for (int u = 0; u < kChunk / G; ++u) {
+        const uint32_t r = (uint32_t)grp + (uint32_t)G * u;
         v[u] = r < count ? ld_agent(rows + (size_t)r * kSlots + j) : 0.0;
     }
     double t = 0.0;
 #pragma unroll
-    for (int u = 0; u < kChunk / 8; ++u) t += v[u];
+    for (int u = 0; u < kChunk / G; ++u) t += v[u];
     __syncthreads();
     sm[grp][j] = t;
     __syncthreads();
     double tot = 0.0;
     if (threadIdx.x < 31) {
 #pragma unroll
-        for (int gi = 0; gi < 8; ++gi) tot += sm[gi][threadIdx.x];
+        for (int gi = 0; gi < G; ++gi) tot += sm[gi][threadIdx.x];
     }
     return tot;
 }
@@ -267,10 +268,10 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
         if (threadIdx.x < 29) {
             const int e = gram_entry_of_slot(threadIdx.x);
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) t += (&red[0][0])[w * 64 + e];
+            for (int w = 0; w < kLinBlock / 64; ++w) t += (&red[0][0])[w * 64 + e];
         } else if (threadIdx.x < 31) {
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) t += cnt[w][threadIdx.x - 29];
+            for (int w = 0; w < kLinBlock / 64; ++w) t += cnt[w][threadIdx.x - 29];
         }
         if (FUSED) {
             st_agent(my_rows + (size_t)vb * kSlots + threadIdx.x, t);
@@ -302,19 +303,19 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
 
 // ---------------------------------------------------------------- k_lin
 template <int MODE, bool FUSED, bool FAST>
-static __global__ __launch_bounds__(kBlock, 4) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+static __global__ __launch_bounds__(kLinBlock, 4) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
-    __shared__ double red[8][kSlots];
-    __shared__ double cnt[kBlock / 64][2];
+    __shared__ double red[kLinBlock / 32][kSlots];
+    __shared__ double cnt[kLinBlock / 64][2];
     __shared__ int s_role;
-    __shared__ RunList runs[kBlock / kWave];
+    __shared__ RunList runs[kLinBlock / kWave];
     const int wave = threadIdx.x >> 6;
     const uint32_t pose_id = blockIdx.y;
     const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
-    const uint32_t i = vb * kBlock + threadIdx.x;
+    const uint32_t i = vb * kLinBlock + threadIdx.x;
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
     double row[8];
@@ -457,9 +458,9 @@ static __global__ __launch_bounds__(kBlock, 4) void k_lin(const float4 *__restri
 // single-pose path (chunk sums, then chunks in index order), so a batched pose is bitwise equal to the same pose
 // linearised alone.  Writes 31 sums to the pinned, host-coherent result row, then publishes the sequence number the
 // host spins on (no stream synchronise on the hot path).  out row layout: [0..30] sums, [31] = sequence number.
-static __global__ __launch_bounds__(kBlock) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out,
+static __global__ __launch_bounds__(kLinBlock) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out,
                                                             unsigned long long seq) {
-    __shared__ double sm[8][kSlots];
+    __shared__ double sm[kLinBlock / 32][kSlots];
     const uint32_t pose_id = blockIdx.x;
     const double *base = partials + (size_t)pose_id * n_blocks * kSlots;
     double tot = 0.0;

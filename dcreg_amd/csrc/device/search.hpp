@@ -40,7 +40,11 @@ inline float med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(
 #define DCREG_TRACE(kk, dz, dy, which, trips) emu_trace_push(((((uint32_t)(kk) << 20) | ((uint32_t)((dz) + 512) << 10) | (uint32_t)((dy) + 512)) << 1) | (uint32_t)(which), (uint32_t)(trips))
 #endif
 
-constexpr int kBlock = 256;          // 4 waves
+constexpr int kBlock = 256;          // 4 waves: the utility kernels
+#if !defined(DCREG_LIN_BLOCK)
+#define DCREG_LIN_BLOCK 256
+#endif
+constexpr int kLinBlock = DCREG_LIN_BLOCK;   // threads per block of the linearisation kernel: one partial row per kLinBlock source points
 constexpr int kSlots = 32;           // doubles per partial row
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
 
