@@ -585,7 +585,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     return DCREG_OK;
 }
 
-// wait for the result rows of a launch.  Hot path: spin on the sequence numbers the kernels publish into pinned host memory.  A
+// wait for the result rows of a launch.  Hot path: spin on the rows the kernels publish into pinned host memory (check word).  A
 // launch may be slow but healthy (a GPU shared with other processes, huge clouds), and while it is awaited a gate for the NEXT launch
 // may already sit in the stream: a stream synchronise would then wait for that gate, i.e. for this very thread.  So the wait is
 // bounded by wall-clock time (far below the gate's own patience); only when it runs out is the stream drained - after calling the
@@ -595,10 +595,21 @@ static int wait_rows(dcreg_ctx *c, LinSlot &S) {
     Clk::time_point t0;
     bool clocked = false;
     const uint64_t every = c->opt_wait_seconds < 1.0 ? ((1ull << 6) - 1) : ((1ull << 20) - 1);      // (sub-second patience: tests of this path)
+    // a row has arrived when its check word fits the 31 values next to it (kernels.hpp publish_row)
+    auto arrived = [&](size_t i) {
+        const volatile unsigned long long *w = (const volatile unsigned long long *)(S.h_out + i * kSlots);
+        unsigned long long v[kSlots];
+        for (int k = 0; k < kSlots; ++k) v[k] = __atomic_load_n(&w[k], __ATOMIC_RELAXED);
+        unsigned long long chk = S.seq * row_check_mult(31);
+        for (int k = 0; k < 31; ++k) chk += v[k] * row_check_mult(k);
+        if (chk != v[31]) return false;
+        std::memcpy(S.h_rows.data() + i * kSlots, v, sizeof(v));      // the snapshot that was checked is the one that is used
+        return true;
+    };
+    S.h_rows.resize(S.n_rows * kSlots);
     for (size_t i = 0; i < S.n_rows; ++i) {
-        volatile unsigned long long *flag = (volatile unsigned long long *)(S.h_out + i * kSlots + 31);
         uint64_t spins = 0;
-        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) {
+        while (!arrived(i)) {
             __builtin_ia32_pause();
             if ((++spins & every) != 0) continue;
             if (!clocked) { t0 = Clk::now(); clocked = true; continue; }
@@ -606,7 +617,8 @@ static int wait_rows(dcreg_ctx *c, LinSlot &S) {
             if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);      // nothing may wait behind us while we drain the stream
             const hipError_t e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->fail("device fault while waiting for a linearisation: %s", hipGetErrorString(e)); return DCREG_E_DEVICE; }
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != S.seq) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
+            if (!arrived(i)) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
+            break;
         }
     }
     return DCREG_OK;
@@ -624,6 +636,7 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
         const hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { c->fail("hipStreamSynchronize failed: %s", hipGetErrorString(e)); rc = DCREG_E_DEVICE; }
         if (rc == DCREG_OK && S.sync) { const hipError_t e2 = hipGetLastError(); if (e2 != hipSuccess) { c->fail("%s", hipGetErrorString(e2)); rc = DCREG_E_DEVICE; } }
+        if (rc == DCREG_OK) rc = wait_rows(c, S);       // (the stream is drained: the rows are there; this checks and snapshots them)
     } else {
         rc = wait_rows(c, S);
     }
@@ -641,12 +654,12 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
     if (S.fused) {   // add the chunk rows in index order (fixed order: deterministic)
         for (int k = 0; k < 31; ++k) total[k] = 0.0;
         for (uint32_t ch = 0; ch < S.n_chunks; ++ch) {
-            const double *row = S.h_out + (size_t)ch * kSlots;
+            const double *row = S.h_rows.data() + (size_t)ch * kSlots;
             for (int k = 0; k < 31; ++k) total[k] += row[k];
         }
     }
     for (int i = 0; i < S.n_poses; ++i) {
-        const double *o = S.fused ? total : S.h_out + (size_t)i * kSlots;
+        const double *o = S.fused ? total : S.h_rows.data() + (size_t)i * kSlots;
         std::memcpy(outs[i].H_upper, o, 21 * sizeof(double));
         std::memcpy(outs[i].g, o + 21, 6 * sizeof(double));
         outs[i].sum_r2 = o[27]; outs[i].sum_b2 = o[28];

@@ -21,6 +21,7 @@ struct LinSlot {
     // source is staged by the runtime, and beyond 16 KB that cost 14 us per launch)
     unsigned char *h_poses = nullptr, *d_poses = nullptr; size_t poses_cap = 0;      // bytes
     double *h_out = nullptr, *d_out = nullptr; size_t out_cap = 0;   // pinned, device-mapped result rows
+    std::vector<double> h_rows;    // ... and the checked snapshot of them the sums are taken from
     unsigned int *d_tickets = nullptr; size_t tickets_cap = 0;
     bool tickets_dirty = false;    // a launch may have died half-way: clear the tickets before the next one
     std::vector<void *> tmp_dev;   // debug dump buffers of the launch in flight

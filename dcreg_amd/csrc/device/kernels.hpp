@@ -143,8 +143,8 @@ struct DebugDev {
 
 // Single-pose launches finish inside the kernel (no second launch): blocks are grouped in chunks of kChunk consecutive
 // partial rows; the last block to finish in a chunk (ticket counter) sums that chunk's rows in a fixed order and writes
-// the chunk row, stamped with the launch's sequence number, straight into pinned host-coherent memory.  The host spins on
-// the stamps and adds the few chunk rows in index order.  WHO sums is timing dependent, WHAT is summed in which order is not: the
+// the chunk row, with a check word that carries the launch's sequence number (publish_row), straight into pinned host-coherent
+// memory.  The host spins on the rows and adds the few chunk rows in index order.  WHO sums is timing dependent, WHAT is summed in which order is not: the
 // result is deterministic.  Batched launches (many poses, few blocks
 // each) use k_finalize instead: a ticket per block costs more there than the extra launch (measured, profiles/r01_search_ablation.md
 // addendum 5).
@@ -154,7 +154,7 @@ constexpr int kChunk = 64;
 constexpr int kCounterStride = 32;      // uint32 words
 struct FinArgs {
     unsigned int *tickets;         // [n_chunks * kCounterStride], zero between launches (the last arrival resets its ticket)
-    double *out;                   // pinned, device-mapped: [n_chunks][kSlots]; slot 31 = sequence number
+    double *out;                   // pinned, device-mapped: [n_chunks][kSlots]; slot 31 = check word (publish_row)
     unsigned long long seq;
 };
 
@@ -171,6 +171,23 @@ __device__ __forceinline__ void st_system(double *p, double v) {
     __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// A result row in pinned host memory: 31 doubles + a check word, all 32 stored at once by the first 32 lanes of a wave.  The check word
+// = launch number x K + sum of (bit pattern of slot i) x K_i (distinct odd multipliers: equal changes in two slots do not cancel): the
+// host takes the row when the word fits the 31 values it sees next to it - whatever order the link delivered the stores in.  No
+// "data, wait for the acknowledgement, then flag": one PCIe round trip less on every result.  Called by threads 0 .. 31 of the block.
+__host__ __device__ inline unsigned long long row_check_mult(int i) { return 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 3); }
+__device__ __forceinline__ void publish_row(double *orow, double value, unsigned long long seq) {
+    const int l = threadIdx.x;                      // 0 .. 31; lane 31 carries no value
+    const unsigned long long bits = l < 31 ? (unsigned long long)__double_as_longlong(value) : 0ull;
+    unsigned long long c = l < 31 ? bits * row_check_mult(l) : seq * row_check_mult(31);
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)c, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(c >> 32), m);
+        c += ((unsigned long long)hi << 32) | lo;
+    }
+    __hip_atomic_store((unsigned long long *)(orow + l), l < 31 ? bits : c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // sum of `count` (<= kChunk) rows of kSlots doubles, fixed order: lane group g (of G = kLinBlock / 32) adds rows g, g + G, ... then the
 // G group sums are added in order.  All kLinBlock threads call; threads < 31 return the total of their slot.
@@ -293,10 +310,7 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
         if (*s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
             const double t = block_sum_rows(my_rows + (size_t)chunk * kChunk * kSlots, csize, red);
             double *orow = fin.out + (size_t)chunk * kSlots;
-            if (threadIdx.x < 31) { st_system(orow + threadIdx.x, t); wait_stores(); }
-            __syncthreads();
-            if (threadIdx.x == 0)
-                __hip_atomic_store((unsigned long long *)(orow + 31), fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x < 32) publish_row(orow, t, fin.seq);
         }
     }
 }
@@ -456,8 +470,8 @@ static __global__ __launch_bounds__(kLinBlock, 4) void k_lin(const float4 *__res
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused
 // single-pose path (chunk sums, then chunks in index order), so a batched pose is bitwise equal to the same pose
-// linearised alone.  Writes 31 sums to the pinned, host-coherent result row, then publishes the sequence number the
-// host spins on (no stream synchronise on the hot path).  out row layout: [0..30] sums, [31] = sequence number.
+// linearised alone.  Writes 31 sums + check word to the pinned, host-coherent result row the host spins on (no stream synchronise on
+// the hot path).  out row layout: [0..30] sums, [31] = check word (publish_row).
 static __global__ __launch_bounds__(kLinBlock) void k_finalize(const double *__restrict__ partials, uint32_t n_blocks, double *__restrict__ out,
                                                             unsigned long long seq) {
     __shared__ double sm[kLinBlock / 32][kSlots];
@@ -467,10 +481,7 @@ static __global__ __launch_bounds__(kLinBlock) void k_finalize(const double *__r
     for (uint32_t c0 = 0; c0 < n_blocks; c0 += kChunk)
         tot += block_sum_rows(base + (size_t)c0 * kSlots, min((uint32_t)kChunk, n_blocks - c0), sm);
     double *orow = out + (size_t)pose_id * kSlots;
-    if (threadIdx.x < 31) { st_system(orow + threadIdx.x, tot); wait_stores(); }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_store((unsigned long long *)(orow + 31), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < 32) publish_row(orow, tot, seq);
 }
 
 // ---------------------------------------------------------------- plain k-NN kernel (p2p metrics, tests)

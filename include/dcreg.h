@@ -150,7 +150,7 @@ int dcreg_linearize_gate_abort(dcreg_ctx *);
 int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
 /* Neighbour states for batched launches.  A single-pose linearisation reuses what its own previous call found (neighbours +
  * certificates, kept inside the ctx); poses of a batch belong to different trajectories, so each needs a state of its own:
- * reserve n_states of them (40 B per source point each; nothing is cleared - a state counts as empty until its first launch
+ * reserve n_states of them (76 B per source point each; nothing is cleared - a state counts as empty until its first launch
  * has filled it), then name the state of every pose in state_ids (0 <= id < n_states, each id at most once per launch,
  * -1 = search from scratch, keep nothing).  A state is read and updated by the launch, so consecutive launches of one
  * Monte-Carlo trial under the same id skip the searches their certificates cover.  dcreg_reset_warm_state marks one state
