@@ -118,7 +118,7 @@ EXPORTS = [
     "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
-    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn",
+    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
@@ -164,6 +164,7 @@ def load():
     L.dcreg_linearize_batch_end.argtypes = [vp, C.c_int, C.POINTER(LinOut)]
     L.dcreg_reserve_warm_states.argtypes = [vp, C.c_int64]
     L.dcreg_reset_warm_state.argtypes = [vp, C.c_int64]
+    L.dcreg_hint_misalignment.argtypes = [vp, C.c_double]
     L.dcreg_launch_stats_get.argtypes = [vp, C.POINTER(LaunchStats), C.c_int]
     L.dcreg_linearize_gated_begin.argtypes = [vp, C.c_int, C.POINTER(LinParams)]
     L.dcreg_linearize_gate_open.argtypes = [vp, dp, dp]
@@ -424,6 +425,10 @@ class Context:
 
     def reserve_warm_states(self, n_states):
         self._check(self._L.dcreg_reserve_warm_states(self._h, int(n_states)), "dcreg_reserve_warm_states")
+
+    def hint_misalignment(self, metres):
+        """Scheduling hint (never needed for correctness): expected distance of the source points from the map at the next poses."""
+        self._check(self._L.dcreg_hint_misalignment(self._h, float(metres)), "dcreg_hint_misalignment")
 
     def reset_warm_state(self, state_id):
         self._check(self._L.dcreg_reset_warm_state(self._h, int(state_id)), "dcreg_reset_warm_state")

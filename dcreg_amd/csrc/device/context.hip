@@ -191,6 +191,20 @@ static int build_gap_field(dcreg_ctx *c, double radius_hint) {
     return DCREG_OK;
 }
 
+// row occupancy words of the target grid (GridDev::ymask): what the searches of the linearisation sweep instead of walking rings
+static int build_row_words(dcreg_ctx *c) {
+    GridDev &g = c->grid;
+    g.ymask = nullptr;
+    g.nxb = (g.nx + 15) >> 4; g.nyw = (g.ny + 31) >> 5;
+    const int64_t n_words = (int64_t)g.nz * g.nxb * g.nyw;
+    if (ensure(c, c->d_ymask, c->ymask_cap, (size_t)n_words)) return DCREG_E_NOMEM;
+    hipLaunchKernelGGL(k_ymask, dim3(blocks_for(n_words, 256)), dim3(256), 0, c->stream, c->d_cell_start, g.nx, g.ny, g.nz, g.sx, g.nxb, g.nyw, c->d_ymask);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    g.ymask = c->d_ymask;
+    return DCREG_OK;
+}
+
 static GridDst target_dst(dcreg_ctx *c) {
     return GridDst{c->d_tgt_raw, c->n_tgt, &c->d_tgt, &c->tgt_cap, &c->d_cell_start, &c->cell_cap, &c->grid, &c->n_cells};
 }
@@ -234,7 +248,10 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) { c->n_tgt = 0; return rc; }
     rc = build_gap_field(c, radius_hint * (1.0 + c->opt_cert_margin));
     if (rc) { c->n_tgt = 0; return rc; }
+    rc = build_row_words(c);
+    if (rc) { c->n_tgt = 0; return rc; }
     drop_warm(c);            // positions and certificates refer to the old target
+    c->order_valid = false;  // ... and the cost estimate of the query groups to the old map
     c->n_batch_states = 0;
     return DCREG_OK;
 }
@@ -271,6 +288,13 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
+    {   // dispatch groups of the single-pose launches (kernels.hpp k_group_cost): multiples of 16 query blocks, at most kMaxGroups of them
+        const uint32_t nb = blocks_for(n, kLinBlock);
+        const uint32_t gq = 16u;                  // one XCD's run of query blocks (opt_xcd_chunk)
+        c->group_blocks = gq * std::max<uint32_t>(1u, (nb + gq * kMaxGroups - 1) / (gq * kMaxGroups));
+        c->n_groups = std::min<uint32_t>(nb / c->group_blocks, (uint32_t)kMaxGroups);
+        c->order_valid = false;                   // estimated at the pose of the next single-pose linearisation
+    }
     c->aux_valid = false;
     drop_warm(c);
     c->n_batch_states = 0;
@@ -368,6 +392,31 @@ static void gate_publish(dcreg_ctx *c, unsigned long long seq_word, const double
 }
 static void gate_call_off(dcreg_ctx *c) { gate_publish(c, (c->gate_seq << 1) | 1ull, nullptr, nullptr); }
 
+// dispatch order of the query-block groups (kernels.hpp k_group_cost): estimated cost of every group at this pose, heaviest first
+static int estimate_dispatch_order(dcreg_ctx *c, const double *R9, const double *t3, int max_ring) {
+    if (!c->d_group_est) { HIP_TRY(c, hipMalloc((void **)&c->d_group_est, sizeof(float) * kMaxGroups)); }
+    PoseArg P{};
+    for (int k = 0; k < 9; ++k) P.R[k] = R9[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = t3[k];
+    const uint32_t ng = c->n_groups;
+    const uint32_t lead = (blocks_for(c->n_src, kLinBlock) - ng * c->group_blocks) * (uint32_t)kLinBlock;      // points in front of the first group
+    hipLaunchKernelGGL(k_group_cost, dim3(ng), dim3(256), 0, c->stream, c->d_src + lead, (uint32_t)c->n_src - lead, c->grid, P, c->group_blocks * (uint32_t)kLinBlock,
+                       max_ring, c->d_group_est);
+    float est[kMaxGroups];
+    HIP_TRY(c, hipMemcpyAsync(est, c->d_group_est, sizeof(float) * ng, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t order[kMaxGroups];
+    for (uint32_t k = 0; k < (uint32_t)kMaxGroups; ++k) order[k] = k;
+    std::stable_sort(order, order + ng, [&](uint32_t x, uint32_t y) { return est[x] > est[y]; });
+    for (uint32_t k = 0; k < (uint32_t)kMaxGroups; ++k) c->group_order[k] = (uint8_t)order[k];
+    double sum = 0.0, mx = 0.0;
+    for (uint32_t k = 0; k < ng; ++k) { sum += est[k]; mx = std::max(mx, (double)est[k]); }
+    c->order_uneven = mx * ng > 1.3 * sum;                       // some group costs well above the mean
+    std::memcpy(c->est_R, R9, sizeof(c->est_R)); std::memcpy(c->est_t, t3, sizeof(c->est_t));
+    c->order_valid = true;
+    return DCREG_OK;
+}
+
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
 // _gate_abort decide its fate)
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
@@ -418,6 +467,29 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const int64_t n = c->n_src;
     a.state = nullptr; a.state_stride = 0;
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
+    {   // heavy groups first: single-pose launches of at least two groups, once the order has been estimated (a gated launch does not
+        // know its pose yet: it uses the order there is)
+        // (a launch whose blocks are all resident at once - 4 per CU - has no order to speak of)
+        const bool wanted = c->opt_dispatch_order && n_poses == 1 && !state_ids && c->n_groups >= 2 && nbx > 4u * (uint32_t)c->n_cus &&
+                            c->hint_misalign > 0.5 * c->grid.h;
+        if (wanted && !gated) {
+            // the estimate holds for poses near the one it was made at (within a cell for every point)
+            bool stale = !c->order_valid;
+            if (!stale) {
+                double dr = 0.0, dt = 0.0;
+                for (int k = 0; k < 9; ++k) dr += (R9[k] - c->est_R[k]) * (R9[k] - c->est_R[k]);
+                for (int k = 0; k < 3; ++k) dt += (t3[k] - c->est_t[k]) * (t3[k] - c->est_t[k]);
+                stale = std::sqrt(dr) * c->src_radius + std::sqrt(dt) > c->grid.h;
+            }
+            if (stale) {
+                rc = estimate_dispatch_order(c, R9, t3, a.max_ring);
+                if (rc) return rc;
+            }
+        }
+        const bool ordered = wanted && c->order_valid && c->order_uneven;
+        a.group_blocks = std::max<uint32_t>(c->group_blocks, 1u); a.n_groups = ordered ? c->n_groups : 0u;
+        std::memcpy(a.group_order, c->group_order, sizeof(a.group_order));
+    }
     PoseArg one{};
     one.state = kNoIdx; one.fresh = 1;
     const PoseArg *d_poses = nullptr;
@@ -749,6 +821,10 @@ int dcreg_backend_create(dcreg_ctx **out, int device) {
     dcreg_ctx *c = new (std::nothrow) dcreg_ctx();
     if (!c) return DCREG_E_NOMEM;
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->d_scratch, 256) != hipSuccess) {
@@ -771,9 +847,10 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->d_euler) (void)hipFree(c->d_euler);
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
+    if (c->d_group_est) (void)hipFree(c->d_group_est);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -814,6 +891,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "dispatch_order") { c->opt_dispatch_order = v != 0.0; c->order_valid = false; }   // heavy query groups first (kernels.hpp k_group_cost)
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
     else if (k == "warm_start") {
@@ -866,6 +944,11 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
     c->state_batch_stride = stride;
     c->n_batch_states = n_states;
     c->batch_state_valid.assign((size_t)n_states, 0);
+    return DCREG_OK;
+}
+int dcreg_hint_misalignment(dcreg_ctx *c, double metres) {
+    if (!c) return DCREG_E_INVALID;
+    c->hint_misalign = metres >= 0.0 ? metres : 1e300;       // (NaN: no knowledge)
     return DCREG_OK;
 }
 int dcreg_reset_warm_state(dcreg_ctx *c, int64_t state_id) {

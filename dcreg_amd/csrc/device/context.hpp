@@ -122,7 +122,17 @@ struct dcreg_ctx {
     bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
+    uint32_t *d_ymask = nullptr; size_t ymask_cap = 0;
     bool opt_keep_source_order = false;   // experiments only
+    // heavy groups first (kernels.hpp k_group_cost): the dispatch order of the query-block groups, estimated once per cloud pair
+    bool opt_dispatch_order = true;
+    uint8_t group_order[256] = {}; float *d_group_est = nullptr;
+    uint32_t group_blocks = 0, n_groups = 0;
+    int n_cus = 256;                // compute units of the device
+    bool order_valid = false;       // group_order is the estimate for est_R / est_t; order_uneven: its costs differ enough to matter
+    bool order_uneven = false;
+    double est_R[9] = {}, est_t[3] = {};
+    double hint_misalign = 1e300;   // dcreg_hint_misalignment     // source processed in groups of the curve order, the groups far from the body origin first (kernels.hpp kFarGroup)
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     int64_t n_launches = 0, n_poses_launched = 0, n_points_launched = 0;    // dcreg_launch_stats
     double kernel_ms_total = 0.0;

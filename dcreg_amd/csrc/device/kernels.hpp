@@ -99,6 +99,13 @@ __device__ __forceinline__ int gram_entry_of_slot(int slot) {
     return tab[slot];
 }
 
+// the searches of k_lin sweep the occupied rows of their ball (search.hpp knn_shells); -DDCREG_RING_WALK: the ring walk (experiments)
+#if defined(DCREG_RING_WALK)
+constexpr bool kLinSweep = false;
+#else
+constexpr bool kLinSweep = true;
+#endif
+
 // XCD-aware block remap: hardware places block b on XCD b % 8 (as that XCD's (b / 8)-th block).
 //   chunk == 0: every XCD gets ONE contiguous run of query blocks, so spatially adjacent (Hilbert-ordered) queries share
 //               that XCD's L2 - best when the work per query is uniform;
@@ -328,7 +335,15 @@ static __global__ __launch_bounds__(kLinBlock, 4) void k_lin(const float4 *__res
     __shared__ RunList runs[kLinBlock / kWave];
     const int wave = threadIdx.x >> 6;
     const uint32_t pose_id = blockIdx.y;
-    const uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
+    uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
+    if (a.n_groups) {       // heavy groups first (k_group_cost).  The groups cover the END of the block range: the blocks no group covers
+                            // are the first ones - dispatched first, whatever they cost
+        const uint32_t lead = n_blocks_x - a.n_groups * a.group_blocks;
+        if (vb >= lead) {
+            const uint32_t slot = (vb - lead) / a.group_blocks;
+            vb = lead + (uint32_t)a.group_order[slot] * a.group_blocks + (vb - lead) % a.group_blocks;
+        }
+    }
     const uint32_t i = vb * kLinBlock + threadIdx.x;
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
@@ -389,7 +404,7 @@ static __global__ __launch_bounds__(kLinBlock, 4) void k_lin(const float4 *__res
             }
             Set6 s6;
             uint32_t c2;
-            lin_search6(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
+            lin_search6<kLinSweep>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
             if (need) {
                 cert = c2;
 #pragma unroll
@@ -603,6 +618,59 @@ static __global__ void k_gather4(const float4 *__restrict__ in, const uint32_t *
     out[i] = in[order[i]];
 }
 
+// Heavy groups first.  The blocks of a launch are dispatched in index order and the launch ends when its slowest block does: where the
+// expensive queries - far from the surface they belong to (many rows to sweep), or in a dense part of the map (many candidates) - sit
+// at the end of the order, the device idles while they finish.  A single-pose launch with more query blocks than the device holds
+// at once can therefore take them in GROUPS (group_blocks = a multiple of 16 consecutive blocks = one XCD's run, xcd_remap; at most
+// kMaxGroups groups) by decreasing ESTIMATED cost - longest processing time first.  The estimate is made at the pose of the first
+// such launch after dcreg_set_source / dcreg_set_target and again when a launch whose pose is known up front is a cell or more away
+// from it (k_group_cost below samples every group: cells to the nearest occupied one, points in the 3x3x3 block); it is used while
+// the caller's misalignment hint (dcreg_hint_misalignment: the engines pass the RMS residual) is above half a cell - on a settled
+// trajectory every block costs the same and streams its state rows, which goes 10 % faster in index order.  The order schedules and
+// nothing else: partial rows and chunk sums are indexed by query block, so the 31 sums are bitwise the same for every order.
+// Measured (1 M x 1 M corridor, first four iterations of a run): 575 / 423 / 337 / 241 us in index order, 431 / 263 / 234 / 211 us so.
+constexpr int kMaxGroups = 256;     // (LinArgs::group_order holds bytes)
+constexpr int kCostSamples = 4;      // per thread: 1024 samples per group
+static __global__ __launch_bounds__(256) void k_group_cost(const float4 *__restrict__ src, uint32_t n, GridDev g, PoseArg P, uint32_t group_points,
+                                                          int max_ring, float *__restrict__ cost) {
+    __shared__ float sm[256];
+    const uint32_t base = blockIdx.x * group_points;
+    const uint32_t step = max(group_points / (256u * kCostSamples), 1u);
+    float acc = 0.f;
+    for (int k = 0; k < kCostSamples; ++k) {
+        const uint32_t j = ((uint32_t)k * 256u + threadIdx.x) * step;
+        if (j >= group_points || base + j >= n) continue;
+        const float4 p = src[base + j];
+        float qx, qy, qz;
+        body_to_global(P, (double)p.x, (double)p.y, (double)p.z, qx, qy, qz);
+        const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+        const double lim = (double)max_ring + 1.0;
+        float c = 1.f;                                   // transform, tests, row: every query
+        if (!(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim)) {
+            const int cx = clampi((int)floor(fx), 0, g.nx - 1), cy = clampi((int)floor(fy), 0, g.ny - 1), cz = clampi((int)floor(fz), 0, g.nz - 1);
+            const int f = g.gap ? (int)g.gap[((int64_t)cz * g.ny + cy) * g.nx + cx] : 0;
+            uint32_t c27 = 0;
+            const int64_t nxf = (int64_t)g.nx * g.sx;
+            for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+                const int y = cy + dy, z = cz + dz;
+                if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+                const int64_t row = ((int64_t)z * g.ny + y) * nxf;
+                c27 += g.cell_start[row + (int64_t)min(cx + 2, g.nx) * g.sx] - g.cell_start[row + (int64_t)max(cx - 1, 0) * g.sx];
+            }
+            c += (float)c27 * (1.f / 32.f);
+            if (f >= 2) c += f == 255 ? 4.f : 6.f + 1.5f * (float)f;      // the sweep of a ball of f cells and more
+        }
+        acc += c;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost[blockIdx.x] = sm[0];
+}
+
 // cell_start[c] = first sorted position whose key >= c (sorted keys ascending), c = 0 .. n_cells: one thread per CELL and a
 // binary search in the key array.  (Round 1 had one thread per POINT fill the run of empty cells in front of it - a single
 // thread then wrote every cell of a long empty stretch, 0.75 ms on the 1 M corridor; the search is ~20 dependent, cached
@@ -651,6 +719,23 @@ static __global__ void k_gap_dilate(uint8_t *gap, int nx, int ny, int nz, int ri
         }
     }
     if (hit) gap[c] = (uint8_t)ring;
+}
+
+// row occupancy words of the row sweep (GridDev::ymask): one thread per word, 32 rows y of one (z, 16-cell x block)
+static __global__ void k_ymask(const uint32_t *__restrict__ cell_start, int nx, int ny, int nz, int sx, int nxb, int nyw, uint32_t *__restrict__ ymask) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (int64_t)nz * nxb * nyw) return;
+    const int yw = (int)(w % nyw), xb = (int)((w / nyw) % nxb), z = (int)(w / ((int64_t)nyw * nxb));
+    const int xa = xb * 16, xe = min(xa + 16, nx);
+    const int64_t nxf = (int64_t)nx * sx;
+    uint32_t m = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int y = yw * 32 + b;
+        if (y >= ny) break;
+        const int64_t row = ((int64_t)z * ny + y) * nxf;
+        if (cell_start[row + (int64_t)xe * sx] > cell_start[row + (int64_t)xa * sx]) m |= 1u << b;
+    }
+    ymask[w] = m;
 }
 
 // reductions for dcreg_p2p_error: sum sqrt(d2), sum d2 [dist<thr], count  (deterministic two-stage)

@@ -59,6 +59,9 @@ struct GridDev {
     const float4 *pts;            // sorted target; at least 3 readable entries follow the last point (candidate loads come in fours)
     const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
     int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
+    const uint32_t *ymask;        // [nz][nxb][nyw] row occupancy: bit (y & 31) of word ((z * nxb + (x >> 4)) * nyw + (y >> 5)) is set iff
+    int nxb, nyw;                 //   one of the 16 cells (x', y, z), x' >> 4 == x >> 4, holds a point.  The bounded searches of the
+                                  //   linearisation sweep the occupied rows of their ball through these words (knn_shells<.., true>)
 };
 
 struct PoseArg {
@@ -105,6 +108,8 @@ struct LinArgs {
     unsigned long long *search_count;   // test / profiling hook: points searched are counted here (one atomic per searching wave), or null
     uint32_t *state;              // [state][kStateRows][state_stride], or null (nothing is kept)
     uint32_t state_stride;
+    uint32_t group_blocks, n_groups;   // heavy groups first (kernels.hpp k_group_cost): dispatch slot -> group of group_blocks query blocks;
+    uint8_t group_order[256];          //   n_groups = 0: index order.  By value: the entry is fetched with the other launch arguments
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     const double *dR;             // euler: 27 doubles in device memory - dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll),
@@ -315,7 +320,7 @@ DCREG_DEVFN float sqrt_approx(float x) {
 #endif
 }
 
-template <class H>
+template <class H, bool SWEEP>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
 
@@ -379,7 +384,7 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
 // closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
 // the ball covers the search radius.
-template <class H>
+template <class H, bool SWEEP = false>
 DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
                                            int max_ring, H &hp, float infl = 1.f, float cap = __builtin_inff()) {   // max_ring < 0: unbounded
     hp.init(bound_f, infl, cap);
@@ -531,7 +536,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             hp.note_outside(om);
         }
     }
-    knn_shells<H>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+    knn_shells<H, SWEEP>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
 // Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
@@ -548,21 +553,22 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //     per-lane iteration order, empty-space culling per face and centre-out rows visited fewer rows
 //     and was 25 % slower; batching the table loads of four rows, a flattened collect-then-scan walk and a 2x2x2 block occupancy
 //     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
-template <class H>
+template <class H, bool SWEEP>
 DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
+    bool done;
     {   // what ring 1's test would say, before anything is loaded: an aligned query is done after the centre block (its K-th best lies
         // within one cell edge), and when that holds for the whole wave the walk costs nothing - not even the field byte below
         const double safe = g.h * (1.0 - 1e-9);
         const double safe2 = safe * safe * (1.0 - 1e-6);
-        const bool done = max_ring <= 1 || (double)hp.worst_d2() <= safe2 || safe2 >= (double)bound_f;
+        done = max_ring <= 1 || (double)hp.worst_d2() <= safe2 || safe2 >= (double)bound_f;
         if (!wave_any(!done)) return;
     }
     // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
     int k0 = 1;
-    if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
+    if (!SWEEP && g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
         const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
         k0 = max(1, f - 1);
     }
@@ -597,6 +603,80 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
         DCREG_TRACE(kk, dz, dy, 0, (g.cell_start[row + x1] - g.cell_start[row + x0] + 3u) / 4u);
         lookup_scan(row + x0, row + x1);
     };
+    // offsets of the rows a ball of squared radius r2 (in the plane of a face) can reach along an axis on which the query sits at
+    // `fr` inside its cell: a row at offset +o is (o - fr) cells away, one at -o is (o - 1 + fr) cells away (conservative by
+    // 1e-5 relative + 1e-4 of a cell); clipped to +-cap.  The loops below are bounded per lane; the wave runs to the widest.
+    auto reach = [&](float r2, float fr, int cap, int &lo, int &hi) {
+        const float rc = fminf(sqrt_approx(fmaxf(r2, 0.f)) * 1.00001f * inv_hf + 1e-4f, 1.0e6f);
+        lo = -min(cap, (int)floorf(rc + 1.f - fr));
+        hi = min(cap, (int)floorf(rc + fr));
+        if (r2 < 0.f) { lo = 1; hi = 0; }
+    };
+    // ---- row sweep (SWEEP: the searches of the linearisation, whose ball is bounded by the search radius) instead of the ring walk: ring kk costs a table lookup for every (y,z) row the ball reaches in that shell - O(r^2) lookups per ring, nearly
+    // all of them on empty rows - while the points it is after sit in the few rows where the ball touches a surface.  The row
+    // occupancy words name those rows directly: per z layer of the ball one OR over the x blocks the ball spans gives the mask of
+    // occupied rows, and only those are looked up (x-run trimmed to the ball as in face_row) and scanned.  Layers are visited
+    // centre-out, every bound is taken from the K-th best as it stands (pruning by worst_d2() only, like the ring walk: the
+    // certificate's "never looked at => at least worst_d2() away" holds), and the sweep covers the whole ball, so the lane is
+    // finished afterwards.  The 3x3 rows of the centre block were scanned over their three centre cells by phase A: only the parts
+    // left and right of those are scanned here.
+    if constexpr (SWEEP) {
+        const float w0 = hp.worst_d2();
+        if (!done) {
+            const int nxb = g.nxb, nyw = g.nyw, cap = 1 << 24;      // (the bound is finite; offsets stay far inside 32 bits: |cx| <= 6e7)
+            auto sweep_row = [&](int y, int z, float gz) {
+                DCREG_STAT(rows);
+                const float gy = slab(y, cy, fry);
+                const float dyz = (gy * gy + gz * gz) * 0.99999f;
+                const float w = hp.worst_d2();
+                if (dyz > w) return;
+                const float xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
+                const int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);           // sub-cell offsets from cxs
+                const int x0 = max(cxs + dlo, 0), x1 = min(cxs + dhi, nxf - 1) + 1;
+                if (x1 <= x0) return;
+                const int64_t row = ((int64_t)z * ny + y) * nxf;
+                if (abs(y - cy) <= 1 && abs(z - cz) <= 1) {
+                    const int l1 = min(x1, cxs - sx), r0 = max(x0, cxs + 2 * sx);
+                    if (l1 > x0) lookup_scan(row + x0, row + l1);
+                    if (x1 > r0) lookup_scan(row + r0, row + x1);
+                } else {
+                    lookup_scan(row + x0, row + x1);
+                }
+            };
+            int zlo, zhi;
+            reach(w0, frz, cap, zlo, zhi);
+            const int zmax = max(-zlo, zhi);
+            for (int i = 0; i <= 2 * zmax; ++i) {
+                const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
+                const float w = hp.worst_d2();
+                { const float nearer = (float)max(adz - 1, 0) * hf; if (nearer * nearer * 0.99999f > w) break; }   // both layers at this |dz| and beyond are out
+                const int z = cz + dz;
+                if (z < 0 || z >= nz) continue;
+                const float gz = slab(z, cz, frz);
+                const float rem = w - gz * gz * 0.99999f;
+                if (rem < 0.f) continue;
+                int ylo, yhi, xlo, xhi;
+                reach(rem, fry, cap, ylo, yhi);
+                reach(rem, frx, cap, xlo, xhi);
+                const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
+                const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
+                if (y1 < y0 || b1 < b0) continue;
+                for (int yw = y0 >> 5; yw <= (y1 >> 5); ++yw) {
+                    uint32_t m = 0;
+                    const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw + yw;
+                    for (int b = b0; b <= b1; ++b, mw += nyw) { m |= *mw; DCREG_STAT(table_loads); }
+                    const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
+                    m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
+                    while (m) {
+                        const int bit = __builtin_ctz(m);
+                        m &= m - 1;
+                        sweep_row((yw << 5) + bit, z, gz);
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int k = k0; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
@@ -634,15 +714,6 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
             const int free_r = gv[f] == 255 ? g.gap_cap + 1 : gv[f];     // every cell closer (Chebyshev) than free_r to that cell is empty
             if (g.gap && live[f] && need[f] < free_r) { live[f] = false; DCREG_STAT(face_skips); }
         }
-        // offsets of the rows a ball of squared radius r2 (in the plane of a face) can reach along an axis on which the query sits at
-        // `fr` inside its cell: a row at offset +o is (o - fr) cells away, one at -o is (o - 1 + fr) cells away (conservative by
-        // 1e-5 relative + 1e-4 of a cell); clipped to +-cap.  The loops below are bounded per lane; the wave runs to the widest.
-        auto reach = [&](float r2, float fr, int cap, int &lo, int &hi) {
-            const float rc = fminf(sqrt_approx(fmaxf(r2, 0.f)) * 1.00001f * inv_hf + 1e-4f, 1.0e6f);
-            lo = -min(cap, (int)floorf(rc + 1.f - fr));
-            hi = min(cap, (int)floorf(rc + fr));
-            if (r2 < 0.f) { lo = 1; hi = 0; }
-        };
         // ---- z faces: layers z = cz -+ kk, rows y = cy-kk .. cy+kk
         for (int sz = 0; sz < 2; ++sz) {
             const int z = fz_[sz];
@@ -1068,9 +1139,10 @@ struct Set6 {
 // 5th and 6th best distances are equal floats; then - lattices, duplicated points - the 64-bit-key search (distance, original index)
 // is run for this lane and its first five entries are the canonical set.  (A tie between the 6th best and a point outside does not
 // matter: neither belongs to the five, and both are at the distance the certificate uses.)
+template <bool SWEEP>
 DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, float cap, Set6 &out) {
     HeapFast<6> hf;
-    knn_search<HeapFast<6>>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap);
+    knn_search<HeapFast<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap);
     out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
@@ -1079,7 +1151,7 @@ DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, floa
     out.lb7 = fminf(hf.outside_min, fminf(hf.worst_d2(), bound_f));
     if (hf.pos[5] != kNoIdx && hf.d[4] == hf.d[5]) {
         HeapExact<6> he;
-        knn_search<HeapExact<6>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
+        knn_search<HeapExact<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, he);
         out.n_eval += he.n_eval;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { out.pos[j] = he.pos[j]; out.d2[j] = he.dist(j); }
@@ -1133,6 +1205,7 @@ DCREG_DEVFN float warm_bound6(const GridDev &g, const uint32_t (&oldpos)[6], flo
 }
 
 // search of one query inside a linearisation: bound (warm or cold), reach test, 6-NN, certificate
+template <bool SWEEP>
 DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, bool have_q, bool warm, const uint32_t (&oldpos)[6],
                              float qx, float qy, float qz, Set6 &st, uint32_t &cert) {
     float bound = a.radius_sq_f;
@@ -1149,7 +1222,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
     st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;
-    if (reach) search6(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st);
+    if (reach) search6<SWEEP>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st);
     cert = make_cert(st, a);
 }
 

@@ -120,6 +120,7 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
     const bool piped = !reduce;
     int slot = 0;
     bool queued = false;                        // a gated launch waits for its pose
+    (void)dcreg_hint_misalignment(ctx, -1.0);   // nothing known about the start pose (scheduling only: include/dcreg.h)
     for (int it = 0; it < cfg->max_iterations; ++it) {
         const auto t_iter = Clock::now();
         dcreg_lin_out lo;
@@ -153,6 +154,7 @@ int dcreg_icp_run_sharded(dcreg_ctx *ctx, const double R0[9], const double t0[3]
             res->iterations = it + 1; res->converged = 0; res->status = 1;
             break;
         }
+        (void)dcreg_hint_misalignment(ctx, std::sqrt(lo.sum_r2 / (double)lo.n_eff));     // for the launches queued from here on
         StepOut so;
         const int st = host_step(lo, detection, handling, *cfg, R, t, so, piped);
         if (st == 2) { res->iterations = it; res->converged = 0; res->status = 2; break; }
@@ -409,6 +411,7 @@ int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, i
         return DCREG_OK;
     }
     double prev_rmse = std::numeric_limits<double>::max(), prev_fitness = 0.0;   // :2115-2116
+    (void)dcreg_hint_misalignment(ctx, -1.0);   // nothing known about the start pose (scheduling only: include/dcreg.h)
     for (int it = 0; it < cfg->max_iterations; ++it) {
         const auto t_iter = Clock::now();
         pose_matrix();
@@ -419,6 +422,7 @@ int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, i
         if (lo.n_eff < 10) { res->iterations = it; res->converged = 0; res->status = 1; break; }   // :2272-2286 (final_iterations_ = iterCount)
         const double fitness = (double)lo.n_pt / (double)info.n_source;          // :2289
         const double rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);            // :2291
+        (void)dcreg_hint_misalignment(ctx, rmse);
         StepOut so;
         dcreg_unpack_hessian(lo.H_upper, so.H);
         dcreg_analyze_degeneracy(so.H, detection, handling, cfg, &so.an);

@@ -38,6 +38,7 @@ def lib():
         L.emu_index_build.restype = C.c_void_p
         L.emu_index_build.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         L.emu_index_free.argtypes = [C.c_void_p]
+        L.emu_index_set_sweep.argtypes = [C.c_void_p, C.c_int32]
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
@@ -84,6 +85,10 @@ class Index:
         h, dims, nc, gc = C.c_double(), (C.c_int32 * 3)(), C.c_int64(), C.c_int32()
         lib().emu_index_info(self.ptr, C.byref(h), dims, C.byref(nc), C.byref(gc))
         self.cell, self.dims, self.n_cells, self.gap_cap = h.value, tuple(dims), nc.value, gc.value
+
+    def set_sweep(self, on):
+        """The searches of linearize(): True = row sweep (what k_lin runs), False = ring walk (-DDCREG_RING_WALK builds, dcreg_knn)."""
+        lib().emu_index_set_sweep(self.ptr, int(bool(on)))
 
     def __del__(self):
         if getattr(self, "ptr", None):

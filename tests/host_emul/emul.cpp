@@ -19,6 +19,8 @@ struct EmuIndex {
     std::vector<float4> pts;            // sorted by cell, +8 padding
     std::vector<uint32_t> cell_start;
     std::vector<uint8_t> gap;
+    std::vector<uint32_t> ymask;
+    bool sweep = true;
     GridDev g{};
     int64_t n_cells = 0;
     uint32_t occupied = 0;
@@ -135,9 +137,24 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
             g.gap = E->gap.data(); g.gap_cap = rings;
         }
     }
+    {   // row occupancy words, as k_ymask / build_row_words
+        const int nx = g.nx, ny = g.ny, nz = g.nz;
+        g.nxb = (nx + 15) >> 4; g.nyw = (ny + 31) >> 5;
+        E->ymask.assign((size_t)nz * g.nxb * g.nyw, 0u);
+        const int64_t nxf = (int64_t)nx * g.sx;
+        for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int xb = 0; xb < g.nxb; ++xb) {
+            const int64_t row = ((int64_t)z * ny + y) * nxf;
+            const int xa = xb * 16, xe = std::min(xa + 16, nx);
+            if (E->cell_start[(size_t)(row + (int64_t)xe * g.sx)] > E->cell_start[(size_t)(row + (int64_t)xa * g.sx)])
+                E->ymask[((size_t)z * g.nxb + xb) * g.nyw + (y >> 5)] |= 1u << (y & 31);
+        }
+        g.ymask = E->ymask.data();
+    }
     return E;
 }
 void emu_index_free(void *p) { delete (EmuIndex *)p; }
+// the searches of emu_linearize: 1 = row sweep (as k_lin), 0 = ring walk (as -DDCREG_RING_WALK; the two must agree bit for bit)
+void emu_index_set_sweep(void *p, int32_t on) { ((EmuIndex *)p)->sweep = on != 0; }
 void emu_index_info(void *p, double *h, int32_t dims[3], int64_t *n_cells, int32_t *gap_cap) {
     EmuIndex *E = (EmuIndex *)p;
     *h = E->g.h; dims[0] = E->g.nx; dims[1] = E->g.ny; dims[2] = E->g.nz; *n_cells = E->n_cells; *gap_cap = E->g.gap_cap;
@@ -257,7 +274,8 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         if (need) {
             if (old && warm) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             uint32_t c2;
-            lin_search6(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
+            if (E->sweep) lin_search6<true>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
+            else lin_search6<false>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
             cert = c2;
             for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
             if (state) for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = s6.pos[j];

@@ -655,6 +655,42 @@ def test_certificates_only_spare_searches(cyl):
     assert a[8]["points_searched"] < 0.75 * a[8]["points"] and a[9]["points_searched"] < 0.75 * a[9]["points"]      # (25 iterations from 0.4 m / 3 deg off)
 
 
+def test_dispatch_order_only_schedules():
+    """Launches with more query blocks than the device holds at once hand them out heaviest group first (kernels.hpp k_group_cost: an
+    estimate per cloud pair at the pose of the first launch, used while the misalignment hint says it matters).  Scheduling only: with
+    the order on, off, estimated at another pose, with hints that switch it on and off between launches, every launch and a pipelined
+    ICP run give bitwise the same sums."""
+    tgt = h.scene_corridor(400_000, seed=21, length=80.0)
+    rng = np.random.default_rng(22)
+    src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
+    T0 = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(1.0))        # 0.7 m at the ends
+    walk = [T0, T0 @ h.pose6d_matrix(0.01, 0.0, 0.0, 0.0, 0.0, 1e-4), np.eye(4), T0]
+    cfg = api.default_config(search_radius=1.0, max_iterations=12, CONVERGENCE_THRESH_ROT=0.0, CONVERGENCE_THRESH_TRANS=0.0)
+    prm = api.default_lin_params(1.0, 1)
+    got = {}
+    for mode in ("off", "on", "other_pose", "hints"):
+        c = api.Context(0)
+        c.set_option("dispatch_order", 0 if mode == "off" else 1)
+        c.set_target(tgt, 1.0); c.set_source(src)
+        if mode == "other_pose":                                    # the estimate is made here, 3 m off: a poor order, still only an order
+            Tx = h.pose6d_matrix(3.0, 0.5, 0.0, 0.0, 0.0, h.deg2rad(-2.0))
+            c.linearize(Tx[:3, :3], Tx[:3, 3], prm)
+        lin = []
+        for k, T in enumerate(walk):
+            if mode == "hints":
+                c.hint_misalignment([10.0, 0.0, 1e-3, float("nan")][k])
+            lin.append(c.linearize(T[:3, :3], T[:3, 3], prm))
+        res, logs = c.icp_run(T0, "Ours", cfg)
+        got[mode] = (lin, np.array(res.R[:]), np.array(res.t[:]), [np.array(L.H_upper[:]) for L in logs])
+        c.close()
+    ref = got["off"]
+    for mode in ("on", "other_pose", "hints"):
+        x = got[mode]
+        for a, b in zip(x[0], ref[0]):
+            assert a["n_eff"] == b["n_eff"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"]), mode
+        assert np.array_equal(x[1], ref[1]) and np.array_equal(x[2], ref[2]) and all(np.array_equal(p, q) for p, q in zip(x[3], ref[3])), mode
+
+
 def test_a_wait_that_runs_out_of_patience_is_harmless(cyl):
     """"wait_seconds": when a result has not arrived after that long, the waiting host calls off the launch queued behind it (a gate
     that would otherwise wait for this very thread), drains the stream to surface a device fault, and carries on when the result is

@@ -87,6 +87,46 @@ def test_synthetic_scenes_and_pose_sequences(name):
     assert a["n_eff"] == b["n_eff"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
 
 
+def test_row_sweep_and_ring_walk_agree_bit_for_bit():
+    """k_lin's searches sweep the occupied rows of their ball (search.hpp knn_shells<.., true>); dcreg_knn and -DDCREG_RING_WALK builds
+    walk rings.  Same neighbours, same certificates (the whole state, bit for bit), same sums - aligned, many cells off, far outside the
+    grid, with a warm bound and without, on a lattice with duplicated points (exact ties: the 64-bit-key search) and far from the origin."""
+    rng = np.random.default_rng(5)
+    g = np.arange(0, 10, dtype=np.float32) * 0.3
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    cases = {name: make() for name, make in SCENES.items()}
+    cases["lattice_dups"] = (np.concatenate([lattice, lattice[::7]]), 0.7)
+    cases["far_corridor"] = ((h.scene_corridor(8000, seed=6, length=20.0).astype(np.float64) + np.array([3.0e4, -2.0e4, 500.0])).astype(np.float32), 0.8)
+    poses = [h.pose6d_matrix(0.4, -0.5, 0.3, h.deg2rad(1.0), h.deg2rad(-2.0), h.deg2rad(3.0)),
+             h.pose6d_matrix(0.35, -0.45, 0.3, h.deg2rad(1.0), h.deg2rad(-1.8), h.deg2rad(2.5)),
+             h.pose6d_matrix(0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+             h.pose6d_matrix(0.0, 0.0, 1e-4, 0.0, 0.0, 0.0),
+             h.pose6d_matrix(300.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+             h.pose6d_matrix(-0.3, 0.2, 0.6, h.deg2rad(-1.0), h.deg2rad(0.5), h.deg2rad(-2.0))]
+    swept = 0
+    for name, (tgt, radius) in cases.items():
+        src = (tgt[::2] + rng.normal(0, 0.01, tgt[::2].shape)).astype(np.float32)
+        c = src.astype(np.float64).mean(axis=0)
+        shift = np.eye(4); shift[:3, 3] = c
+        for cell in (0.0, radius / 7.3):                            # the density-adapted cell, and one that makes every ball span many cells
+            idx = emul.Index(tgt, radius, cell=cell)
+            out = {}
+            for sweep in (True, False):
+                idx.set_sweep(sweep)
+                S = emul.Source(src)
+                out[sweep] = []
+                for T in poses:
+                    T = shift @ T @ np.linalg.inv(shift)
+                    r = emul.linearize(idx, S, T[:3, :3], T[:3, 3], radius=radius, wd=1, stats=True)
+                    out[sweep].append((r, S.state.copy()))
+            for (a, sa), (b, sb) in zip(out[True], out[False]):
+                assert a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and a["searched"] == b["searched"], name
+                assert np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"]) and a["sum_r2"] == b["sum_r2"], name
+                assert np.array_equal(sa, sb), name
+                swept += int((b["stats"][:, 1] > 1).sum())           # queries whose ring walk went beyond the centre block
+    assert swept > 10_000
+
+
 def test_certificate_torture():
     """The certificate must never outlive its set.  Histories that try to break it: a long drift in steps of every size (the charged
     moves accumulate; the float store of the query position jitters), steps that undo each other, a lattice with duplicated points (no
@@ -202,6 +242,7 @@ def test_ring_walk_cost_counters():
     rng = np.random.default_rng(1100)
     src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
     idx, S = emul.Index(tgt, 1.0), emul.Source(src)
+    idx.set_sweep(False)                                                 # the ring walk (dcreg_knn; k_lin sweeps rows instead)
     emul.linearize(idx, S, np.eye(3), np.zeros(3), wd=1)
     T = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(3.0))   # 0.8 m at the ends of 30 m
     out = emul.linearize(idx, S, T[:3, :3], T[:3, 3], wd=1, stats=True, trace_cap=512)
