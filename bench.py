@@ -354,7 +354,10 @@ def profile_record(workload):
     note in MI355X_MICROARCH.md + WRITE_SIZE, separate passes) and wave-level VALU instructions."""
     import glob
     rec = {}
+    import re
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % workload))):
+        if not re.fullmatch(r"r\d+_%s\.json" % re.escape(workload), os.path.basename(f)):
+            continue                                  # (e.g. rNN_steady_<workload>.json: the settled launches only, another command)
         try:
             j = json.load(open(f))
         except Exception:

@@ -175,19 +175,20 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
 // empty-space distance field of the target grid (queries far from any point skip the rings they know are empty)
 static int build_gap_field(dcreg_ctx *c, double radius_hint) {
     GridDev &g = c->grid;
-    g.gap = nullptr; g.gap_cap = 0;
+    g.gap = nullptr; g.gap_cap = 0; g.owner = nullptr;
     if (!c->opt_gap_field) return DCREG_OK;
     const int64_t n_cells = c->n_cells;
     int rings = 1;                                            // rings that a search up to the radius can need
     while (rings < 12 && (double)rings * g.h < (radius_hint > 0.0 ? radius_hint : 4.0 * g.h)) ++rings;
     if (rings < 2) return DCREG_OK;                           // one ring covers the radius: nothing to skip
-    if (ensure(c, c->d_gap, c->gap_cap, (size_t)n_cells)) return DCREG_E_NOMEM;
-    hipLaunchKernelGGL(k_gap_init, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_cell_start, n_cells, g.sx, c->d_gap);
+    if (ensure(c, c->d_gap, c->gap_cap, (size_t)n_cells) || ensure(c, c->d_owner, c->owner_cap, (size_t)n_cells)) return DCREG_E_NOMEM;
+    hipLaunchKernelGGL(k_gap_init, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_cell_start, n_cells, g.sx, c->d_gap, c->d_owner);
     for (int r = 1; r <= rings; ++r)
-        hipLaunchKernelGGL(k_gap_dilate, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_gap, g.nx, g.ny, g.nz, r);
+        hipLaunchKernelGGL(k_gap_dilate, dim3(blocks_for(n_cells, 256)), dim3(256), 0, c->stream, c->d_gap, c->d_owner, g.nx, g.ny, g.nz, r);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     g.gap = c->d_gap; g.gap_cap = rings;
+    g.owner = c->opt_far_bound ? c->d_owner : nullptr;
     return DCREG_OK;
 }
 
@@ -850,7 +851,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->d_group_est) (void)hipFree(c->d_group_est);
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -891,6 +892,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "far_bound") c->opt_far_bound = v != 0.0;       // next dcreg_set_target: start bound of far queries from the nearest occupied cell
     else if (k == "dispatch_order") { c->opt_dispatch_order = v != 0.0; c->order_valid = false; }   // heavy query groups first (kernels.hpp k_group_cost)
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target

@@ -122,6 +122,8 @@ struct dcreg_ctx {
     bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
+    bool opt_far_bound = true;     // far queries with a loose bound start from the points around the nearest occupied cell (search.hpp lin_search6)
+    uint32_t *d_owner = nullptr; size_t owner_cap = 0;
     uint32_t *d_ymask = nullptr; size_t ymask_cap = 0;
     bool opt_keep_source_order = false;   // experiments only
     // heavy groups first (kernels.hpp k_group_cost): the dispatch order of the query-block groups, estimated once per cloud pair

@@ -694,31 +694,43 @@ static __global__ void k_cell_start(const uint32_t *__restrict__ keys, int64_t n
 
 // empty-space distance field of the target grid: gap[c] = 0 on occupied cells, then one dilation pass per ring.
 // In place: a pass only turns 255 into `ring`, and only looks for neighbours equal to ring - 1.
-static __global__ void k_gap_init(const uint32_t *__restrict__ cell_start, int64_t n_cells, int sx, uint8_t *__restrict__ gap) {
+static __global__ void k_gap_init(const uint32_t *__restrict__ cell_start, int64_t n_cells, int sx, uint8_t *__restrict__ gap, uint32_t *__restrict__ owner) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // cell; its sx sub-cells are consecutive table entries
-    if (c < n_cells) gap[c] = cell_start[(c + 1) * sx] > cell_start[c * sx] ? 0 : 255;
+    if (c < n_cells) {
+        const bool occ = cell_start[(c + 1) * sx] > cell_start[c * sx];
+        gap[c] = occ ? 0 : 255;
+        owner[c] = occ ? (uint32_t)c : kNoIdx;
+    }
 }
-static __global__ void k_gap_dilate(uint8_t *gap, int nx, int ny, int nz, int ring) {
+// (a cell of ring r takes, of the owners of its neighbours of ring r - 1, the one nearest to itself - vector propagation, so the owner
+// stays near the foot of the perpendicular instead of drifting along the diagonal; rings r - 1 are final when ring r is written, and
+// a launch only writes cells that are still 255: no cell is read and written in the same launch with a value that matters)
+static __global__ void k_gap_dilate(uint8_t *gap, uint32_t *owner, int nx, int ny, int nz, int ring) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_cells = (int64_t)nx * ny * nz;
     if (c >= n_cells || gap[c] != 255) return;
     const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((int64_t)nx * ny));
     const uint8_t want = (uint8_t)(ring - 1);
-    bool hit = false;
-    for (int dz = -1; dz <= 1 && !hit; ++dz) {
+    uint32_t own = kNoIdx;
+    int64_t best = INT64_MAX;
+    for (int dz = -1; dz <= 1; ++dz) {
         const int zz = z + dz;
         if (zz < 0 || zz >= nz) continue;
-        for (int dy = -1; dy <= 1 && !hit; ++dy) {
+        for (int dy = -1; dy <= 1; ++dy) {
             const int yy = y + dy;
             if (yy < 0 || yy >= ny) continue;
             const int64_t row = ((int64_t)zz * ny + yy) * nx;
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = x + dx;
-                if (xx >= 0 && xx < nx && gap[row + xx] == want) { hit = true; break; }
+                if (xx < 0 || xx >= nx || gap[row + xx] != want) continue;
+                const uint32_t o = owner[row + xx];
+                const int64_t ox = o % (uint32_t)nx, oy = (o / (uint32_t)nx) % (uint32_t)ny, oz = o / ((uint32_t)nx * (uint32_t)ny);
+                const int64_t d = (ox - x) * (ox - x) + (oy - y) * (oy - y) + (oz - z) * (oz - z);
+                if (d < best) { best = d; own = o; }
             }
         }
     }
-    if (hit) gap[c] = (uint8_t)ring;
+    if (own != kNoIdx) { gap[c] = (uint8_t)ring; owner[c] = own; }
 }
 
 // row occupancy words of the row sweep (GridDev::ymask): one thread per word, 32 rows y of one (z, 16-cell x block)

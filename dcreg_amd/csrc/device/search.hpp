@@ -59,6 +59,8 @@ struct GridDev {
     const float4 *pts;            // sorted target; at least 3 readable entries follow the last point (candidate loads come in fours)
     const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
     int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
+    const uint32_t *owner;        // [nx*ny*nz] with the field: an occupied cell at that distance (kNoIdx beyond gap_cap); null = not built.
+                                  //   Real points near a far query: the start bound of its search (lin_search6)
     const uint32_t *ymask;        // [nz][nxb][nyw] row occupancy: bit (y & 31) of word ((z * nxb + (x >> 4)) * nyw + (y >> 5)) is set iff
     int nxb, nyw;                 //   one of the 16 cells (x', y, z), x' >> 4 == x >> 4, holds a point.  The bounded searches of the
                                   //   linearisation sweep the occupied rows of their ball through these words (knn_shells<.., true>)
@@ -1213,12 +1215,41 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
     // a search whose ball is small (the query sits among its neighbours: the regime in which certificates get used) looks a little
     // further than it must - bound and pruning distance inflated alike (HeapFast::worst_d2), so that what lies beyond is a useful
     // lower bound for the 7th neighbour; a search over many cells (a query far from the surface it belongs to) is expensive enough
-    const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
-    bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)a.max_ring + 1.0;
     // a query farther than max_ring cells from the grid has no neighbour inside the search bound
     const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
+    if (g.owner) {
+        // A query in empty space whose bound is loose (nothing known, or neighbours of a pose far from this one): the ball of that
+        // bound cuts a wide cap out of the surface it faces - candidates ~ bound - d^2, hundreds where six are wanted.  The field
+        // names an occupied cell near the foot of the perpendicular; the sixth nearest of the points around it (the x-run of that
+        // cell and its two x neighbours, at most 48 points) is a distance six REAL points lie within, i.e. a valid bound, and a
+        // far tighter one.  Measured on the first iteration of a C4 run: profiles/r03_ablation.md.
+        bool far = false;
+        uint32_t oc = kNoIdx;
+        if (reach && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz) {
+            const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
+            const int f = (int)g.gap[cell];
+            const float loose = ((float)f + 1.5f) * (float)g.h;
+            if (f >= 2 && f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
+        }
+        if (wave_any(far)) {
+            HeapFast<6> hb;
+            hb.init(bound);
+            uint32_t s_ = 0, e_ = 0;
+            if (far) {
+                const uint32_t ox = oc % (uint32_t)g.nx;
+                const uint32_t row = (oc - ox) * (uint32_t)g.sx;                      // first table entry of the cell's (y,z) row
+                s_ = g.cell_start[row + (ox > 0u ? ox - 1u : 0u) * (uint32_t)g.sx];
+                e_ = g.cell_start[row + min(ox + 2u, (uint32_t)g.nx) * (uint32_t)g.sx];
+                e_ = min(e_, s_ + 48u);
+            }
+            scan_run<HeapFast<6>>(g, s_, e_, qx, qy, qz, hb);
+            if (far && hb.full()) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(hb.d[5]) + 1u), 1.17549435e-38f));   // inclusive, as warm_bound6
+        }
+    }
+    const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
+    bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
     st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;

@@ -19,6 +19,7 @@ struct EmuIndex {
     std::vector<float4> pts;            // sorted by cell, +8 padding
     std::vector<uint32_t> cell_start;
     std::vector<uint8_t> gap;
+    std::vector<uint32_t> owner;
     std::vector<uint32_t> ymask;
     bool sweep = true;
     GridDev g{};
@@ -111,30 +112,37 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
     GridDev &g = E->g;
     g.cell_start = E->cell_start.data();
     g.pts = E->pts.data();
-    g.gap = nullptr; g.gap_cap = 0;
+    g.gap = nullptr; g.gap_cap = 0; g.owner = nullptr;
     if (gap_field) {           // empty-space field, as build_gap_field / k_gap_dilate
         int rings = 1;
         while (rings < 12 && (double)rings * g.h < (radius_hint > 0.0 ? radius_hint : 4.0 * g.h)) ++rings;
         if (rings >= 2) {
             const int nx = g.nx, ny = g.ny, nz = g.nz;
             E->gap.assign((size_t)E->n_cells, 255);
-            for (int64_t c = 0; c < E->n_cells; ++c) if (E->cell_start[(size_t)(c + 1) * g.sx] > E->cell_start[(size_t)c * g.sx]) E->gap[(size_t)c] = 0;
+            E->owner.assign((size_t)E->n_cells, kNoIdx);
+            for (int64_t c = 0; c < E->n_cells; ++c) if (E->cell_start[(size_t)(c + 1) * g.sx] > E->cell_start[(size_t)c * g.sx]) { E->gap[(size_t)c] = 0; E->owner[(size_t)c] = (uint32_t)c; }
             for (int r = 1; r <= rings; ++r) {
                 std::vector<uint8_t> nxt = E->gap;
                 for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
                     const int64_t c = ((int64_t)z * ny + y) * nx + x;
                     if (E->gap[(size_t)c] != 255) continue;
                     bool hit = false;
-                    for (int dz = -1; dz <= 1 && !hit; ++dz) for (int dy = -1; dy <= 1 && !hit; ++dy) for (int dx = -1; dx <= 1 && !hit; ++dx) {
+                    int64_t best = INT64_MAX;
+                    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
                         const int xx = x + dx, yy = y + dy, zz = z + dz;
                         if (xx < 0 || yy < 0 || zz < 0 || xx >= nx || yy >= ny || zz >= nz) continue;
-                        if (E->gap[(size_t)(((int64_t)zz * ny + yy) * nx + xx)] == (uint8_t)(r - 1)) hit = true;
+                        const size_t nb = (size_t)(((int64_t)zz * ny + yy) * nx + xx);
+                        if (E->gap[nb] != (uint8_t)(r - 1)) continue;
+                        const uint32_t o = E->owner[nb];              // (as k_gap_dilate: the nearest of the neighbours' owners)
+                        const int64_t ox = o % (uint32_t)nx, oy = (o / (uint32_t)nx) % (uint32_t)ny, oz = o / ((uint32_t)nx * (uint32_t)ny);
+                        const int64_t d = (ox - x) * (ox - x) + (oy - y) * (oy - y) + (oz - z) * (oz - z);
+                        if (d < best) { best = d; E->owner[(size_t)c] = o; hit = true; }
                     }
                     if (hit) nxt[(size_t)c] = (uint8_t)r;
                 }
                 E->gap.swap(nxt);
             }
-            g.gap = E->gap.data(); g.gap_cap = rings;
+            g.gap = E->gap.data(); g.gap_cap = rings; g.owner = E->owner.data();
         }
     }
     {   // row occupancy words, as k_ymask / build_row_words
