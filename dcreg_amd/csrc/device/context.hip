@@ -447,7 +447,9 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
     const bool fused = (n_poses == 1);
     const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
-    const size_t n_rows = fused ? (size_t)n_chunks : (size_t)n_poses;      // result rows the host waits for
+    // a launch of one chunk's worth of blocks: the blocks publish their rows themselves and the host adds them (kernels.hpp FinArgs)
+    const bool direct = fused && nbx <= (uint32_t)kChunk && c->opt_direct_rows;
+    const size_t n_rows = direct ? (size_t)nbx : (fused ? (size_t)n_chunks : (size_t)n_poses);      // result rows the host waits for
     if (fused) {   // tickets: zero when (re)allocated, afterwards every completed launch leaves them zero
         const size_t had = S.tickets_cap;
         if (ensure(c, S.d_tickets, S.tickets_cap, (size_t)n_chunks * kCounterStride)) return DCREG_E_NOMEM;
@@ -586,7 +588,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (oom) { free_tmp(S); drop_warm(c); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
-    FinArgs fin{S.d_tickets, S.d_out, seq};
+    FinArgs fin{S.d_tickets, S.d_out, seq, direct ? 1u : 0u};
     if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
     // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
     const bool timed = slot == 0 && c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
@@ -649,7 +651,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     }
     c->n_launches += 1; c->n_poses_launched += n_poses; c->n_points_launched += (int64_t)n_poses * n;
     if (uses_state) c->state_valid = true;          // once this launch has run, the state holds a search of the current clouds
-    S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.timed = timed;
+    S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
     if (gated) {
         c->gate_slot = slot;
@@ -724,7 +726,19 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
         c->kernel_ms_total += ms; c->kernel_launches += 1;
     }
     double total[kSlots];
-    if (S.fused) {   // add the chunk rows in index order (fixed order: deterministic)
+    if (S.direct) {  // the rows of the blocks of ONE chunk, added exactly as block_sum_rows adds them on the device (so a pose gives
+                     // bitwise the same sums alone and in a batch): lane group g takes rows g, g + G, ..., then the G sums in order
+        constexpr int G = kLinBlock / 32;
+        for (int k = 0; k < 31; ++k) {
+            double tot = 0.0;
+            for (int g = 0; g < G; ++g) {
+                double t = 0.0;
+                for (size_t r = (size_t)g; r < S.n_rows; r += G) t += S.h_rows[r * kSlots + k];
+                tot += t;
+            }
+            total[k] = 0.0 + tot;                            // (the chunk total enters a sum that starts at zero, as everywhere)
+        }
+    } else if (S.fused) {   // add the chunk rows in index order (fixed order: deterministic)
         for (int k = 0; k < 31; ++k) total[k] = 0.0;
         for (uint32_t ch = 0; ch < S.n_chunks; ++ch) {
             const double *row = S.h_rows.data() + (size_t)ch * kSlots;
@@ -892,6 +906,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "spin") c->opt_spin = v != 0.0;
+    else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host
     else if (k == "far_bound") c->opt_far_bound = v != 0.0;       // next dcreg_set_target: start bound of far queries from the nearest occupied cell
     else if (k == "dispatch_order") { c->opt_dispatch_order = v != 0.0; c->order_valid = false; }   // heavy query groups first (kernels.hpp k_group_cost)
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort

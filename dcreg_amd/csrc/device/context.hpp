@@ -28,6 +28,7 @@ struct LinSlot {
     bool pending = false, fused = false, timed = false, sync = false;
     int n_poses = 0;
     uint32_t n_chunks = 0;
+    bool direct = false;           // the rows are block rows of one chunk (kernels.hpp FinArgs::direct)
     size_t n_rows = 0;
     unsigned long long seq = 0;
 };
@@ -122,6 +123,7 @@ struct dcreg_ctx {
     bool opt_fast_plane = true;    // plane_fit_qr_fast (search.hpp) instead of the Eigen-shaped plane_fit_qr
     bool opt_gap_field = true;     // build the empty-space distance field of the target grid
     uint8_t *d_gap = nullptr; size_t gap_cap = 0;
+    bool opt_direct_rows = true;   // single-pose launches of at most kChunk blocks publish block rows; the host adds them
     bool opt_far_bound = true;     // far queries with a loose bound start from the points around the nearest occupied cell (search.hpp lin_search6)
     uint32_t *d_owner = nullptr; size_t owner_cap = 0;
     uint32_t *d_ymask = nullptr; size_t ymask_cap = 0;

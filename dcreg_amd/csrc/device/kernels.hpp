@@ -163,6 +163,8 @@ struct FinArgs {
     unsigned int *tickets;         // [n_chunks * kCounterStride], zero between launches (the last arrival resets its ticket)
     double *out;                   // pinned, device-mapped: [n_chunks][kSlots]; slot 31 = check word (publish_row)
     unsigned long long seq;
+    unsigned int direct;           // 1: a launch of at most kChunk blocks - every block publishes its own row to out[block], the host adds
+                                   //    them in block_sum_rows' order (context.hip linearize_end): no ticket, no cross-XCD read of the rows
 };
 
 // Cross-block traffic of the tree uses agent-scope (sc1, write-through / L2-coherent) relaxed atomics plus an explicit
@@ -297,14 +299,16 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
 #pragma unroll
             for (int w = 0; w < kLinBlock / 64; ++w) t += cnt[w][threadIdx.x - 29];
         }
-        if (FUSED) {
+        if (FUSED && fin.direct) {
+            publish_row(fin.out + (size_t)vb * kSlots, t, fin.seq);
+        } else if (FUSED) {
             st_agent(my_rows + (size_t)vb * kSlots + threadIdx.x, t);
             wait_stores();                                 // the row is at the coherence point before the ticket is taken
         } else {
             my_rows[(size_t)vb * kSlots + threadIdx.x] = t;
         }
     }
-    if (FUSED) {
+    if (FUSED && !fin.direct) {
         const uint32_t chunk = vb / kChunk;
         const uint32_t csize = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
         __syncthreads();
