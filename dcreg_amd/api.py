@@ -118,7 +118,7 @@ EXPORTS = [
     "dcreg_backend_create", "dcreg_backend_destroy", "dcreg_last_error", "dcreg_set_stream", "dcreg_set_option",
     "dcreg_set_target", "dcreg_set_target_device", "dcreg_set_source", "dcreg_set_source_device",
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
-    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn",
+    "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn", "dcreg_kdtree_build", "dcreg_kdtree_info", "dcreg_knn_timed",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
     "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
@@ -171,6 +171,9 @@ def load():
     L.dcreg_linearize_gate_abort.argtypes = [vp]
     L.dcreg_linearize_debug.argtypes = [vp, dp, dp, C.POINTER(LinParams), C.POINTER(LinOut), C.POINTER(LinDebug)]
     L.dcreg_knn.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int, C.c_double, ip, fp]
+    L.dcreg_kdtree_build.argtypes = [vp, C.c_int]
+    L.dcreg_kdtree_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
+    L.dcreg_knn_timed.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, ip, fp, dp]
     L.dcreg_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
     L.dcreg_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     L.dcreg_default_config.restype = None
@@ -482,6 +485,24 @@ class Context:
         self._check(self._L.dcreg_knn(self._h, q.ctypes.data_as(C.POINTER(C.c_float)), q.shape[0], 3, k, float(max_radius),
                                       idx.ctypes.data_as(C.POINTER(C.c_int32)), d2.ctypes.data_as(C.POINTER(C.c_float))), "dcreg_knn")
         return idx, d2
+
+    def kdtree_build(self, leaf_size=16):
+        """kd-tree comparator over the current target (dcreg_debug.h); returns (depth, leaf_size, host build ms)"""
+        self._check(self._L.dcreg_kdtree_build(self._h, int(leaf_size)), "dcreg_kdtree_build")
+        d, l, ms = C.c_int32(), C.c_int32(), C.c_double()
+        self._check(self._L.dcreg_kdtree_info(self._h, C.byref(d), C.byref(l), C.byref(ms)), "dcreg_kdtree_info")
+        return d.value, l.value, ms.value
+
+    def knn_timed(self, q, k=5, max_radius=0.0, index="grid", repeats=10):
+        """exact k-NN on the grid or on the kd-tree comparator -> (idx, d2, kernel ms per launch)"""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)
+        idx = np.empty((q.shape[0], k), np.int32)
+        d2 = np.empty((q.shape[0], k), np.float32)
+        ms = C.c_double()
+        self._check(self._L.dcreg_knn_timed(self._h, q.ctypes.data_as(C.POINTER(C.c_float)), q.shape[0], 3, k, float(max_radius),
+                                            {"grid": 0, "kdtree": 1, "grid_sweep": 2}[index], int(repeats), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            d2.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ms)), "dcreg_knn_timed")
+        return idx, d2, ms.value
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()

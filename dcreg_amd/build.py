@@ -18,6 +18,7 @@ RUNNER = os.path.join(BINDIR, "icp_test_runner")
 SOURCES = [
     "device/context.hip",
     "device/metrics.hip",
+    "device/kdtree.hip",
     "device/exchange.hip",
     "host/solver.cpp",
     "host/engine.cpp",

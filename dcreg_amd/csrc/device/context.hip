@@ -784,7 +784,7 @@ int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *
 
 // k-NN of arbitrary queries (host pointer) or of the transformed source cloud (q == nullptr)
 int launch_knn(dcreg_ctx *c, const GridDev &grid, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
-               int32_t *d_idx, float *d_d2) {
+               int32_t *d_idx, float *d_d2, bool sweep) {
     float bound = INFINITY;
     int max_ring;
     if (max_radius > 0.0 && std::isfinite(max_radius)) {
@@ -800,6 +800,12 @@ int launch_knn(dcreg_ctx *c, const GridDev &grid, const float4 *d_q, int64_t n, 
     }
     PoseArg P{};
     if (pose) P = *pose;
+    if (sweep) {       // the linearisation's way of covering what lies beyond the 27-cell block, in the plain kernel (k = 5, bounded)
+        if (k != 5 || max_ring < 0 || !grid.ymask) { c->fail("the row sweep needs k = 5, a radius and the target grid"); return DCREG_E_INVALID; }
+        hipLaunchKernelGGL((k_knn<5, true>), dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
+        HIP_TRY(c, hipGetLastError());
+        return DCREG_OK;
+    }
     if (k == 1)
         hipLaunchKernelGGL(k_knn<1>, dim3(blocks_for(n, kBlock)), dim3(kBlock), 0, c->stream, d_q, (uint32_t)n, grid, bound, max_ring, P, pose ? 1 : 0, d_idx, d_d2);
     else
@@ -863,6 +869,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     if (c->d_group_est) (void)hipFree(c->d_group_est);
+    kdtree_free(c->kd); c->kd = nullptr;
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
                     c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner};

@@ -133,6 +133,7 @@ struct dcreg_ctx {
     uint8_t group_order[256] = {}; float *d_group_est = nullptr;
     uint32_t group_blocks = 0, n_groups = 0;
     int n_cus = 256;                // compute units of the device
+    void *kd = nullptr;             // kd-tree comparator (kdtree.hip), built on request
     bool order_valid = false;       // group_order is the estimate for est_R / est_t; order_uneven: its costs differ enough to matter
     bool order_uneven = false;
     double est_R[9] = {}, est_t[3] = {};
@@ -148,6 +149,7 @@ struct dcreg_ctx {
 namespace dcreg {
 int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
                      dcreg_lin_out *outs, dcreg_lin_debug *dbg_host);
+void kdtree_free(void *kd);      // kdtree.hip (the comparator index of dcreg_debug.h)
 int launch_knn(dcreg_ctx *c, const GridDev &grid, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
-               int32_t *d_idx, float *d_d2);
+               int32_t *d_idx, float *d_d2, bool sweep = false);
 }  // namespace dcreg

@@ -504,7 +504,8 @@ static __global__ __launch_bounds__(kLinBlock) void k_finalize(const double *__r
 }
 
 // ---------------------------------------------------------------- plain k-NN kernel (p2p metrics, tests)
-template <int K>
+// SWEEP: bounded searches only (the row sweep covers the ball of the bound: search.hpp knn_shells); experiments (dcreg_knn_timed)
+template <int K, bool SWEEP = false>
 static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict__ q, uint32_t n, GridDev g, float bound_f, int max_ring,
                                                  PoseArg pose, int apply_pose, int32_t *__restrict__ idx, float *__restrict__ d2) {
     __shared__ RunList runs[kBlock / kWave];
@@ -516,7 +517,7 @@ static __global__ __launch_bounds__(kBlock) void k_knn(const float4 *__restrict_
         body_to_global(pose, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
     }
     KnnResult<K> nn;
-    knn_exact<K>(g, runs[threadIdx.x / kWave], qx, qy, qz, bound_f, max_ring, nn);
+    knn_exact<K, SWEEP>(g, runs[threadIdx.x / kWave], qx, qy, qz, bound_f, max_ring, nn);
     const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
     for (int j = 0; j < K; ++j) {

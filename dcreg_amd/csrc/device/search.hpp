@@ -792,20 +792,20 @@ struct KnnResult {
     uint32_t n_eval, n_shell;
 };
 
-template <int K>
+template <int K, bool SWEEP = false>
 DCREG_DEVFN void knn_exact(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring,
                                           KnnResult<K> &res) {
     uint32_t pos[K];
     {
         HeapFast<K> hf;
-        knn_search<HeapFast<K>>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
+        knn_search<HeapFast<K>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, hf);
         res.full = hf.full();
         res.n_eval = hf.n_eval; res.n_shell = hf.n_shell;
 #pragma unroll
         for (int j = 0; j < K; ++j) { res.d2[j] = hf.d[j]; pos[j] = hf.pos[j]; }
         if (hf.boundary_tie()) {                       // rare (exactly-equal float distances): exact redo
             HeapExact<K> he;
-            knn_search<HeapExact<K>>(g, rl, qx, qy, qz, bound_f, max_ring, he);
+            knn_search<HeapExact<K>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, he);
             res.n_eval += he.n_eval;
 #pragma unroll
             for (int j = 0; j < K; ++j) { res.d2[j] = he.dist(j); pos[j] = he.pos[j]; }

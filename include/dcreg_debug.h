@@ -44,6 +44,16 @@ typedef struct dcreg_launch_stats {
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
 
+/* A kd-tree over the target cloud as a COMPARATOR of the grid index (SURVEY.md 7.1 "benchmark both"): median splits along the widest
+ * axis, a complete implicit tree with at most leaf_size points per leaf, built on the host from the cloud of the last dcreg_set_target.
+ * dcreg_knn_timed runs the exact k-NN (k = 1 or 5) of dcreg_knn on the grid (index 0: the ring walk of dcreg_knn; index 2: the row
+ * sweep the linearisation uses, k = 5 with a radius only) or on the tree (index 1): one untimed launch, then `repeats` launches between
+ * two HIP events; all return the same lists, bit for bit.  scripts/kdtree_compare.py. */
+int dcreg_kdtree_build(dcreg_ctx *, int leaf_size);
+int dcreg_kdtree_info(const dcreg_ctx *, int32_t *depth, int32_t *leaf_size, double *build_ms);
+int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_floats, int k, double max_radius, int index, int repeats,
+                    int32_t *idx, float *d2, double *kernel_ms);
+
 /* experiment knobs of dcreg_set_option (defaults are what the product runs with):
  *   "time_kernels"       see dcreg_kernel_time;
  *   "xcd_chunk"          query-block -> XCD mapping: 0 = one contiguous run of query blocks per XCD, c = runs of c blocks dealt

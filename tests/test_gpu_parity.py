@@ -655,6 +655,42 @@ def test_certificates_only_spare_searches(cyl):
     assert a[8]["points_searched"] < 0.75 * a[8]["points"] and a[9]["points_searched"] < 0.75 * a[9]["points"]      # (25 iterations from 0.4 m / 3 deg off)
 
 
+def test_kdtree_comparator_returns_what_the_grid_returns():
+    """The kd-tree over the target (csrc/device/kdtree.hip, a comparator of the grid index: dcreg_debug.h) answers exact k-NN queries
+    with the same lists as the grid, bit for bit: aligned and misaligned queries, queries far outside the cloud, with and without a
+    radius, k = 1 and 5, a lattice with duplicated points (ties: the (d2, index) order decides), several leaf sizes."""
+    rng = np.random.default_rng(31)
+    g = np.arange(0, 12, dtype=np.float32) * 0.25
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    cases = {"corridor": (h.scene_corridor(120_000, seed=3, length=40.0), 1.0),
+             "fixture": (h.cylinder_cloud(), 1.0),
+             "lattice_dups": (np.concatenate([lattice, lattice[::5]]), 0.6)}
+    for name, (tgt, radius) in cases.items():
+        c = api.Context(0)
+        c.set_target(tgt, radius)
+        T = h.pose6d_matrix(0.4, -0.5, 0.3, h.deg2rad(1.0), h.deg2rad(-2.0), h.deg2rad(3.0))
+        base = tgt[rng.permutation(len(tgt))[:20_000]]
+        queries = [base + rng.normal(0, 0.01, base.shape).astype(np.float32),
+                   (base.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32),
+                   base + np.float32(300.0), base if name == "lattice_dups" else base[:1000] * np.float32(0.5)]
+        for leaf in (4, 16, 64):
+            depth, _, _ = c.kdtree_build(leaf)
+            assert (leaf << depth) >= len(tgt)
+            for q in queries:
+                for k in (1, 5):
+                    for r in (0.0, radius):
+                        ig, dg, _ = c.knn_timed(q, k, r, "grid", repeats=1)
+                        ik, dk, _ = c.knn_timed(q, k, r, "kdtree", repeats=1)
+                        assert np.array_equal(ig, ik) and np.array_equal(dg.view(np.uint32), dk.view(np.uint32)), (name, leaf, k, r)
+                        if k == 5 and r > 0.0 and leaf == 16:       # the row sweep of the linearisation in the plain kernel
+                            i2, d2_, _ = c.knn_timed(q, k, r, "grid_sweep", repeats=1)
+                            assert np.array_equal(ig, i2) and np.array_equal(dg.view(np.uint32), d2_.view(np.uint32)), (name, "sweep")
+        i0, d0 = c.knn(queries[1], 5, radius)
+        i1, d1, _ = c.knn_timed(queries[1], 5, radius, "kdtree", repeats=1)
+        assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+        c.close()
+
+
 def test_dispatch_order_only_schedules():
     """Launches with more query blocks than the device holds at once hand them out heaviest group first (kernels.hpp k_group_cost: an
     estimate per cloud pair at the pose of the first launch, used while the misalignment hint says it matters).  Scheduling only: with
