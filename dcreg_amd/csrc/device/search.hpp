@@ -1220,18 +1220,19 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
     // a query farther than max_ring cells from the grid has no neighbour inside the search bound
     const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
     if (g.owner) {
-        // A query in empty space whose bound is loose (nothing known, or neighbours of a pose far from this one): the ball of that
-        // bound cuts a wide cap out of the surface it faces - candidates ~ bound - d^2, hundreds where six are wanted.  The field
-        // names an occupied cell near the foot of the perpendicular; the sixth nearest of the points around it (the x-run of that
-        // cell and its two x neighbours, at most 48 points) is a distance six REAL points lie within, i.e. a valid bound, and a
-        // far tighter one.  Measured on the first iteration of a C4 run: profiles/r03_ablation.md.
+        // A query whose bound is loose (nothing known, or neighbours of a pose far from this one): the ball of that bound cuts a wide
+        // cap out of the surface it faces - candidates ~ bound - d^2, hundreds where six are wanted.  The field names an occupied
+        // cell near the foot of the perpendicular (the query's own cell when that holds points); the sixth nearest of the points
+        // around it (the x-run of that cell and its two x neighbours, at most 48 points) is a distance six REAL points lie within,
+        // i.e. a valid bound, and a far tighter one.  "Loose" = beyond 1.5 cells more than the distance to that cell.  Measured on
+        // the first iteration of a C4 run: profiles/r03_ablation.md section 9.
         bool far = false;
         uint32_t oc = kNoIdx;
         if (reach && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz) {
             const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
             const int f = (int)g.gap[cell];
             const float loose = ((float)f + 1.5f) * (float)g.h;
-            if (f >= 2 && f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
+            if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
         }
         if (wave_any(far)) {
             HeapFast<6> hb;

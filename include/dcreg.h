@@ -118,8 +118,8 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *   "wait_seconds"  default 30: how long a result is awaited before the stream is drained to look for a device fault;
  *   "dispatch_order" 1 (default) = launches with more query blocks than the device holds at once hand them out heaviest group
  *                   first while dcreg_hint_misalignment says the clouds are misaligned (kernels.hpp k_group_cost); 0 = index order;
- *   "far_bound"     1 (default) = a query in empty space with a loose bound starts its search from the points around the nearest
- *                   occupied cell (next dcreg_set_target);
+ *   "far_bound"     1 (default) = a query whose bound is loose (nothing known yet, or neighbours of a pose far away) starts its
+ *                   search from the points around the nearest occupied cell (next dcreg_set_target);
  *   "cell", "cell_factor", "x_subdiv", "gap_field": the grid index (cell edge in metres, 0 = auto = cell_factor x the estimated
  *                   5th-neighbour distance; x sub-cells per cell 1..16, default 8; 1 = build the empty-space distance field) at the
  *                   next dcreg_set_target.
