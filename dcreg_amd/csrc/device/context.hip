@@ -414,7 +414,7 @@ static int estimate_dispatch_order(dcreg_ctx *c, const double *R9, const double 
     for (uint32_t k = 0; k < ng; ++k) { sum += est[k]; mx = std::max(mx, (double)est[k]); }
     c->order_uneven = mx * ng > 1.3 * sum;                       // some group costs well above the mean
     std::memcpy(c->est_R, R9, sizeof(c->est_R)); std::memcpy(c->est_t, t3, sizeof(c->est_t));
-    c->order_valid = true;
+    c->order_valid = true; c->est_launch = c->n_launches;
     return DCREG_OK;
 }
 
@@ -478,7 +478,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (wanted && !gated) {
             // the estimate holds for poses near the one it was made at (within a cell for every point)
             bool stale = !c->order_valid;
-            if (!stale) {
+            if (!stale && c->n_launches - c->est_launch >= 16) {       // (a loop of ungated launches does not re-estimate at every step)
                 double dr = 0.0, dt = 0.0;
                 for (int k = 0; k < 9; ++k) dr += (R9[k] - c->est_R[k]) * (R9[k] - c->est_R[k]);
                 for (int k = 0; k < 3; ++k) dt += (t3[k] - c->est_t[k]) * (t3[k] - c->est_t[k]);

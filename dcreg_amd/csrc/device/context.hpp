@@ -137,6 +137,7 @@ struct dcreg_ctx {
     bool order_valid = false;       // group_order is the estimate for est_R / est_t; order_uneven: its costs differ enough to matter
     bool order_uneven = false;
     double est_R[9] = {}, est_t[3] = {};
+    int64_t est_launch = 0;         // n_launches when the estimate was made
     double hint_misalign = 1e300;   // dcreg_hint_misalignment     // source processed in groups of the curve order, the groups far from the body origin first (kernels.hpp kFarGroup)
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     int64_t n_launches = 0, n_poses_launched = 0, n_points_launched = 0;    // dcreg_launch_stats

@@ -328,7 +328,7 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
 
 // ---------------------------------------------------------------- k_lin
 template <int MODE, bool FUSED, bool FAST>
-static __global__ __launch_bounds__(kLinBlock, 4) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag) {

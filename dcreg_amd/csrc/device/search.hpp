@@ -41,6 +41,9 @@ inline float med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(
 #endif
 
 constexpr int kBlock = 256;          // 4 waves: the utility kernels
+#if !defined(DCREG_LIN_OCC)
+#define DCREG_LIN_OCC 4            // waves per SIMD the linearisation kernel is compiled for (register budget 512 / that)
+#endif
 #if !defined(DCREG_LIN_BLOCK)
 #define DCREG_LIN_BLOCK 256
 #endif
