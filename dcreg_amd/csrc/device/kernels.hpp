@@ -428,13 +428,14 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             // between the 5th and the 6th itself, i.e. the fit works on all six
             const bool use6 = fitnow && cert_is_set6(cert);
             const bool six = wave_any(use6);
+            const bool presorted = !wave_any(fitnow && !need);     // every lane that fits was searched just now: its six are in order
             if (fitnow && !need) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) pos6[j] = (j < 5 || use6) ? st[(size_t)j * ss] : kNoIdx;
             }
             if (!use6) pos6[5] = kNoIdx;
             if (fitnow) {
-                const uint8_t in_r = fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit);
+                const uint8_t in_r = fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted);
                 gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
                 if (keep) {                         // the new reference position, the certificate as seen from there, the fit
                     if (!need)                      // (the old reference position is read again: three registers less across the search)

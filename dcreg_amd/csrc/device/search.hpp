@@ -1364,7 +1364,7 @@ struct Fit { double plane[4]; uint32_t word; };
 // fit.word's gate bits set.
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, const uint32_t (&pos)[6], bool six,
-                                 KnnResult<5> &nn, Fit &fit) {
+                                 KnnResult<5> &nn, Fit &fit, bool presorted = false) {
     float d2[6];
     float4 pt[6];
     const bool use6 = six && pos[5] != kNoIdx;
@@ -1385,11 +1385,22 @@ DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, f
         pt[x].x = sw ? py.x : px.x; pt[x].y = sw ? py.y : px.y; pt[x].z = sw ? py.z : px.z; pt[x].w = sw ? py.w : px.w;
         pt[y].x = sw ? px.x : py.x; pt[y].y = sw ? px.y : py.y; pt[y].z = sw ? px.z : py.z; pt[y].w = sw ? px.w : py.w;
     };
-    if (six) {          // 12 compare-exchanges for six
-        cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(0, 2); cswap(3, 5); cswap(1, 4);
-        cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(1, 2); cswap(3, 4); cswap(2, 3);
-    } else {            // 9 for five
-        cswap(0, 1); cswap(3, 4); cswap(2, 4); cswap(2, 3); cswap(0, 3); cswap(0, 2); cswap(1, 4); cswap(1, 3); cswap(1, 2);
+    // `presorted` (uniform over the wave): every lane's positions come straight from this launch's search, i.e. in ascending distance
+    // already - the recomputed floats are the search's own - and only equal distances may still be out of (d2, idx) order
+    bool sort = !presorted;
+    if (presorted) {
+        bool eq = false;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) eq |= d2[j] == d2[j + 1] && (j < 4 || use6);
+        sort = wave_any(eq);
+    }
+    if (sort) {
+        if (six) {          // 12 compare-exchanges for six
+            cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(0, 2); cswap(3, 5); cswap(1, 4);
+            cswap(0, 1); cswap(2, 3); cswap(4, 5); cswap(1, 2); cswap(3, 4); cswap(2, 3);
+        } else {            // 9 for five
+            cswap(0, 1); cswap(3, 4); cswap(2, 4); cswap(2, 3); cswap(0, 3); cswap(0, 2); cswap(1, 4); cswap(1, 3); cswap(1, 2);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) { nn.d2[j] = d2[j]; nn.pt[j] = pt[j]; nn.idx[j] = __float_as_uint(pt[j].w); nn.pos[j] = 0u; }

@@ -300,7 +300,8 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
             const bool six = cert_is_set6(cert);      // (then the fit certificate has to cover the 5th / 6th gap itself)
             if (!need) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             if (!six) pos6[5] = kNoIdx;
-            const uint8_t in_r = p->fast_plane_fit ? fit_from_set<true>(g, a, qx, qy, qz, pos6, six, nn, fit) : fit_from_set<false>(g, a, qx, qy, qz, pos6, six, nn, fit);
+            const bool presorted = need;                   // (k_lin: uniform over the wave; a wave of one lane here)
+            const uint8_t in_r = p->fast_plane_fit ? fit_from_set<true>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted) : fit_from_set<false>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted);
             gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
             if (state) {
                 if (!need) cert = cert_rebased(cert, q0x, q0y, q0z, qx, qy, qz);
