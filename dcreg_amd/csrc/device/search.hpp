@@ -1231,11 +1231,17 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
         // the first iteration of a C4 run: profiles/r03_ablation.md section 9.
         bool far = false;
         uint32_t oc = kNoIdx;
-        if (reach && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz) {
-            const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
-            const int f = (int)g.gap[cell];
-            const float loose = ((float)f + 1.5f) * (float)g.h;
-            if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
+        const float loose0 = 1.5f * (float)g.h;
+        // (a bound within 1.5 cells is tight wherever the query sits: the usual case once a trajectory converges - no field byte is
+        // loaded for it, and a wave of such queries skips the block)
+        const bool maybe = reach && bound > loose0 * loose0 && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz;
+        if (wave_any(maybe)) {
+            if (maybe) {
+                const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
+                const int f = (int)g.gap[cell];
+                const float loose = ((float)f + 1.5f) * (float)g.h;
+                if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
+            }
         }
         if (wave_any(far)) {
             HeapFast<6> hb;
