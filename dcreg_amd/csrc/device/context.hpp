@@ -111,7 +111,7 @@ struct dcreg_ctx {
     int opt_x_subdiv = 8;          // x sub-cells per grid cell (1, 2, 4, 8, 16)
     bool opt_use_cert = true;      // skip the search of every point whose certificate still holds (0: only bound the searches)
     bool opt_count_searches = false;
-    double opt_cert_inflate = 0.02; // searches prune at (1 + inflate) x the 6th best distance: the 7th neighbour's lower bound (SET6 certificates)
+    double opt_cert_inflate = 0.005; // searches prune at (1 + inflate) x the 6th best distance: the 7th neighbour's lower bound (SET6 certificates)
     double opt_cert_margin = 0.05; // searches cover R (1 + margin): what "5th neighbour beyond R" certificates can spend
     int opt_time_kernels = 0;      // N > 0: bracket every N-th linearisation with HIP events
     uint64_t launch_counter = 0;

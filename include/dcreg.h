@@ -110,7 +110,7 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *                   from scratch in every call;
  *   "cert_margin"   default 0.05: searches cover search_radius * (1 + margin), so that "the 5th neighbour is beyond the radius" can
  *                   be certified too (takes effect at the next dcreg_set_target: the grid cells follow the search radius);
- *   "cert_inflate"  default 0.02: searches among nearby points look 2 % further than they must, which yields the second kind of
+ *   "cert_inflate"  default 0.005: searches among nearby points look 0.5 % further than they must, which yields the second kind of
  *                   certificate ("the five nearest are among these six"; search.hpp);
  *   "fast_plane_fit" 1 (default) = the reduced-instruction 5x3 plane fit; 0 = the Eigen-shaped factorisation step for step (planes
  *                   agree to a few ulp, gate flags are identical on every test scene);

@@ -69,7 +69,7 @@ def plane_fit(Q, fast):
 
 CERT_MARGIN = 0.05      # dcreg_ctx::opt_cert_margin
 CERT_MOVE = 0.5         # dcreg_ctx::opt_cert_move
-CERT_INFLATE = 0.02     # dcreg_ctx::opt_cert_inflate
+CERT_INFLATE = 0.005    # dcreg_ctx::opt_cert_inflate
 
 
 class Index:
