@@ -60,6 +60,8 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *                        round-robin (default 16);
  *   "keep_source_order"  1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert-curve sort;
  *   "use_certificates"   0 = search every point in every launch (the old neighbours still bound the searches), 1 = default;
+ *   "direct_rows"        1 (default) = a single-pose launch of at most 64 blocks publishes its block rows straight to pinned memory and
+ *                        the host adds them (in the device's association); 0 = chunk rows as for larger launches;
  *   "count_searches"     see dcreg_launch_stats. */
 
 #ifdef __cplusplus
