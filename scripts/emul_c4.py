@@ -5,6 +5,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dcreg_amd import scenes as h
+
+
+def _rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
 import emul
 from oracle import pyoracle as po
 
@@ -35,7 +41,7 @@ for k in range(iters):
     st = out["stats"].astype(np.int64)
     w = emul.wave_cost(out["stats"]).astype(np.int64)
     ref = logs[k]
-    ok = out["n_eff"] == ref.n_eff and h.rel_err(out["H_upper"], np.array(ref.H_upper[:])) < 1e-9
+    ok = out["n_eff"] == ref.n_eff and _rel_err(out["H_upper"], np.array(ref.H_upper[:])) < 1e-9
     print("iter %d parity %s n_eff %d | per query mean: %s | per wave max-lane mean: %s | p99 wave: %s | %.1fs" % (
         k, ok, out["n_eff"], " ".join("%s %.1f" % (a, b) for a, b in zip(names, st.mean(0))),
         " ".join("%s %.1f" % (a, b) for a, b in zip(names, w.mean(0))),
