@@ -325,8 +325,9 @@ DCREG_DEVFN float sqrt_approx(float x) {
 #endif
 }
 
+struct RunList;
 template <class H, bool SWEEP>
-DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
 
 // Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
@@ -383,6 +384,47 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
 #pragma unroll
         for (int u = 0; u < 4; ++u) push_point<H>(hp, qx, qy, qz, c[u], p + u, p + u < e);
     }
+}
+
+// The same run with DEFERRED insertion (the rows of the sweep: a far query scans hundreds of candidates of which a few per cent can
+// still enter once the first rows have tightened the ball): a candidate is filtered against the pruning bound as of the last flush
+// - one compare instead of the sorted insertion - and, if it passes, parked in the lane's pending list; the list
+// is pushed into the heap when some lane runs out of room and at the end of the run.  Pushes happen in scan order and everything
+// that was filtered out is noted as "seen and not kept", so heap, tie flag and 7th-neighbour bound come out as with scan_run.
+template <class H>
+DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
+    DCREG_STAT(runs);
+    const int tid = threadIdx.x & (kWave - 1);
+    float lim = hp.worst_d2();           // nothing at or beyond it can enter; tightened at every flush
+    float om = __builtin_inff();
+    int cnt = 0;
+    auto flush = [&]() {
+        for (int j = 0; j < cnt; ++j) {
+            const PendEntry pe = rl.pend[j][tid];
+            hp.template push<false>(__uint_as_float(pe.d2_bits), 0u, pe.pos, true);
+        }
+        cnt = 0;
+        lim = hp.worst_d2();
+    };
+    for (uint32_t p = s; p < e; p += 4) {
+        DCREG_STAT(trips);
+        if (wave_any(cnt > kPend - 4)) flush();
+        float4 c[4];
+        const float4 *cp4 = g.pts + p;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = cp4[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d2 = dist2_nofma(qx, qy, qz, c[u]);
+            const bool valid = p + u < e;
+            const bool pass = valid && d2 < lim;
+            hp.n_eval += valid ? 1u : 0u;
+            if (pass) { rl.pend[cnt][tid] = PendEntry{__float_as_uint(d2), p + u}; ++cnt; }
+            om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
+        }
+    }
+    flush();
+    hp.note_outside(om);
 }
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
@@ -541,7 +583,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             hp.note_outside(om);
         }
     }
-    knn_shells<H, SWEEP>(g, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+    knn_shells<H, SWEEP>(g, rl, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
 // Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
@@ -559,7 +601,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //     and was 25 % slower; batching the table loads of four rows, a flattened collect-then-scan walk and a 2x2x2 block occupancy
 //     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
 template <class H, bool SWEEP>
-DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int cx, int cy, int cz,
+DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
@@ -580,7 +622,8 @@ DCREG_DEVFN void knn_shells(const GridDev &g, float qx, float qy, float qz, int 
     auto lookup_scan = [&](int64_t c0, int64_t c1) {
         DCREG_STAT(table_loads); DCREG_STAT(table_loads); DCREG_STAT(faces);
         const uint32_t s_ = g.cell_start[c0], e_ = g.cell_start[c1];
-        scan_run<H>(g, s_, e_, qx, qy, qz, hp);
+        if constexpr (SWEEP && H::kDeferred) scan_run_deferred<H>(g, rl, s_, e_, qx, qy, qz, hp);
+        else scan_run<H>(g, s_, e_, qx, qy, qz, hp);
     };
     // slab distance (metres, float) from the query to cell index c along an axis (cq = the query's cell, fr = the query's position
     // inside that cell, in cells): single precision - every use carries a 1e-5 relative safety factor against 1e-7 of rounding
