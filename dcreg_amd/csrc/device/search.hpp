@@ -433,7 +433,7 @@ DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, ui
 // the ball covers the search radius.
 template <class H, bool SWEEP = false>
 DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, H &hp, float infl = 1.f, float cap = __builtin_inff()) {   // max_ring < 0: unbounded
+                                           int max_ring, H &hp, float infl = 1.f, float cap = __builtin_inff(), bool empty_block = false) {   // max_ring < 0: unbounded
     hp.init(bound_f, infl, cap);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
     const double lim = (double)max_ring + 1.0;
@@ -459,7 +459,9 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
     // here are 1e-5 relative plus 1e-4 of a sub-cell).  Empty runs are dropped when the list is written, nearest rows first.
     const int tid = threadIdx.x & (kWave - 1);
     int nrun = 0;
-    {
+    // (empty_block, uniform over the wave: the caller knows from the empty-space field that the 27-cell block of every query of the
+    // wave holds no point - queries in empty space, all of them: phases A and B have nothing to find)
+    if (!empty_block) {
         const float hf = (float)g.h;
         const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
         const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
@@ -503,7 +505,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
     }
     // ---- phase B: flattened walk over the runs (the wave iterates max-over-lanes of the total, not the
     // sum of per-row maxima), 4 candidates in flight per trip
-    {
+    if (!empty_block) {
         int ri = 0;
         uint32_t p = 0, e = 0;
         // deferred insertion state: lim = the lane's filter bound (the heap's K-th best as of the last flush: nothing at or
@@ -1188,9 +1190,10 @@ struct Set6 {
 // is run for this lane and its first five entries are the canonical set.  (A tie between the 6th best and a point outside does not
 // matter: neither belongs to the five, and both are at the distance the certificate uses.)
 template <bool SWEEP>
-DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, float cap, Set6 &out) {
+DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, float cap, Set6 &out,
+                         bool empty_block = false) {
     HeapFast<6> hf;
-    knn_search<HeapFast<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap);
+    knn_search<HeapFast<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap, empty_block);
     out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
@@ -1199,7 +1202,7 @@ DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, floa
     out.lb7 = fminf(hf.outside_min, fminf(hf.worst_d2(), bound_f));
     if (hf.pos[5] != kNoIdx && hf.d[4] == hf.d[5]) {
         HeapExact<6> he;
-        knn_search<HeapExact<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, he);
+        knn_search<HeapExact<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, he, 1.f, __builtin_inff(), empty_block);
         out.n_eval += he.n_eval;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { out.pos[j] = he.pos[j]; out.d2[j] = he.dist(j); }
@@ -1265,6 +1268,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
     const double lim = (double)a.max_ring + 1.0;
     // a query farther than max_ring cells from the grid has no neighbour inside the search bound
     const bool reach = have_q && !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
+    bool all_in_space = false;        // ... and that holds for every searching query of the wave (knn_search skips the block then)
     if (g.owner) {
         // A query whose bound is loose (nothing known, or neighbours of a pose far from this one): the ball of that bound cuts a wide
         // cap out of the surface it faces - candidates ~ bound - d^2, hundreds where six are wanted.  The field names an occupied
@@ -1274,6 +1278,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
         // the first iteration of a C4 run: profiles/r03_ablation.md section 9.
         bool far = false;
         uint32_t oc = kNoIdx;
+        bool in_space = false;            // the query's cell is at least two cells from any occupied one: its 27-cell block is empty
         const float loose0 = 1.5f * (float)g.h;
         // (a bound within 1.5 cells is tight wherever the query sits: the usual case once a trajectory converges - no field byte is
         // loaded for it, and a wave of such queries skips the block)
@@ -1282,9 +1287,11 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
             if (maybe) {
                 const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
                 const int f = (int)g.gap[cell];
+                in_space = f >= 2;
                 const float loose = ((float)f + 1.5f) * (float)g.h;
                 if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
             }
+            all_in_space = !wave_any(reach && !in_space);
         }
         if (wave_any(far)) {
             HeapFast<6> hb;
@@ -1306,7 +1313,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
     st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;
-    if (reach) search6<SWEEP>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st);
+    if (reach) search6<SWEEP>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st, SWEEP && all_in_space);
     cert = make_cert(st, a);
 }
 
