@@ -326,7 +326,7 @@ DCREG_DEVFN float sqrt_approx(float x) {
 }
 
 struct RunList;
-template <class H, bool SWEEP>
+template <class H, bool SWEEP, bool NOTE>
 DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
 
@@ -391,7 +391,7 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
 // - one compare instead of the sorted insertion - and, if it passes, parked in the lane's pending list; the list
 // is pushed into the heap when some lane runs out of room and at the end of the run.  Pushes happen in scan order and everything
 // that was filtered out is noted as "seen and not kept", so heap, tie flag and 7th-neighbour bound come out as with scan_run.
-template <class H>
+template <class H, bool NOTE>
 DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
     DCREG_STAT(runs);
     const int tid = threadIdx.x & (kWave - 1);
@@ -420,18 +420,22 @@ DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, ui
             const bool pass = valid && d2 < lim;
             hp.n_eval += valid ? 1u : 0u;
             if (pass) { rl.pend[cnt][tid] = PendEntry{__float_as_uint(d2), p + u}; ++cnt; }
-            om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
+            if (NOTE) om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
         }
     }
     flush();
-    hp.note_outside(om);
+    if (NOTE) hp.note_outside(om);
 }
 
 // Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
 // Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
 // closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
 // the ball covers the search radius.
-template <class H, bool SWEEP = false>
+// NOTE = false: the candidates the deferred insertion filters out are not noted as "seen and not kept".  Each of them is at or beyond
+// the pruning distance of its moment, hence of the end: the 7th-neighbour bound min(outside_min, final pruning distance, bound) does
+// not need them.  The boundary-tie test of knn_exact does (a filtered candidate may equal the K-th best where the pruning distance is
+// not inflated), so only search6 - which decides ties on the 5th / 6th entries alone - turns it off.
+template <class H, bool SWEEP = false, bool NOTE = true>
 DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
                                            int max_ring, H &hp, float infl = 1.f, float cap = __builtin_inff(), bool empty_block = false) {   // max_ring < 0: unbounded
     hp.init(bound_f, infl, cap);
@@ -564,7 +568,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
                     const bool pass = valid && d2 < lim;
                     hp.n_eval += valid ? 1u : 0u;
                     if (pass) { rl.pend[cnt][tid] = PendEntry{__float_as_uint(d2), sl.cp + u}; ++cnt; }
-                    om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
+                    if (NOTE) om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
                 }
             } else {
 #pragma unroll
@@ -585,7 +589,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             hp.note_outside(om);
         }
     }
-    knn_shells<H, SWEEP>(g, rl, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
+    knn_shells<H, SWEEP, NOTE>(g, rl, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
 // Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
@@ -602,7 +606,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //     per-lane iteration order, empty-space culling per face and centre-out rows visited fewer rows
 //     and was 25 % slower; batching the table loads of four rows, a flattened collect-then-scan walk and a 2x2x2 block occupancy
 //     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
-template <class H, bool SWEEP>
+template <class H, bool SWEEP, bool NOTE>
 DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, float qz, int cx, int cy, int cz,
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
@@ -624,7 +628,7 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
     auto lookup_scan = [&](int64_t c0, int64_t c1) {
         DCREG_STAT(table_loads); DCREG_STAT(table_loads); DCREG_STAT(faces);
         const uint32_t s_ = g.cell_start[c0], e_ = g.cell_start[c1];
-        if constexpr (SWEEP && H::kDeferred) scan_run_deferred<H>(g, rl, s_, e_, qx, qy, qz, hp);
+        if constexpr (SWEEP && H::kDeferred) scan_run_deferred<H, NOTE>(g, rl, s_, e_, qx, qy, qz, hp);
         else scan_run<H>(g, s_, e_, qx, qy, qz, hp);
     };
     // slab distance (metres, float) from the query to cell index c along an axis (cq = the query's cell, fr = the query's position
@@ -1193,7 +1197,7 @@ template <bool SWEEP>
 DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, float cap, Set6 &out,
                          bool empty_block = false) {
     HeapFast<6> hf;
-    knn_search<HeapFast<6>, SWEEP>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap, empty_block);
+    knn_search<HeapFast<6>, SWEEP, false>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap, empty_block);
     out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
