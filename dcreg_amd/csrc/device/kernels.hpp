@@ -155,7 +155,10 @@ struct DebugDev {
 // result is deterministic.  Batched launches (many poses, few blocks
 // each) use k_finalize instead: a ticket per block costs more there than the extra launch (measured, profiles/r01_search_ablation.md
 // addendum 5).
-constexpr int kChunk = 64;
+#if !defined(DCREG_CHUNK)
+#define DCREG_CHUNK 64
+#endif
+constexpr int kChunk = DCREG_CHUNK;
 // counters that many blocks hit with atomics live one per 128-byte line: atomics on ONE line are served one after the other (~11 ns
 // each), whatever word they address - 3907 ticket arrivals on two lines were 10 us of a 46 us kernel
 constexpr int kCounterStride = 32;      // uint32 words
