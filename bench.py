@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--repeats", type=int, default=30, help="the timed region of --steps iterations is repeated this many times")
+    ap.add_argument("--repeats", type=int, default=300, help="the timed region of --steps iterations is repeated this many times")
     ap.add_argument("--workload", default="c4_corridor_1m", choices=list(WORKLOADS))
     ap.add_argument("--method", default="Ours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
