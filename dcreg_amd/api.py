@@ -120,7 +120,7 @@ EXPORTS = [
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
     "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn", "dcreg_kdtree_build", "dcreg_kdtree_info", "dcreg_knn_timed",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
-    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy",
+    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_icp_run_montecarlo", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
     "dcreg_set_host_threads", "dcreg_get_host_threads", "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
@@ -179,6 +179,7 @@ def load():
     L.dcreg_default_config.restype = None
     L.dcreg_default_config.argtypes = [C.POINTER(Config)]
     L.dcreg_analyze_degeneracy.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis)]
+    L.dcreg_analyze_degeneracy_two_part.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis), C.POINTER(C.c_int)]
     L.dcreg_solve_degenerate_system.argtypes = [dp, dp, C.c_int, C.POINTER(Config), C.POINTER(Analysis), dp]
     L.dcreg_unpack_hessian.restype = None
     L.dcreg_unpack_hessian.argtypes = [dp, dp]
@@ -266,6 +267,15 @@ def analyze_degeneracy(H, detection, handling, cfg):
     if rc:
         raise DcregError("dcreg_analyze_degeneracy rc=%d" % rc)
     return an
+
+
+def analyze_degeneracy_two_part(H, detection, handling, cfg):
+    """the analysis as the pipelined engine takes it (dcreg_debug.h) -> (Analysis, owed mask)"""
+    an, owed = Analysis(), C.c_int(0)
+    rc = load().dcreg_analyze_degeneracy_two_part(_dp(_f64(H, 36)), DETECTION[detection], HANDLING[handling], C.byref(cfg), C.byref(an), C.byref(owed))
+    if rc:
+        raise DcregError("dcreg_analyze_degeneracy_two_part rc=%d" % rc)
+    return an, owed.value
 
 
 def solve_degenerate_system(H, g, handling, cfg, an):

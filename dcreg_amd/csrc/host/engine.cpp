@@ -20,8 +20,8 @@
 
 namespace dcreg {
 bool invertSpd6(const double H[36], double inv[36]);
-bool analyzeStep(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res);   // solver.cpp
-void analyzeFinish(const double H[36], dcreg_analysis &res);
+int analyzeStep(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res);    // solver.cpp
+void analyzeFinish(const double H[36], dcreg_analysis &res, int owed);
 }
 
 namespace {
@@ -39,7 +39,7 @@ inline dcreg_lin_params lin_params_of(const dcreg_config &cfg) {
 // steps 6-9 of one iteration for one state; returns 0 continue, 1 converged, 2 abort (non-finite)
 // defer = true: when nothing of the step depends on the full eigen-decomposition of H (a diagnostic of the log for "Ours"), it is
 // left to host_step_finish() - the caller lets the device start on the new pose in between
-struct StepOut { dcreg_analysis an; double dx[6]; double H[36]; bool evd_owed = false; };
+struct StepOut { dcreg_analysis an; double dx[6]; double H[36]; int evd_owed = 0; };
 inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const dcreg_config &cfg, double R[9], double t[3], StepOut &so,
                      bool defer = false) {
     dcreg_unpack_hessian(lo.H_upper, so.H);
@@ -54,7 +54,7 @@ inline int host_step(const dcreg_lin_out &lo, int detection, int handling, const
 }
 
 inline void host_step_finish(StepOut &so) {
-    if (so.evd_owed) { dcreg::analyzeFinish(so.H, so.an); so.evd_owed = false; }
+    if (so.evd_owed) { dcreg::analyzeFinish(so.H, so.an, so.evd_owed); so.evd_owed = 0; }
 }
 
 // eigenvalue clamp of a symmetric 6x6 (:2020-2029): only when the smallest eigenvalue is <= 1e-12 (or `always`), to 1e-9

@@ -56,8 +56,10 @@ static void alignAndOrthonormalize(const double Vraw[9], double Valigned[9], int
 }
 
 // icp_test_runner.cpp:2418-2469 + eigenvalue-clamped block preconditioner
-static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis &res) {
-    const Mat3 Hrr = block3(H, 0, 0), Htt = block3(H, 3, 3), Hrt = block3(H, 0, 3), Htr = block3(H, 3, 0);
+// eigenvalues and condition numbers of the diagonal blocks (the first lines of the Schur analysis): read by the EVD_SUB_CONDITION
+// detection only, otherwise a diagnostic of the log
+static void diagBlocks(const Mat6 &H, dcreg_analysis &res) {
+    const Mat3 Hrr = block3(H, 0, 0), Htt = block3(H, 3, 3);
     Vec<3> w; Mat3 V;
     symEig<3>(Hrr, w, V);
     std::memcpy(res.lambda_sub_rot, w.data(), sizeof(double) * 3);
@@ -65,6 +67,10 @@ static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis
     symEig<3>(Htt, w, V);
     std::memcpy(res.lambda_sub_trans, w.data(), sizeof(double) * 3);
     res.cond_diag_trans = vmax3(res.lambda_sub_trans) / std::max(vmin3(res.lambda_sub_trans), 1e-12);
+}
+static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis &res, bool defer_diag = false) {
+    const Mat3 Hrr = block3(H, 0, 0), Htt = block3(H, 3, 3), Hrt = block3(H, 0, 3), Htr = block3(H, 3, 0);
+    if (!defer_diag) diagBlocks(H, res);
 
     Mat3 HttInv, HrrInv;
     const bool okT = fullPivLuInverse3(Htt, HttInv), okR = fullPivLuInverse3(Hrr, HrrInv);
@@ -131,9 +137,10 @@ static bool evdIsDiagnosticOnly(int detection, int handling) {
     return det && hand;
 }
 
-// defer_evd: leave the full eigen-decomposition block out when nothing of the step depends on it.  Returns true if it was left
-// out: analyzeFinish() then completes the record, bit for bit what the one-pass analysis writes.
-static bool analyze(const Mat6 &H, int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res, bool defer_evd = false) {
+// defer_evd: leave the full eigen-decomposition block - and the diagonal blocks of the Schur analysis - out when nothing of the step
+// depends on them; analyzeFinish() then completes the record, bit for bit what the one-pass analysis writes.
+// (returns a mask of what is owed: 1 = the full eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis)
+static int analyze(const Mat6 &H, int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res, bool defer_evd = false) {
     const double nan = std::numeric_limits<double>::quiet_NaN();
     std::memset(&res, 0, sizeof(res));
     res.cond_schur_rot = res.cond_schur_trans = res.cond_diag_rot = res.cond_diag_trans = nan;
@@ -147,8 +154,8 @@ static bool analyze(const Mat6 &H, int detection, int handling, const dcreg_conf
     const bool deferred = defer_evd && evdIsDiagnosticOnly(detection, handling);
     const bool evdOk = deferred ? false : fullEvdBlock(H, res);      // dcreg.hpp:66-89
 
-    if (detection == DCREG_SCHUR_CONDITION_NUMBER || handling == DCREG_PRECONDITIONED_CG || cfg.always_compute_schur)
-        schurAnalysis(H, cfg, res);
+    const bool schur = detection == DCREG_SCHUR_CONDITION_NUMBER || handling == DCREG_PRECONDITIONED_CG || cfg.always_compute_schur;
+    if (schur) schurAnalysis(H, cfg, res, deferred);
 
     switch (detection) {
     case DCREG_SCHUR_CONDITION_NUMBER: {
@@ -190,7 +197,7 @@ static bool analyze(const Mat6 &H, int detection, int handling, const dcreg_conf
         break;
     default: break;                        // NONE_DETE and everything else: not degenerate
     }
-    return deferred;
+    return (deferred ? 1 : 0) | ((deferred && schur) ? 2 : 0);
 }
 
 // preconditioned conjugate gradients on the 6x6 SPD system (dcreg.hpp:279-287 is a stub)
@@ -283,12 +290,16 @@ static Vec<6> solve(const Mat6 &H, const Vec<6> &g, int handling, const dcreg_co
 void analyzeDegeneracy(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res) {
     analyze(toMat6(H), detection, handling, cfg, res);
 }
-// the analysis in two parts, for a loop that wants the step out of the door first (engine.cpp): analyzeStep returns true if the
-// eigen-decomposition block is still owed, analyzeFinish pays it.  Together they write exactly what analyzeDegeneracy writes.
-bool analyzeStep(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res) {
+// the analysis in two parts, for a loop that wants the step out of the door first (engine.cpp): analyzeStep returns what is still
+// owed (the eigen-decomposition block, the diagonal blocks of the Schur analysis), analyzeFinish pays it.  Together they write exactly what analyzeDegeneracy writes.
+int analyzeStep(const double H[36], int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res) {
     return analyze(toMat6(H), detection, handling, cfg, res, true);
 }
-void analyzeFinish(const double H[36], dcreg_analysis &res) { fullEvdBlock(toMat6(H), res); }
+void analyzeFinish(const double H[36], dcreg_analysis &res, int owed) {
+    const Mat6 M = toMat6(H);
+    if (owed & 1) fullEvdBlock(M, res);
+    if (owed & 2) diagBlocks(M, res);
+}
 void solveDegenerateSystem(const double H[36], const double g[6], int handling, const dcreg_config &cfg,
                            dcreg_analysis &an, double x[6]) {
     Vec<6> gv; std::memcpy(gv.data(), g, sizeof(double) * 6);
@@ -317,6 +328,15 @@ void dcreg_default_config(dcreg_config *c) {
     for (int i = 0; i < 4; ++i) c->gt_matrix[i * 5] = 1.0;
 }
 
+// (dcreg_debug.h) the two-part analysis of the pipelined engine - step part, then what it left owed - for the parity tests
+int dcreg_analyze_degeneracy_two_part(const double H[36], int detection, int handling, const dcreg_config *cfg, dcreg_analysis *res,
+                                      int *owed) {
+    if (!H || !cfg || !res) return DCREG_E_INVALID;
+    const int o = dcreg::analyzeStep(H, detection, handling, *cfg, *res);
+    if (owed) *owed = o;
+    dcreg::analyzeFinish(H, *res, o);
+    return DCREG_OK;
+}
 int dcreg_analyze_degeneracy(const double H[36], int detection, int handling, const dcreg_config *cfg, dcreg_analysis *res) {
     if (!H || !cfg || !res) return DCREG_E_INVALID;
     dcreg::analyzeDegeneracy(H, detection, handling, *cfg, *res);

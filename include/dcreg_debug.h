@@ -44,6 +44,10 @@ typedef struct dcreg_launch_stats {
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
 
+/* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 1 = the full
+ * eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis); the record must equal dcreg_analyze_degeneracy's */
+int dcreg_analyze_degeneracy_two_part(const double H[36], int detection, int handling, const dcreg_config *, dcreg_analysis *, int *owed);
+
 /* A kd-tree over the target cloud as a COMPARATOR of the grid index (SURVEY.md 7.1 "benchmark both"): median splits along the widest
  * axis, a complete implicit tree with at most leaf_size points per leaf, built on the host from the cloud of the last dcreg_set_target.
  * dcreg_knn_timed runs the exact k-NN (k = 1 or 5) of dcreg_knn on the grid (index 0: the ring walk of dcreg_knn; index 2: the row

@@ -84,6 +84,24 @@ def test_analyze_and_solve_match_oracle(method, paper, systems):
         assert np.allclose(x, ox, rtol=1e-8, atol=1e-12 * max(1.0, np.max(np.abs(ox)))), (method, x, ox)
 
 
+@pytest.mark.parametrize("paper", [False, True])
+def test_two_part_analysis_writes_the_same_record(paper, systems):
+    """The pipelined engine takes the part of the analysis its step needs first and pays the rest - the 6x6 eigen-decomposition and the
+    eigenvalues of the diagonal blocks, diagnostics of the log for Schur detection + PCG - after the device has its new pose.  Both
+    parts together must write byte for byte what dcreg_analyze_degeneracy writes, for every method (those whose step reads the
+    eigen-decomposition defer nothing)."""
+    cfg, _ = _cfgs(paper)
+    deferred = 0
+    for method in METHODS:
+        det, hand = api.METHODS[method]
+        for H, _g in systems:
+            one = api.analyze_degeneracy(H, det, hand, cfg)
+            two, owed = api.analyze_degeneracy_two_part(H, det, hand, cfg)
+            assert bytes(one) == bytes(two), (method, owed)
+            deferred += owed != 0
+    assert deferred > 0
+
+
 def test_ours_first_iteration_golden():
     """degeneracy_analysis_first_iter.txt (paper run): spectra, kappas, mask, alignment, dx = Gauss-Newton."""
     pts = h.cylinder_cloud()
