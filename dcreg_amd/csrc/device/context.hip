@@ -464,6 +464,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         const size_t cap = std::max<size_t>(n_rows, 64);
         HIP_TRY(c, hipHostMalloc((void **)&S.h_out, cap * kSlots * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(S.h_out, 0, cap * kSlots * sizeof(double));
+        std::fill(S.row_chk.begin(), S.row_chk.end(), 0ull);
         HIP_TRY(c, hipHostGetDevicePointer((void **)&S.d_out, S.h_out, 0));
         S.out_cap = cap;
     }
@@ -670,31 +671,49 @@ static int wait_rows(dcreg_ctx *c, LinSlot &S) {
     Clk::time_point t0;
     bool clocked = false;
     const uint64_t every = c->opt_wait_seconds < 1.0 ? ((1ull << 6) - 1) : ((1ull << 20) - 1);      // (sub-second patience: tests of this path)
-    // a row has arrived when its check word fits the 31 values next to it (kernels.hpp publish_row)
+    // a row has arrived when its check word fits the 31 values next to it (kernels.hpp publish_row).  The row is copied out in one
+    // piece (plain loads behind a compiler barrier: a torn snapshot fails the check and is read again) and the snapshot that was
+    // checked is the one that is used.
+    static const struct Mults { unsigned long long m[kSlots]; Mults() { for (int k = 0; k < kSlots; ++k) m[k] = row_check_mult(k); } } mults;
     auto arrived = [&](size_t i) {
-        const volatile unsigned long long *w = (const volatile unsigned long long *)(S.h_out + i * kSlots);
         unsigned long long v[kSlots];
-        for (int k = 0; k < kSlots; ++k) v[k] = __atomic_load_n(&w[k], __ATOMIC_RELAXED);
-        unsigned long long chk = S.seq * row_check_mult(31);
-        for (int k = 0; k < 31; ++k) chk += v[k] * row_check_mult(k);
-        if (chk != v[31]) return false;
-        std::memcpy(S.h_rows.data() + i * kSlots, v, sizeof(v));      // the snapshot that was checked is the one that is used
+        asm volatile("" ::: "memory");
+        std::memcpy(v, (const void *)(S.h_out + i * kSlots), sizeof(v));
+        unsigned long long c0 = S.seq * mults.m[31], c1 = 0, c2 = 0, c3 = 0;
+        for (int k = 0; k < 28; k += 4) { c0 += v[k] * mults.m[k]; c1 += v[k + 1] * mults.m[k + 1]; c2 += v[k + 2] * mults.m[k + 2]; c3 += v[k + 3] * mults.m[k + 3]; }
+        c0 += v[28] * mults.m[28]; c1 += v[29] * mults.m[29]; c2 += v[30] * mults.m[30];
+        if (c0 + c1 + c2 + c3 != v[31]) return false;
+        std::memcpy(S.h_rows.data() + i * kSlots, v, sizeof(v));
+        S.row_chk[i] = v[31];
         return true;
     };
+    // (cheap look first: a row whose check word is still the one taken last time has not been written again - the word carries the
+    // launch number)
+    auto touched = [&](size_t i) {
+        return __atomic_load_n((const unsigned long long *)(S.h_out + i * kSlots) + 31, __ATOMIC_RELAXED) != S.row_chk[i];
+    };
     S.h_rows.resize(S.n_rows * kSlots);
-    for (size_t i = 0; i < S.n_rows; ++i) {
-        uint64_t spins = 0;
-        while (!arrived(i)) {
-            __builtin_ia32_pause();
-            if ((++spins & every) != 0) continue;
-            if (!clocked) { t0 = Clk::now(); clocked = true; continue; }
-            if (std::chrono::duration<double>(Clk::now() - t0).count() < c->opt_wait_seconds) continue;
-            if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);      // nothing may wait behind us while we drain the stream
-            const hipError_t e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { c->fail("device fault while waiting for a linearisation: %s", hipGetErrorString(e)); return DCREG_E_DEVICE; }
-            if (!arrived(i)) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
-            break;
-        }
+    // rows are taken in the order they arrive (the last one to come is then the only one left to check), not in index order
+    S.row_done.assign(S.n_rows, 0);
+    if (S.row_chk.size() < S.n_rows) S.row_chk.resize(S.n_rows, 0ull);
+    size_t pending = S.n_rows;
+    uint64_t spins = 0;
+    while (pending) {
+        for (size_t i = 0; i < S.n_rows; ++i)
+            if (!S.row_done[i] && touched(i) && arrived(i)) { S.row_done[i] = 1; --pending; }
+        if (!pending) break;
+        __builtin_ia32_pause();
+        if ((++spins & every) != 0) continue;
+        if (!clocked) { t0 = Clk::now(); clocked = true; continue; }
+        if (std::chrono::duration<double>(Clk::now() - t0).count() < c->opt_wait_seconds) continue;
+        if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);      // nothing may wait behind us while we drain the stream
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->fail("device fault while waiting for a linearisation: %s", hipGetErrorString(e)); return DCREG_E_DEVICE; }
+        for (size_t i = 0; i < S.n_rows; ++i)
+            if (!S.row_done[i]) {
+                if (!arrived(i)) { c->fail("linearisation result never arrived"); return DCREG_E_DEVICE; }
+                S.row_done[i] = 1; --pending;
+            }
     }
     return DCREG_OK;
 }

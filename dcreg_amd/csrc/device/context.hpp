@@ -29,6 +29,8 @@ struct LinSlot {
     int n_poses = 0;
     uint32_t n_chunks = 0;
     bool direct = false;           // the rows are block rows of one chunk (kernels.hpp FinArgs::direct)
+    std::vector<uint8_t> row_done; // wait_rows: rows taken so far
+    std::vector<unsigned long long> row_chk;   // ... and the check word each row carried when it was last taken
     size_t n_rows = 0;
     unsigned long long seq = 0;
 };
