@@ -14,8 +14,16 @@ ranks); `value` = all timed steps / all timed time, `ms_per_step` = the same mea
 The other BASELINE configs (C1 fixture, C2 100 k cylinder, C3 PK01-like 200 k, C5 = the 5000-trial Monte-Carlo experiment end
 to end) are measured briefly afterwards and reported under "configs", each with its own roofline block.
 
+On the same line (N = 1): `roofline_by_regime` (every launch of a few whole runs timed with HIP events and bucketed by the fraction of
+its points that went through the search - the launch reports it itself), `converged_run` (the same pair with the reference's
+convergence thresholds on), `configs.c3_pk01_8k_registration` (what ONE registration of an 8 k-point frame costs from host buffers:
+dcreg_set_source + run to convergence, the reference's own metric, icp_test_runner.cpp:442-461) and the C5 experiment at 2 / 4 / all host
+threads.
+
 --gpus N: one process per GPU (RCCL); when not already under torch.distributed.run the script re-executes itself under it.
-Every rank runs its own scan pair (weak scaling, no data-path collective); RCCL carries only the final statistics gather.
+Every rank runs its own scan pair (weak scaling, no data-path collective) = `value`; then the 5000-trial Monte-Carlo experiment
+(BASELINE configs[4]) is run ONCE across all ranks - trials k = rank mod N, the 64-double trial records gathered over RCCL inside the
+timed region, statistics on rank 0 (icp_test_runner.cpp:604-664) - and reported as `configs.c5_montecarlo_5000` (strong scaling).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -84,6 +92,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-configs", action="store_true", help="skip the brief measurements of the other BASELINE configs")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the per-regime roofline and the thresholds-on run of the main workload")
     ap.add_argument("--sharding", default="pairs", choices=["pairs", "points"],
                     help="pairs (default): one independent scan pair per GPU, no data-path collective, weak scaling; "
                          "points: ONE pair, source points split over the GPUs, one 256 B all_gather per iteration, strong scaling")
@@ -233,7 +242,7 @@ class Pair:
                                           use_weight_derivative=w["wd"], always_compute_schur=1)
             self.mc_base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
             self.mc_rank, self.mc_world = D.rank, D.world
-            self.mc_stats = None
+            self.mc_stats, self.mc_ranks_seen, self.D = None, 0, D
 
     def _restart(self):
         self.pos = 0
@@ -273,14 +282,20 @@ class Pair:
                 self._restart()
 
     def _run_steps_mc(self, k):
-        """k passes of the Monte-Carlo experiment (this rank's share of the trials: k = rank mod world)."""
+        """k passes of the WHOLE Monte-Carlo experiment: this rank runs the trials k = rank mod world, the fixed-size trial records of all
+        ranks are gathered (one all_gather: RCCL on the GPU node) and rank 0 takes the statistics (icp_test_runner.cpp:604-664) - all of
+        it inside the caller's timed region.  mc_iters counts the ICP iterations of ALL trials (strong scaling: the job is fixed)."""
         from dcreg_amd import montecarlo as mcm
+        D = self.D
         for _ in range(k):
             mine = mcm.shard_indices(MC_TRIALS, self.mc_rank, self.mc_world)
             res = self.ctx.icp_run_montecarlo(self.mc_base, MC_SEED, self.mc_rank, self.mc_world, len(mine), 0.5, np.deg2rad(2.0), self.method, self.cfg, slots=MC_SLOTS)
-            recs = mcm.records_from_results(mine, res)
+            local = mcm.records_from_results(mine, res)
+            recs = mcm.gather_records(local, MC_TRIALS, D.dist, D.cdev)
             self.mc_iters += int(recs[:, mcm.R_ITERS].sum())
-            self.mc_stats = mcm.method_statistics(recs)
+            self.mc_ranks_seen = int(len(set((recs[:, mcm.R_TRIAL].astype(np.int64) % self.mc_world).tolist())))
+            if D.rank == 0:
+                self.mc_stats = mcm.method_statistics(recs)
 
     def close(self):
         self.ctx.close()
@@ -376,7 +391,7 @@ def profile_record(workload):
 def summarize(name, P, D, m, steps, n_gpus):
     times = np.array(m["times"])
     per_step_s = times / steps
-    total_iters = (1 if P.by_points else n_gpus) * steps * len(times) * m["iters_per_step"]
+    total_iters = (1 if (P.by_points or P.mc) else n_gpus) * steps * len(times) * m["iters_per_step"]
     value = total_iters / float(times.sum())
     w = WORKLOADS[name]
     rec = {"value": value, "unit": "iterations/s", "ms_per_step": 1e3 * float(times.sum()) / (steps * len(times)),
@@ -389,9 +404,151 @@ def summarize(name, P, D, m, steps, n_gpus):
                name, w["cfg"], P.n_src_total, len(P.tgt), w["radius"], w["run_len"], P.method))}
     rec.update(roofline_blocks(name, m["points_per_launch"], m["kernel_us"]))
     rec["poses_per_launch"] = m["poses_per_launch"]
-    if P.mc and P.mc_stats:
-        rec["montecarlo"] = {"trials": MC_TRIALS, "slots_in_flight": MC_SLOTS, "seed": MC_SEED, "statistics": P.mc_stats}
+    if P.mc:
+        rec["n_gpus"] = n_gpus
+        rec["scaling"] = "strong"
+        rec["rccl_ranks_seen"] = P.mc_ranks_seen
+        rec["montecarlo"] = {"trials": MC_TRIALS, "trials_per_rank": "k = rank mod %d" % n_gpus, "slots_in_flight": MC_SLOTS, "seed": MC_SEED,
+                             "record_gather": "one all_gather of %d-double trial records inside the timed region" % 64,
+                             "statistics": P.mc_stats}
     return rec
+
+
+def regime_probe(P, runs=6):
+    """Where the launches of whole runs spend their time: every launch of `runs` back-to-back runs is bracketed by HIP events and
+    reports how many of its points it searched (the count travels in the launch's own result rows: dcreg_debug.h dcreg_launch_series);
+    bucketed by that fraction.  all_search: >= half of the points searched (the first iterations of a run); settled: <= 1e-4 of them
+    (certificates hold: the launch streams 72 B per point); transition: in between.  frac = 72 B x points / mean time / HBM peak."""
+    w = P.w
+    P._restart()
+    P.ctx.set_option("time_kernels", 1)
+    P.ctx.set_option("record_launches", 1)
+    P.ctx.launch_series(reset=True)
+    P.run_steps(runs * w["run_len"])
+    ser = P.ctx.launch_series(reset=True)
+    P.ctx.set_option("record_launches", 0)
+    P.ctx.set_option("time_kernels", 0)
+    P.ctx.kernel_time(reset=True)
+    P._restart()
+    ok = (ser["ms"] >= 0) & (ser["searched"] >= 0) & (ser["points"] > 0)
+    ms, frac_s, pts = ser["ms"][ok], ser["searched"][ok] / ser["points"][ok], ser["points"][ok]
+    refit = ser["refitted"][ok] / ser["points"][ok]
+    out = {"runs": runs, "launches": int(ok.sum()), "source": "HIP events around every launch of %d whole runs (dcreg_launch_series); the searched / refitted "
+           "counts are reported by the launches themselves" % runs,
+           "bucket_rule": {"all_search": "searched >= 0.5 of the points", "transition": "1e-4 < searched < 0.5", "settled": "searched <= 1e-4"}}
+    for name, sel in (("all_search", frac_s >= 0.5), ("transition", (frac_s > 1e-4) & (frac_s < 0.5)), ("settled", frac_s <= 1e-4)):
+        if not sel.any():
+            out[name] = {"launches": 0}
+            continue
+        us = 1e3 * ms[sel]
+        mean_us = float(us.mean())
+        algo = BYTES_PER_QUERY * float(pts[sel].mean())
+        out[name] = {"launches": int(sel.sum()), "mean_us": mean_us, "min_us": float(us.min()), "max_us": float(us.max()),
+                     "share_of_kernel_time": float(us.sum() / (1e3 * ms.sum())),
+                     "mean_searched_frac": float(frac_s[sel].mean()), "mean_refitted_frac": float(refit[sel].mean()),
+                     "achieved_GBps": algo / (mean_us * 1e-6) / 1e9, "frac": algo / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    # the first four launches of a run, by position (the launches 0.87 m off the surface)
+    per_run = w["run_len"]
+    k = np.arange(int(ok.sum())) % per_run
+    if ok.all() and len(ms) == runs * per_run:
+        out["by_iteration_us"] = {"iter_%d" % i: float(1e3 * ms[k == i][1:].mean()) for i in (0, 1, 2, 3, 5, 10, 15, 20, 30, 49) if i < per_run}
+    return out
+
+
+def converged_run(P, D, repeats=10):
+    """The workload's pair with the reference's convergence test on (icp_test_runner.cpp:1957-1975; thresholds = dcreg_default_config =
+    utils.hpp:139-140): runs from the same initial pose until convergence."""
+    api, C, L = P.api, P.C, P.L
+    cfg = api.default_config(search_radius=P.w["radius"], max_iterations=P.w["run_len"], KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0,
+                             use_weight_derivative=P.w["wd"], always_compute_schur=1)
+    R0 = np.ascontiguousarray(P.T_init[:3, :3]).reshape(9).copy()
+    t0 = P.T_init[:3, 3].copy()
+    res = api.IcpResult()
+    its, times = [], []
+    for rep in range(repeats + 1):
+        D.fence()
+        ta = time.perf_counter()
+        rc = L.dcreg_icp_run(P.ctx._h, R0.ctypes.data_as(P.dp), t0.ctypes.data_as(P.dp), api.DETECTION[P.det], api.HANDLING[P.hand], C.byref(cfg), None, 0, C.byref(res))
+        D.fence()
+        if rc != 0:
+            raise RuntimeError("dcreg_icp_run failed: rc=%d" % rc)
+        if rep > 0:                                            # (the first run also pays the walk back from the last pose of the bench loop)
+            times.append(time.perf_counter() - ta); its.append(res.iterations)
+    P._restart()
+    t = np.array(times)
+    return {"thresholds": {"rot_rad": cfg.CONVERGENCE_THRESH_ROT, "trans_m": cfg.CONVERGENCE_THRESH_TRANS, "source": "dcreg_default_config = DCReg/include/utils.hpp:139-140"},
+            "converged": int(res.converged), "iterations_to_convergence": float(np.mean(its)), "ms_per_run": 1e3 * float(t.mean()),
+            "ms_per_run_min": 1e3 * float(t.min()), "iterations_per_s": float(np.sum(its) / t.sum()), "repeats": repeats,
+            "note": "runs from the bench's initial pose until |d rot| < %.0e rad and |d trans| < %.0e m; max %d iterations" % (
+                cfg.CONVERGENCE_THRESH_ROT, cfg.CONVERGENCE_THRESH_TRANS, P.w["run_len"])}
+
+
+def c3_registration(D, args, repeats=20):
+    """What the reference itself times (icp_test_runner.cpp:442-461; paper tables 6 / 7: Parking Lot 2.11 ms per registration on 1-10 k-point
+    frames): ONE registration of an 8 k-point frame against the 200 k-point map from HOST buffers - dcreg_set_source (upload, curve
+    sort) + run to convergence with the yaml's thresholds; the map and its index are resident (the reference's kd-tree of the map is
+    built once as well).  The CPU oracle's run of the same pair beside it (8 OpenMP threads, kd-tree of the map built beforehand)."""
+    import dcreg_amd
+    from dcreg_amd import api, scenes as h
+    tgt, src = h.scene_parkinglot()
+    gt, T0 = h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
+    ctx = dcreg_amd.Context(D.local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        ctx.set_option(k, float(v))
+    ctx.set_target(tgt, 0.5)
+    cfg = api.default_config(search_radius=0.5, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=1e-5,
+                             CONVERGENCE_THRESH_TRANS=1e-3, use_weight_derivative=0, always_compute_schur=1, gt_matrix=gt.reshape(16))
+    t_src, t_tot, its = [], [], []
+    res = None
+    for rep in range(repeats + 3):
+        ta = time.perf_counter()
+        ctx.set_source(src)
+        tb = time.perf_counter()
+        res, _ = ctx.icp_run(T0, args.method, cfg, log_capacity=0)
+        tc = time.perf_counter()
+        if rep >= 3:
+            t_src.append(tb - ta); t_tot.append(tc - ta); its.append(res.iterations)
+    T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
+    te, re_ = api.pose_error(gt, T)
+    ctx.close()
+    out = {"ms_total": 1e3 * float(np.mean(t_tot)), "ms_total_min": 1e3 * float(np.min(t_tot)), "ms_set_source": 1e3 * float(np.mean(t_src)),
+           "ms_iterations": 1e3 * float(np.mean(t_tot) - np.mean(t_src)), "iterations": float(np.mean(its)), "converged": int(res.converged),
+           "trans_error_vs_gt_m": float(te), "rot_error_vs_gt_deg": float(re_), "repeats": repeats,
+           "workload": "PK01 stand-in: %d-pt frame vs %d-pt map, radius 0.5, method %s, thresholds 1e-5 rad / 1e-3 m, init / gt poses of config/icp_pk01.yaml; "
+                       "frame from a host buffer every time (dcreg_set_source), map resident" % (len(src), len(tgt), args.method),
+           "reference_published_ms": 2.11, "reference_source": "paper table 6 / results/long_duration experiments/table3_4/*/dcreg/data_time.txt (Parking Lot, the authors' CPU; real data)"}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        tree = po.KdTree(tgt)
+        ocfg = po.default_config(search_radius=0.5, max_iterations=30, kappa_target=10.0, std_reg_gamma=100.0, thresh_rot=1e-5, thresh_trans=1e-3,
+                                 use_weight_derivative=0, always_compute_schur=1, num_threads=8, gt=gt.reshape(16))
+        po.icp_run(tree, src, T0, args.method, ocfg)
+        ts = []
+        for _ in range(5):
+            ta = time.perf_counter()
+            ores, _ = po.icp_run(tree, src, T0, args.method, ocfg)
+            ts.append(time.perf_counter() - ta)
+        out["cpu_oracle"] = {"ms_total": 1e3 * float(np.mean(ts)), "iterations": int(ores.iterations), "cores": 8, "kind": "port"}
+    return out
+
+
+def c5_host_thread_sweep(D, args, counts):
+    """The Monte-Carlo experiment on ONE GPU with the host steps of the engine limited to 2 / 4 / ... OpenMP threads: what a rank of an
+    8-rank job on a 16-CPU box has."""
+    from dcreg_amd import api
+    out = {}
+    Q = Pair("c5_montecarlo_5000", D, args, seed=100)
+    keep = api.load().dcreg_get_host_threads()
+    for n in counts:
+        got = api.set_host_threads(n)
+        mq = measure(Q, D, steps=1, warmup=1, repeats=3)
+        r = summarize("c5_montecarlo_5000", Q, D, mq, 1, 1)
+        out["threads_%d" % got] = {"host_threads": got, "value": r["value"], "unit": "iterations/s", "ms_per_experiment": r["ms_per_step"]}
+    if keep:
+        api.set_host_threads(keep)
+    Q.close()
+    return out
 
 
 def concurrent_pairs(P0, D, args, steps, warmup):
@@ -439,8 +596,9 @@ def dry_run(args, D):
     """DCREG_BENCH_DRYRUN=1 (CPU test hook): the launcher, rendezvous, fence, max-over-ranks and gather paths with a
     synthetic per-rank record instead of device work.  Prints a line marked "dry_run": true that is NOT a measurement."""
     from dcreg_amd import api, hostinfo
+    from dcreg_amd import montecarlo as mcm
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(D.world)))
-    want = hostinfo.threads_per_rank(local_world)
+    want, _ = hostinfo.setup_rank(D.local_rank, local_world)     # share first, then the rank's slice of the CPU mask (as main())
     got = api.set_host_threads(want)                 # (overrides the OMP_NUM_THREADS=1 torch.distributed.run exports)
     times = []
     for _ in range(2):
@@ -450,11 +608,28 @@ def dry_run(args, D):
         D.fence()
         times.append(D.max_over_ranks(time.perf_counter() - t0))
     recs = D.gather_rows([float(D.rank), float(100 + D.rank), float(got), 0.0])
+    # the strong-scaling leg (configs[4]): this rank's share of the trials -> synthetic records -> ONE gather inside the timed region ->
+    # statistics on rank 0, exactly the calls Pair._run_steps_mc makes around the engine
+    D.fence()
+    t0 = time.perf_counter()
+    mine = mcm.shard_indices(MC_TRIALS, D.rank, D.world)
+    local = np.zeros((len(mine), mcm.REC))
+    local[:, mcm.R_TRIAL] = mine
+    local[:, mcm.R_ITERS] = 10 + mine % 7
+    local[:, mcm.R_CONV] = (mine % 4 != 0)
+    allr = mcm.gather_records(local, MC_TRIALS, D.dist, D.cdev)
+    seen = int(len(set((allr[:, mcm.R_TRIAL].astype(np.int64) % D.world).tolist())))
+    stats = mcm.method_statistics(allr) if D.rank == 0 else None
+    D.fence()
+    t_mc = D.max_over_ranks(time.perf_counter() - t0)
     if D.rank == 0:
         print(json.dumps({"dry_run": True, "metric": "ICP iterations/sec", "value": None, "n_gpus": D.world, "steps": args.steps,
                           "warmup": args.warmup, "rank_seeds": [int(r[1]) for r in recs], "ranks": [int(r[0]) for r in recs],
                           "host_threads": [int(r[2]) for r in recs], "host_threads_per_rank": want,
-                          "block_times_s": times}), flush=True)
+                          "block_times_s": times,
+                          "c5_montecarlo_5000": {"n_gpus": D.world, "scaling": "strong", "trials": int(stats["total_runs"]), "rccl_ranks_seen": seen,
+                                                 "iterations": int(allr[:, mcm.R_ITERS].sum()), "converged_runs": int(stats["converged_runs"]),
+                                                 "seconds": t_mc}}), flush=True)
     D.close()
 
 
@@ -468,13 +643,19 @@ def main(argv=None):
     from dcreg_amd import scenes as h
     from dcreg_amd import api, hostinfo
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(D.world)))
-    hostinfo.pin_rank(D.local_rank, local_world)
-    # (torch.distributed.run exports OMP_NUM_THREADS=1: the batched engine's host steps get this rank's share of the usable CPUs)
-    host_threads = api.set_host_threads(hostinfo.threads_per_rank(local_world))
+    # (torch.distributed.run exports OMP_NUM_THREADS=1: the batched engine's host steps get this rank's share of the usable CPUs -
+    # computed before the rank is pinned to its slice of them)
+    want_threads, _ = hostinfo.setup_rank(D.local_rank, local_world)
+    host_threads = api.set_host_threads(want_threads)
 
     P = Pair(args.workload, D, args, seed=100 + (0 if args.sharding == "points" else D.rank))   # pairs: every rank its own scan pair
     m = measure(P, D, args.steps, args.warmup, args.repeats)
     main_rec = summarize(args.workload, P, D, m, args.steps, n_gpus)
+
+    regimes = conv = None
+    if not P.mc and not P.by_points and n_gpus == 1 and not args.no_regimes:
+        regimes = regime_probe(P)
+        conv = converged_run(P, D)
 
     conc = None
     if args.concurrent_pairs > 1 and not P.mc and not P.by_points and n_gpus == 1:
@@ -493,16 +674,25 @@ def main(argv=None):
     recs = D.gather_rows([te, re_, float(last["n_eff"]), float(100 + D.rank)])
 
     sub = {}
-    if not args.no_configs and n_gpus == 1 and args.sharding == "pairs":
+    if not args.no_configs and args.sharding == "pairs":
         for name in WORKLOADS:
             if name == args.workload:
                 continue
+            mc = name.startswith("c5_")
+            if n_gpus > 1 and not mc:
+                continue                        # N > 1: only the experiment that is sharded over the ranks (strong scaling)
             w = WORKLOADS[name]
             Q = Pair(name, D, args, seed=100)
-            k = 1 if name.startswith("c5_") else w["run_len"] * 2
-            mq = measure(Q, D, steps=k, warmup=1 if name.startswith("c5_") else w["run_len"], repeats=5)
-            sub[name] = summarize(name, Q, D, mq, k, 1)
+            k = 1 if mc else w["run_len"] * 2
+            mq = measure(Q, D, steps=k, warmup=1 if mc else w["run_len"], repeats=5)
+            sub[name] = summarize(name, Q, D, mq, k, n_gpus)
+            sub[name]["host_threads_per_rank"] = host_threads
             Q.close()
+        if n_gpus == 1:
+            sub["c3_pk01_8k_registration"] = c3_registration(D, args)
+            usable = hostinfo.usable_cpus()
+            sub["c5_montecarlo_5000"]["by_host_threads"] = c5_host_thread_sweep(D, args, sorted({2, 4, min(16, usable)}))
+            api.set_host_threads(host_threads)
 
     if D.rank == 0:
         result = {
@@ -524,6 +714,10 @@ def main(argv=None):
         }
         if "roofline_valu_issue" in main_rec:
             result["roofline_valu_issue"] = main_rec["roofline_valu_issue"]
+        if regimes is not None:
+            result["roofline_by_regime"] = regimes
+        if conv is not None:
+            result["converged_run"] = conv
         if conc is not None:
             result["concurrent_pairs"] = conc
         if sub:

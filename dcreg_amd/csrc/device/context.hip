@@ -36,11 +36,16 @@ static int ensure(dcreg_ctx *c, T *&ptr, size_t &cap, size_t need) {
     ptr = nullptr; cap = 0;
     size_t n = std::max<size_t>(need, 1);
     hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
-    if (e != hipSuccess) { c->fail("hipMalloc(%zu B) failed: %s", n * sizeof(T), hipGetErrorString(e)); return DCREG_E_NOMEM; }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // (the failed allocation must not surface as the "launch error" of whatever is queued next)
+        c->fail("hipMalloc(%zu B) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return DCREG_E_NOMEM;
+    }
     cap = n;
     return DCREG_OK;
 }
 
+constexpr double kCountScale = 67108864.0;      // 2^26 (search.hpp LinArgs::count_scale)
 constexpr size_t kSearchCountBytes = 64 * kCounterStride * sizeof(uint32_t);     // 64 counters, one per 128-byte line
 static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 static void drop_warm(dcreg_ctx *c);
@@ -322,6 +327,7 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     a.max_thick_sq = p->max_plane_thickness_sq; a.min_norm = p->min_normal_norm;
     a.w_slope = p->weight_slope; a.w_min = p->weight_min; a.use_wd = p->use_weight_derivative;
     a.warm = c->opt_warm ? 1 : 0;
+    a.team_max = std::min(std::max(c->opt_team_max, 0), kTeamMax);
     a.prune_infl = (float)((1.0 + c->opt_cert_inflate) * (1.0 + c->opt_cert_inflate));
     a.infl_max_d2 = (float)(4.0 * c->grid.h * c->grid.h);
     int k = 1;
@@ -332,6 +338,7 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     }
     a.max_ring = k;
     c->last_max_ring = k;
+    a.count_scale = c->n_src <= ((int64_t)1 << 26) ? kCountScale : 0.0;
     a.euler = p->parameterization == DCREG_PARAM_EULER ? 1 : 0;
     if (p->parameterization != DCREG_PARAM_SO3 && p->parameterization != DCREG_PARAM_EULER) { c->fail("unknown parameterization"); return DCREG_E_INVALID; }
     a.dR = nullptr;
@@ -438,10 +445,15 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (n_poses > 65535) { c->fail("at most 65535 poses per batched launch (grid.y limit), got %d", n_poses); return DCREG_E_INVALID; }
     if (c->n_tgt <= 0) { c->fail("KdTree/target index is not set up in context"); return DCREG_E_STATE; }   // :1639
     if (c->n_src <= 0) { c->fail("measure cloud is not set"); return DCREG_E_STATE; }
+    if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }     // (before make_lin_args: the Euler branch allocates and copies)
     LinArgs a;
     int rc = make_lin_args(c, p, a);
     if (rc) return rc;
-    if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }
+    // the parameters the stored certificates, gate bits and planes depend on (context.hpp StateKey): a launch with other values
+    // starts from empty states
+    dcreg_ctx::StateKey key;
+    key.radius_sq = a.radius_sq; key.max_thick_sq = a.max_thick_sq; key.min_norm = a.min_norm;
+    key.radius_sq_f = a.radius_sq_f; key.cert_r_out = a.cert_r_out; key.cert_r_in = a.cert_r_in; key.fast_plane = c->opt_fast_plane ? 1 : 0;
     const uint32_t nbx = blocks_for(c->n_src, kLinBlock);
     if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
@@ -498,6 +510,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     one.state = kNoIdx; one.fresh = 1;
     const PoseArg *d_poses = nullptr;
     bool uses_state = false;
+    if (n_poses == 1 && !state_ids && c->opt_warm && !(key == c->state_key)) { c->state_valid = false; c->state_key = key; }
     const bool state_was_valid = c->state_valid;
     if (n_poses == 1 && !state_ids) {
         std::memcpy(one.R, R9, sizeof(one.R)); std::memcpy(one.t, t3, sizeof(one.t));
@@ -534,6 +547,10 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     } else {
         // batched poses: each may own one of the reserved states (dcreg_reserve_warm_states); -1 = search cold, keep nothing
         const bool use_states = state_ids && c->opt_warm && c->n_batch_states > 0;
+        if (use_states && !(key == c->batch_state_key)) {
+            std::fill(c->batch_state_valid.begin(), c->batch_state_valid.end(), (uint8_t)0);
+            c->batch_state_key = key;
+        }
         if (state_ids && c->opt_warm) {
             std::vector<uint8_t> seen((size_t)std::max<int64_t>(c->n_batch_states, 1), 0);
             for (int i = 0; i < n_poses; ++i) {
@@ -737,12 +754,14 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
     free_tmp(S);
     if (rc != DCREG_OK) { drop_warm(c); return rc; }       // what the launch left in the states is unknown
     S.tickets_dirty = false;   // every chunk published its row: all tickets are back to zero
+    float launch_ms = -1.f;
     if (S.timed) {
         float ms = 0.f;
         hipError_t te = hipEventElapsedTime(&ms, c->ev0, c->ev1);
         if (te == hipErrorNotReady) { HIP_TRY(c, hipEventSynchronize(c->ev1)); te = hipEventElapsedTime(&ms, c->ev0, c->ev1); }
         HIP_TRY(c, te);
         c->kernel_ms_total += ms; c->kernel_launches += 1;
+        launch_ms = ms;
     }
     double total[kSlots];
     if (S.direct) {  // the rows of the blocks of ONE chunk, added exactly as block_sum_rows adds them on the device (so a pose gives
@@ -764,13 +783,25 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
             for (int k = 0; k < 31; ++k) total[k] += row[k];
         }
     }
+    // the count slots carry two numbers each when the launch was asked to report what it did (LinArgs::count_scale): exact integers
+    const bool coded = c->n_src <= ((int64_t)1 << 26);
+    int64_t searched = coded ? 0 : -1, refitted = coded ? 0 : -1;
     for (int i = 0; i < S.n_poses; ++i) {
         const double *o = S.fused ? total : S.h_rows.data() + (size_t)i * kSlots;
         std::memcpy(outs[i].H_upper, o, 21 * sizeof(double));
         std::memcpy(outs[i].g, o + 21, 6 * sizeof(double));
         outs[i].sum_r2 = o[27]; outs[i].sum_b2 = o[28];
-        outs[i].n_eff = (int64_t)std::llround(o[29]); outs[i].n_pt = (int64_t)std::llround(o[30]);
+        int64_t c29 = (int64_t)std::llround(o[29]), c30 = (int64_t)std::llround(o[30]);
+        if (coded) {
+            const int64_t S26 = (int64_t)1 << 26;
+            searched += c29 / S26; refitted += c30 / S26;
+            c29 %= S26; c30 %= S26;
+        }
+        outs[i].n_eff = c29; outs[i].n_pt = c30;
     }
+    c->last_searched = searched; c->last_refitted = refitted; c->last_points = (int64_t)S.n_poses * c->n_src;
+    if (c->opt_record_launches && c->launch_series.size() < ((size_t)1 << 20))
+        c->launch_series.push_back(dcreg_ctx::LaunchRec{(double)launch_ms, searched, refitted, c->last_points});
     return DCREG_OK;
 }
 
@@ -926,23 +957,28 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
         }
         c->opt_count_searches = v != 0.0;
     }
-    else if (k == "cert_margin") { c->opt_cert_margin = v >= 1e-4 ? std::min(v, 1.0) : 1e-4; drop_warm(c); }    // the cells follow at the next dcreg_set_target
-    else if (k == "cert_inflate") { c->opt_cert_inflate = v >= 0.0 ? std::min(v, 1.0) : 0.0; drop_warm(c); }
+    else if (k == "cert_margin" || k == "cert_inflate" || k == "warm_start" || k == "fast_plane_fit") {
+        // options the neighbour states depend on: not while a queued launch may still write them (a later _gate_abort would also
+        // restore state_valid, undoing the drop)
+        if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it before changing \"%s\"", key); return DCREG_E_STATE; }
+        if (k == "cert_margin") c->opt_cert_margin = v >= 1e-4 ? std::min(v, 1.0) : 1e-4;    // the cells follow at the next dcreg_set_target
+        else if (k == "cert_inflate") c->opt_cert_inflate = v >= 0.0 ? std::min(v, 1.0) : 0.0;
+        else if (k == "warm_start") c->opt_warm = v != 0.0;
+        else c->opt_fast_plane = v != 0.0;   // 1 (default) = plane_fit_qr_fast, 0 = the Eigen-shaped plane_fit_qr
+        drop_warm(c);
+    }
     else if (k == "wait_seconds") c->opt_wait_seconds = v > 0.0 ? v : 30.0;
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
+    else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
+    else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host
     else if (k == "far_bound") c->opt_far_bound = v != 0.0;       // next dcreg_set_target: start bound of far queries from the nearest occupied cell
     else if (k == "dispatch_order") { c->opt_dispatch_order = v != 0.0; c->order_valid = false; }   // heavy query groups first (kernels.hpp k_group_cost)
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
-    else if (k == "warm_start") {
-        if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it before changing \"warm_start\""); return DCREG_E_STATE; }
-        c->opt_warm = v != 0.0; drop_warm(c);
-    }
     else if (k == "xcd_chunk") c->opt_xcd_chunk = (int)v;   // 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks round-robin
-    else if (k == "fast_plane_fit") c->opt_fast_plane = v != 0.0;   // 1 (default) = plane_fit_qr_fast, 0 = the Eigen-shaped plane_fit_qr
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;
 }
@@ -1056,18 +1092,34 @@ int dcreg_index_info_get(const dcreg_ctx *c, dcreg_index_info *info) {
 int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
     if (!c || !st) return DCREG_E_INVALID;
     st->launches = c->n_launches; st->poses = c->n_poses_launched; st->points = c->n_points_launched;
-    st->points_searched = -1;
+    st->points_searched = -1; st->points_team = -1;
     if (c->opt_count_searches && c->d_search_count) {      // synchronous: every launch so far has finished when this returns
         std::vector<unsigned long long> v(kSearchCountBytes / sizeof(unsigned long long));
         HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_search_count, kSearchCountBytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        unsigned long long tot = 0;
-        for (size_t k = 0; k < v.size(); k += kCounterStride / 2) tot += v[k];
+        unsigned long long tot = 0, team = 0;
+        for (size_t k = 0; k < v.size(); k += kCounterStride / 2) { tot += v[k]; team += v[k + 1]; }
         st->points_searched = (int64_t)tot;
+        st->points_team = (int64_t)team;
         if (reset) HIP_TRY(c, hipMemsetAsync(c->d_search_count, 0, kSearchCountBytes, c->stream));
     }
     if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; }
     return DCREG_OK;
+}
+
+int dcreg_launch_series(dcreg_ctx *c, double *ms, int64_t *searched, int64_t *refitted, int64_t *points, int64_t cap, int reset) {
+    if (!c || cap < 0) return -1;
+    const int64_t n = std::min<int64_t>(cap, (int64_t)c->launch_series.size());
+    for (int64_t i = 0; i < n; ++i) {
+        const dcreg_ctx::LaunchRec &r = c->launch_series[(size_t)i];
+        if (ms) ms[i] = r.ms;
+        if (searched) searched[i] = r.searched;
+        if (refitted) refitted[i] = r.refitted;
+        if (points) points[i] = r.points;
+    }
+    const int64_t total = (int64_t)c->launch_series.size();
+    if (reset) c->launch_series.clear();
+    return (int)std::min<int64_t>(total, 0x7FFFFFFF);
 }
 
 int dcreg_kernel_time(dcreg_ctx *c, double *ms_total, int64_t *launches, int reset) {

@@ -67,6 +67,20 @@ struct dcreg_ctx {
     uint32_t *d_state = nullptr; size_t state_cap = 0;
     size_t state_stride = 0;
     bool state_valid = false;      // the state holds the results of a search of the current clouds
+    // What the states hold was measured against the parameters of the launch that wrote it: certificates against the search / gate
+    // radii, the stored gate bits against the plane thresholds, the stored plane by one of the two fits.  A launch with another key
+    // finds the states empty (linearize_begin); the weights, the weight derivative and the parameterisation are not part of it
+    // (they enter after the stored plane).  One key for the ctx's own state and one for the batch states.
+    struct StateKey {
+        double radius_sq = -1.0, max_thick_sq = 0.0, min_norm = 0.0;
+        float radius_sq_f = 0.f, cert_r_out = 0.f, cert_r_in = 0.f;
+        int fast_plane = -1;
+        bool operator==(const StateKey &o) const {
+            return radius_sq == o.radius_sq && max_thick_sq == o.max_thick_sq && min_norm == o.min_norm && radius_sq_f == o.radius_sq_f &&
+                   cert_r_out == o.cert_r_out && cert_r_in == o.cert_r_in && fast_plane == o.fast_plane;
+        }
+    };
+    StateKey state_key, batch_state_key;
     double src_radius = 0.0;       // largest distance of a source point from the body-frame origin (bounds a pose change's effect)
     // batched launches: n_batch_states states of the same layout, [state][kStateRows][state_batch_stride] (dcreg_reserve_warm_states),
     // and whether each holds anything yet
@@ -141,10 +155,17 @@ struct dcreg_ctx {
     double est_R[9] = {}, est_t[3] = {};
     int64_t est_launch = 0;         // n_launches when the estimate was made
     double hint_misalign = 1e300;   // dcreg_hint_misalignment     // source processed in groups of the curve order, the groups far from the body origin first (kernels.hpp kFarGroup)
+    int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     int64_t n_launches = 0, n_poses_launched = 0, n_points_launched = 0;    // dcreg_launch_stats
     double kernel_ms_total = 0.0;
     int64_t kernel_launches = 0;
+    // what the last completed launch did (decoded from the count slots of its result rows, search.hpp LinArgs::count_scale): points
+    // searched / refitted, -1 = not reported.  Scheduling input of the next launches; "record_launches": every launch is also logged
+    int64_t last_searched = -1, last_refitted = -1, last_points = 0;
+    struct LaunchRec { double ms; int64_t searched, refitted, points; };
+    bool opt_record_launches = false;
+    std::vector<LaunchRec> launch_series;
 
     void fail(const char *fmt, ...);
 };

@@ -275,7 +275,8 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
 }
 
 // ---- the common tail of a block: the wave's rows -> its Gram matrix and counts in LDS (the wave's LDS staging area must be free) ...
-__device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t flag, double *stage, double (*red)[kSlots], double (*cnt)[2]) {
+__device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t flag, double *stage, double (*red)[kSlots], double (*cnt)[2],
+                                                 double extra0 = 0.0, double extra1 = 0.0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double u0, u1;
     wave_gram_mfma(row, stage, lane, u0, u1);
@@ -285,7 +286,8 @@ __device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t
         gm[32 + (lane >> 4) * 8 + (lane & 7)] = u1;
     }
     const unsigned long long eff = __builtin_amdgcn_ballot_w64(flag == 1), inr = __builtin_amdgcn_ballot_w64(flag != 0);
-    if (lane == 0) { cnt[wave][0] = (double)__builtin_popcountll(eff); cnt[wave][1] = (double)__builtin_popcountll(inr); }
+    // (extra0 / extra1: the wave's searched / refitted lanes x LinArgs::count_scale, riding above the counts)
+    if (lane == 0) { cnt[wave][0] = (double)__builtin_popcountll(eff) + extra0; cnt[wave][1] = (double)__builtin_popcountll(inr) + extra1; }
 }
 // ... and, after a block barrier: the block partial (fixed order, no float atomics) and, for single-pose launches, the arrival at
 // the chunk's ticket: the last of its blocks sums the chunk and publishes the row to the host.  All 256 threads call.
@@ -382,6 +384,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     const bool need = have_q && !(CERT && cert_holds(cert, q0x, q0y, q0z, qx, qy, qz));
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
+    uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
     KnnResult<5> nn;
     Fit fit;
     uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
@@ -401,6 +404,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
 #pragma unroll
         for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
+        w_search = (uint32_t)__builtin_popcountll(need_mask);
         if (need_mask != 0ull) {
             if (a.search_count && (threadIdx.x & 63) == 0)       // 64 counters on lines of their own (kCounterStride): see there
                 atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)__builtin_popcountll(need_mask));
@@ -409,23 +413,45 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
 #pragma unroll
                 for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             }
-            Set6 s6;
-            uint32_t c2;
-            lin_search6<kLinSweep>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
-            if (need) {
-                cert = c2;
+            bool by_team = false;                   // uniform: the team served every lane that had to be searched
+            // a wave with a few lanes to search, each of them near its old neighbours: the 64 lanes serve one query at a time
+            if (warm && w_search <= (uint32_t)a.team_max) {
+                float tb = 0.f;
+                bool tight = false;
+                if (need && pos6[5] != kNoIdx) tb = team_bound(g, a, pos6, qx, qy, qz, tight);
+                if (!wave_any(need && !tight)) {
+                    uint32_t tpos[6], tcert;
+                    by_team = team_search6(g, runs[wave], a, need_mask, qx, qy, qz, tb, tpos, tcert) == need_mask;
+                    if (a.search_count && by_team && (threadIdx.x & 63) == 0)      // (statistics: the word next to the search counter)
+                        atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2) + 1, (unsigned long long)w_search);
+                    if (by_team && need) {
+                        cert = tcert;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
-                if (keep) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = s6.pos[j];
+                        for (int j = 0; j < 6; ++j) pos6[j] = tpos[j];
+                    }
                 }
-                stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+            }
+            // (all or nothing: a team result kept alive across the lock-step search would cost that search registers)
+            if (!by_team) {
+                Set6 s6;
+                uint32_t c2;
+                lin_search6<kLinSweep>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
+                if (need) {
+                    cert = c2;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
+                    stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
+                }
+            }
+            if (need && keep) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = pos6[j];
             }
         }
         // level 2 for the lanes that were searched and the lanes whose order may have changed
         const bool set = have_q && !cert_is_out(cert);
         const bool fitnow = set && (need || refit);
+        w_refit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fitnow && !need));
         if (wave_any(fitnow)) {
             // a SET6 certificate says nothing about which five of the six are nearest: the fit certificate must then cover the gap
             // between the 5th and the 6th itself, i.e. the fit works on all six
@@ -486,7 +512,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         if (dbg.stats) dbg.stats[oi] = stats;
     }
     // (the wave's RunList is free now: it stages the rows)
-    wave_rows_to_lds(row, flag, runs[wave].stage, red, cnt);
+    wave_rows_to_lds(row, flag, runs[wave].stage, red, cnt, a.count_scale * (double)w_search, a.count_scale * (double)w_refit);
     __syncthreads();
     block_publish<FUSED>(red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
 }

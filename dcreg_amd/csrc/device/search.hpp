@@ -107,6 +107,8 @@ struct LinArgs {
     int max_ring;                 // rings needed to cover the search bound
     int warm;                     // searches of a non-fresh state are bounded by the old neighbours' distances from the new position
     int use_cert;                 // ... and skipped for the points whose certificate still holds (0: debug dumps search everything)
+    int team_max;                 // a wave with at most this many lanes to search (<= kTeamMax; 0 = never) serves them one at a time
+                                  // with all 64 lanes (team_search6) instead of searching in lock-step
     float prune_infl;             // (1 + cert_inflate)^2: the searches prune at the 6th best distance x (1 + cert_inflate), which is
                                   // what makes the 7th neighbour's lower bound - and SET6 certificates - worth something ...
     float infl_max_d2;            // ... for searches bounded by at most this squared distance (a couple of cells)
@@ -116,6 +118,12 @@ struct LinArgs {
     uint32_t group_blocks, n_groups;   // heavy groups first (kernels.hpp k_group_cost): dispatch slot -> group of group_blocks query blocks;
     uint8_t group_order[256];          //   n_groups = 0: index order.  By value: the entry is fetched with the other launch arguments
     uint32_t xcd_chunk;           // block -> query-block mapping: 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks dealt round-robin
+    double count_scale;           // 2^26, or 0: the two count slots of a partial row also carry, above the counts themselves, how many
+                                  // points of the launch were searched (level 1) and refitted (level 2): slot 29 = n_eff + scale x
+                                  // searched, slot 30 = n_pt + scale x refitted - integers far below 2^53, so the fp64 sums stay exact
+                                  // and the host splits them again (context.hip linearize_end).  What the host does with them:
+                                  // scheduling only (which instantiation the next launch uses) and the launch statistics.  0 for
+                                  // clouds of more than 2^26 points.
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     const double *dR;             // euler: 27 doubles in device memory - dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll),
                                   // row-major (behind a pointer: as a member the 54 words would be hoisted into registers for every launch)
@@ -346,6 +354,9 @@ struct PendEntry { uint32_t d2_bits, pos; };
 // One RunList per WAVE ([slot][lane]); a wave's list is private to it, so once its search is over the same LDS serves as
 // that wave's staging area for the MFMA reduction of the rows (kernels.hpp) without a block barrier in between.
 constexpr int kRowStride = 9;          // doubles per staged row: 8 values + 1 pad (bank-conflict-free 64-bit writes)
+// scratch of the wave-cooperative search (team_search6 below): the candidates of ONE query that lie inside its bound, one per lane,
+// and the seven best of them in order
+struct TeamLds { uint32_t d2[kWave], pos[kWave], idx[kWave]; uint32_t out_d2[8], out_pos[8]; };
 struct alignas(16) RunList {
     union {
         struct {
@@ -356,6 +367,7 @@ struct alignas(16) RunList {
             PendEntry pend[kPend][kWave];
         };
         double stage[kWave * kRowStride];
+        TeamLds team;
     };
 };
 DCREG_DEVFN bool wave_any(bool x) {
@@ -1320,6 +1332,189 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
     if (reach) search6<SWEEP>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st, SWEEP && all_in_space);
     cert = make_cert(st, a);
 }
+
+// ---------------------------------------------------------------- wave-cooperative search of a few queries (sparse waves)
+// Once a trajectory converges, a wave that has to search at all has one to four lanes that do (profiles/r03_ablation.md section 11);
+// the lock-step search above then spends the whole wave - ~7 k instructions issued for one wave alone, ~29 us - on them.  Such
+// queries are all of one kind: they moved a little since their last search, so the ball that holds their six old neighbours (the warm
+// bound) lies inside their 27-cell block.  For them the roles are turned round: the 64 lanes serve ONE query at a time -
+//   * the nine (y,z) rows of the block, cut to the x sub-cells the ball reaches (the arithmetic of knn_search's phase A, one row per
+//     lane, up to seven queries' rows in one pass: 18 table loads in flight per query instead of 18 per lane);
+//   * every row read by all lanes at once (pts[s + lane]: coalesced), one float distance each, the candidates inside the bound
+//     compacted into a per-wave list (ballot + prefix count);
+//   * the list ranked by the exact key (distance bits, original index): lane i counts the keys below its own - the first seven ranks
+//     are the six neighbours in the canonical order (what the 64-bit-key search returns, ties included) and the distance of the
+//     seventh, i.e. the lower bound SET6 certificates want, exact.
+// Everything inside the ball is looked at (the rows are cut conservatively, as there), so "not in the list => at least the bound
+// away" holds as it does for the lock-step search.  A wave with a query that has more than 64 points inside its bound goes through the lock-step search after all.
+// Device only (wave intrinsics); team_row is plain per-thread code and is replayed on the host by the test suite.
+
+// [s, e) of row (dy, dz) of the query's 27-cell block, cut to the sub-cells the ball of squared radius bound_f reaches: knn_search's
+// phase A for one row with run-time offsets (an empty interval where the row is outside the grid or out of reach)
+DCREG_DEVFN void team_row(const GridDev &g, float qx, float qy, float qz, float bound_f, int dy, int dz, uint32_t &s_out, uint32_t &e_out) {
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+    const double big = 6.0e7;
+    const double flx = floor(fmin(fmax(fx, -big), big)), fly = floor(fmin(fmax(fy, -big), big)), flz = floor(fmin(fmax(fz, -big), big));
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int nx = g.nx, ny = g.ny, nz = g.nz;
+    const float hf = (float)g.h;
+    const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
+    const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
+    const float gy2 = dy < 0 ? gyl * gyl * 0.99999f : (dy > 0 ? gyh * gyh * 0.99999f : 0.f);
+    const float gz2 = dz < 0 ? gzl * gzl * 0.99999f : (dz > 0 ? gzh * gzh * 0.99999f : 0.f);
+    const int sx = g.sx, nxf = nx * sx;
+    const int cxs = cx * sx;
+    const float uf = frx * (float)sx;
+    const float kx = (float)g.inv_h * (float)sx * 1.00001f;
+    const uint32_t unx = (uint32_t)nxf, uny = (uint32_t)ny, sxy = unx * uny;
+    const bool yok = (uint32_t)(cy + dy) < uny, zok = (uint32_t)(cz + dz) < (uint32_t)nz;
+    const float g2 = gy2 + gz2;
+    const float rxf = fminf(sqrt_approx(fmaxf(bound_f - g2, 0.f)) * kx + 1e-4f, 1.0e6f);
+    const int lo = max((int)floorf(uf - rxf), -sx), hi = min((int)floorf(uf + rxf), 2 * sx - 1);
+    const int x0 = clampi(cxs + lo, 0, nxf), x1 = clampi(cxs + hi + 1, 0, nxf);   // [x0, x1)
+    const bool ok = yok && zok && (x1 > x0) && !(g2 > bound_f);
+    const uint32_t row = ((uint32_t)(cz + dz) * uny + (uint32_t)(cy + dy)) * unx;     // (garbage when outside: not used then)
+    (void)sxy;
+    s_out = g.cell_start[ok ? row + (uint32_t)x0 : 0u];
+    e_out = g.cell_start[ok ? row + (uint32_t)x1 : 0u];
+}
+
+// the bound a warm search of the linearisation starts from when nothing about it is loose (lin_search6: old neighbours' distances,
+// inflated like the pruning distance), and whether the ball of that bound provably lies inside the query's 27-cell block and the
+// query close enough to the grid: such a search ends with the cell-table phase (knn_shells' first test), which is all the team does
+DCREG_DEVFN float team_bound(const GridDev &g, const LinArgs &a, const uint32_t (&oldpos)[6], float qx, float qy, float qz, bool &tight) {
+    float bound = warm_bound6(g, oldpos, qx, qy, qz, a.radius_sq_f);
+    const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
+    bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+    const double lim = (double)a.max_ring + 1.0;
+    const bool reach = !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
+    const double safe = g.h * (1.0 - 1e-9);
+    tight = reach && (double)bound <= safe * safe * (1.0 - 1e-6);
+    return bound;
+}
+
+#if DCREG_ON_DEVICE
+#if !defined(DCREG_TEAM_PREFETCH)
+#define DCREG_TEAM_PREFETCH 4
+#endif
+constexpr int kTeamPre = DCREG_TEAM_PREFETCH;   // rows of a query whose first 64 points are requested together
+constexpr int kTeamMax = 7;            // queries of one wave the team serves (nine rows each: 63 lanes for the table phase)
+DCREG_DEVFN float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
+DCREG_DEVFN uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+DCREG_DEVFN float shfl_f(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)__float_as_uint(v))); }
+
+// team_mask: the lanes (at most kTeamMax) whose queries (qx, qy, qz, bound: valid in those lanes) are searched.  Returns the lanes
+// that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound) and
+// the certificate of the search (make_cert).
+DCREG_DEVFN unsigned long long team_search6(const GridDev &g, RunList &rl, const LinArgs &a, unsigned long long team_mask, float qx, float qy,
+                                            float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    TeamLds &T = rl.team;
+    // ---- the rows of all queries: lane 9 k + r = row r of the k-th query
+    const int k_of = lane / 9, r_of = lane - 9 * k_of;
+    int src = 0;
+    bool has = false;
+    {
+        unsigned long long m = team_mask;
+#pragma unroll
+        for (int k = 0; k < kTeamMax; ++k) {
+            const bool any = m != 0ull;
+            const int L = any ? __builtin_ctzll(m) : 0;
+            m &= m - 1ull;
+            if (any && k_of == k) { src = L; has = true; }
+        }
+    }
+    const float ax = shfl_f(qx, src), ay = shfl_f(qy, src), az = shfl_f(qz, src), ab = shfl_f(bound, src);
+    uint32_t rs = 0, re = 0;
+    if (has) team_row(g, ax, ay, az, ab, r_of % 3 - 1, r_of / 3 - 1, rs, re);
+    unsigned long long served = 0ull;
+    int k = 0;
+    for (unsigned long long m = team_mask; m != 0ull; m &= m - 1ull, ++k) {
+        const int L = __builtin_ctzll(m);
+        const float ux = readlane_f(qx, L), uy = readlane_f(qy, L), uz = readlane_f(qz, L), ub = readlane_f(bound, L);
+        uint32_t n = 0;                                  // candidates inside the bound so far (uniform)
+        auto take = [&](const float4 &c, uint32_t p, bool in) {
+            const float d2 = dist2_nofma(ux, uy, uz, c);
+            const bool pass = in && d2 < ub;
+            const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass);
+            const uint32_t slot = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            if (pass && slot < (uint32_t)kWave) { T.d2[slot] = __float_as_uint(d2); T.pos[slot] = p; T.idx[slot] = __float_as_uint(c.w); }
+            n += (uint32_t)__builtin_popcountll(pm);
+        };
+        // the first 64 points of (up to) kTeamPre non-empty rows are requested together, then taken in row order; what is left - more
+        // rows, longer rows - follows one load at a time
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(re > rs) >> (9 * k);
+        uint32_t rows = (uint32_t)live & 0x1FFu;
+        uint32_t s4[kTeamPre] = {}, e4[kTeamPre] = {};
+        float4 c4[kTeamPre];
+        int n4 = 0;
+#pragma unroll
+        for (int i = 0; i < kTeamPre; ++i) {
+            if (rows != 0u) {
+                const int r = __builtin_ctz(rows);
+                rows &= rows - 1u;
+                s4[i] = readlane_u(rs, 9 * k + r); e4[i] = readlane_u(re, 9 * k + r);
+                const uint32_t p = s4[i] + (uint32_t)lane;
+                c4[i] = g.pts[p < e4[i] ? p : s4[i]];
+                n4 = i + 1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kTeamPre; ++i) {
+            if (i < n4) {
+                take(c4[i], s4[i] + (uint32_t)lane, s4[i] + (uint32_t)lane < e4[i]);
+                for (uint32_t p0 = s4[i] + (uint32_t)kWave; p0 < e4[i]; p0 += (uint32_t)kWave) {
+                    const uint32_t p = p0 + (uint32_t)lane;
+                    const float4 c = g.pts[p < e4[i] ? p : p0];
+                    take(c, p, p < e4[i]);
+                }
+            }
+        }
+        while (rows != 0u) {
+            const int r = __builtin_ctz(rows);
+            rows &= rows - 1u;
+            const uint32_t s_ = readlane_u(rs, 9 * k + r), e_ = readlane_u(re, 9 * k + r);
+            for (uint32_t p0 = s_; p0 < e_; p0 += (uint32_t)kWave) {
+                const uint32_t p = p0 + (uint32_t)lane;
+                const float4 c = g.pts[p < e_ ? p : p0];
+                take(c, p, p < e_);
+            }
+        }
+        if (n > (uint32_t)kWave) continue;               // more than a list's worth inside the bound: the lock-step search takes it
+        __builtin_amdgcn_wave_barrier();
+        // ---- rank by (distance bits, original index): a total order, so the ranks are a permutation
+        const bool mine = (uint32_t)lane < n;
+        const uint32_t my_d2 = mine ? T.d2[lane] : 0xFFFFFFFFu, my_idx = mine ? T.idx[lane] : 0xFFFFFFFFu, my_pos = mine ? T.pos[lane] : kNoIdx;
+        const unsigned long long key = ((unsigned long long)my_d2 << 32) | my_idx;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const unsigned long long kj = ((unsigned long long)readlane_u(my_d2, (int)j) << 32) | readlane_u(my_idx, (int)j);
+            rank += kj < key ? 1u : 0u;
+        }
+        if (mine && rank < 7u) { T.out_d2[rank] = my_d2; T.out_pos[rank] = my_pos; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == L) {
+            Set6 out;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const bool got = (uint32_t)j < n;
+                out.pos[j] = got ? T.out_pos[j] : kNoIdx;
+                out.d2[j] = got ? __uint_as_float(T.out_d2[j]) : ub;
+            }
+            out.lb7 = n > 6u ? fminf(__uint_as_float(T.out_d2[6]), ub) : ub;
+            out.n_eval = 0; out.n_shell = 1;
+            cert_out = make_cert(out, a);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) pos_out[j] = out.pos[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        served |= 1ull << L;
+    }
+    return served;
+}
+#endif
+
 
 // Steps 3-4a for one query with its ordered neighbour set (icp_test_runner.cpp:1727-1773): plane fit and the two gates that depend on
 // the neighbours alone.  plane = {a, b, c, d} of a x + b y + c z + d = 0 with |(a,b,c)| = 1.  Returns 0 (ok), 2 (|x| < min_normal_norm,

@@ -257,7 +257,7 @@ static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, c
     std::vector<Slot> slot((size_t)n_slots);
     struct Group { std::vector<int> live; std::vector<int32_t> ids; std::vector<double> Rb, tb; std::vector<dcreg_lin_out> outs; bool in_flight = false; };
     Group grp[2];
-    int64_t next_trial = 0, done = 0;
+    int64_t next_trial = 0;
     auto load = [&](int si) -> bool {                      // next trial in line -> slot si
         if (next_trial >= n_trials) { slot[(size_t)si].trial = -1; return false; }
         Slot &S = slot[(size_t)si];
@@ -267,7 +267,6 @@ static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, c
         return true;
     };
     for (int si = 0; si < n_slots; ++si) load(si);
-    auto group_of = [&](int si) { return n_groups == 2 ? (si & 1) : 0; };
     double t_lin_ms = 0.0, t_host_ms = 0.0;
     int64_t n_steps = 0;
     auto begin = [&](int gi) -> int {
@@ -327,7 +326,6 @@ static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, c
             dcreg_trial_result &tr = results[S.trial];
             dcreg::stateToMatrix(S.R, S.t, tr.final_transform);
             dcreg::poseError(cfg->gt_matrix, tr.final_transform, &tr.trans_error_m, &tr.rot_error_deg);   // :501-503
-            ++done;
             load(si);
         }
         t_host_ms += ms_since(t_b);
@@ -339,7 +337,6 @@ static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, c
         for (int si = gi; si < n_slots; si += n_groups) if (slot[(size_t)si].trial >= 0) return true;
         return false;
     };
-    (void)group_of;
     int rc = begin(0);
     while (rc == DCREG_OK && (has_work(0) || (n_groups == 2 && has_work(1)))) {
         if (n_groups == 2 && !grp[1].in_flight && (rc = begin(1)) != DCREG_OK) break;   // queued behind group 0

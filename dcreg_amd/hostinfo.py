@@ -51,3 +51,14 @@ def pin_rank(local_rank, local_world):
     except Exception:
         return None
     return mine
+
+
+def setup_rank(local_rank, local_world, cap=32):
+    """Thread count and CPU slice of one rank, in the only order that works: the share is computed from the mask the process was
+    STARTED with, then the mask is cut down to the rank's slice (usable_cpus() reads the affinity mask: asked after pin_rank it
+    sees the slice and would divide by local_world a second time).  Returns (threads, pinned CPUs or None)."""
+    want = threads_per_rank(local_world, cap)
+    mine = pin_rank(local_rank, local_world)
+    if mine:
+        want = max(1, min(want, len(mine)))
+    return want, mine

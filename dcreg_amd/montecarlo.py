@@ -170,9 +170,10 @@ def main(argv=None):
     from . import api, Context, hostinfo
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    hostinfo.pin_rank(local, local_world)
-    # torch.distributed.run exports OMP_NUM_THREADS=1; the engine's host steps want this rank's share of the CPUs
-    api.set_host_threads(a.host_threads if a.host_threads > 0 else hostinfo.threads_per_rank(local_world))
+    # torch.distributed.run exports OMP_NUM_THREADS=1; the engine's host steps want this rank's share of the CPUs (computed before
+    # the rank is pinned to its slice)
+    share, _ = hostinfo.setup_rank(local, local_world)
+    api.set_host_threads(a.host_threads if a.host_threads > 0 else share)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -41,8 +41,18 @@ typedef struct dcreg_launch_stats {
     int64_t poses;             /* poses linearised */
     int64_t points;            /* source points those poses had, all told */
     int64_t points_searched;   /* ... of which went through the 6-NN search (the others' certificates held) */
+    int64_t points_team;       /* ... of which were searched by a whole wave at a time (search.hpp team_search6: waves with a few
+                                  lanes to search), the rest in lock-step; -1 like points_searched */
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
+
+/* Log of the launches completed since the option "record_launches" = 1 was set (or since the last reset), oldest first: duration
+ * (ms, HIP events; -1 for a launch that was not timed - see "time_kernels"), points that went through the 6-NN search (level 1),
+ * points whose known neighbours were only re-ordered and refitted (level 2), points the launch linearised in all (poses x source
+ * points).  The two counts travel in the count slots of the launch's own result rows (no atomics, no extra transfer); -1 for clouds of
+ * more than 2^26 points.  Any array may be NULL; at most `cap` entries are written; returns the number of entries logged (which may
+ * exceed cap), < 0 on invalid arguments.  bench.py's per-regime roofline is built from this. */
+int dcreg_launch_series(dcreg_ctx *, double *ms, int64_t *searched, int64_t *refitted, int64_t *points, int64_t cap, int reset);
 
 /* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 1 = the full
  * eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis); the record must equal dcreg_analyze_degeneracy's */
@@ -66,7 +76,8 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "use_certificates"   0 = search every point in every launch (the old neighbours still bound the searches), 1 = default;
  *   "direct_rows"        1 (default) = a single-pose launch of at most 64 blocks publishes its block rows straight to pinned memory and
  *                        the host adds them (in the device's association); 0 = chunk rows as for larger launches;
- *   "count_searches"     see dcreg_launch_stats. */
+ *   "count_searches"     see dcreg_launch_stats;
+ *   "record_launches"    see dcreg_launch_series. */
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,9 @@ def lib():
         L.emu_index_build.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         L.emu_index_free.argtypes = [C.c_void_p]
         L.emu_index_set_sweep.argtypes = [C.c_void_p, C.c_int32]
+        L.emu_index_set_team.argtypes = [C.c_void_p, C.c_int32]
+        L.emu_index_team_served.restype = C.c_int64
+        L.emu_index_team_served.argtypes = [C.c_void_p]
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
@@ -89,6 +92,14 @@ class Index:
     def set_sweep(self, on):
         """The searches of linearize(): True = row sweep (what k_lin runs), False = ring walk (-DDCREG_RING_WALK builds, dcreg_knn)."""
         lib().emu_index_set_sweep(self.ptr, int(bool(on)))
+
+    def set_team(self, on):
+        """True: the queries a sparse wave of k_lin would hand to team_search6 (warm bound inside the 27-cell block) are searched by the
+        scalar replay of that algorithm instead of the lock-step search (team_served() counts them)."""
+        lib().emu_index_set_team(self.ptr, int(bool(on)))
+
+    def team_served(self):
+        return int(lib().emu_index_team_served(self.ptr))
 
     def __del__(self):
         if getattr(self, "ptr", None):

@@ -22,6 +22,8 @@ struct EmuIndex {
     std::vector<uint32_t> owner;
     std::vector<uint32_t> ymask;
     bool sweep = true;
+    bool team = false;                  // replay team_search6's algorithm for the queries it would take (tight warm bound)
+    int64_t team_served = 0;
     GridDev g{};
     int64_t n_cells = 0;
     uint32_t occupied = 0;
@@ -74,6 +76,37 @@ static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, con
     g.n_pts = (uint32_t)n;
     E.g = g; E.n_cells = n_cells / sx; E.occupied = occ;
     return occ;
+}
+
+// Scalar replay of search.hpp team_search6 for ONE query (the device spreads this over the 64 lanes of a wave): the nine rows of the
+// 27-cell block cut by team_row, every point of them with a float distance below the bound, ranked by (distance bits, original
+// index); the first six + the seventh's distance -> positions and certificate.  false: more than 64 points inside the bound (the
+// device leaves such a query to the lock-step search).
+static bool team_search_host(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out) {
+    struct Ent { uint64_t key; uint32_t pos, d2; };
+    std::vector<Ent> list;
+    for (int r = 0; r < 9; ++r) {
+        uint32_t s_ = 0, e_ = 0;
+        team_row(g, qx, qy, qz, bound, r % 3 - 1, r / 3 - 1, s_, e_);
+        for (uint32_t p = s_; p < e_; ++p) {
+            const float4 c = g.pts[p];
+            const float d2 = dist2_nofma(qx, qy, qz, c);
+            if (d2 < bound) list.push_back(Ent{((uint64_t)__float_as_uint(d2) << 32) | __float_as_uint(c.w), p, __float_as_uint(d2)});
+        }
+    }
+    if (list.size() > 64) return false;
+    std::sort(list.begin(), list.end(), [](const Ent &x, const Ent &y) { return x.key < y.key; });
+    Set6 out{};
+    const uint32_t n = (uint32_t)list.size();
+    for (int j = 0; j < 6; ++j) {
+        const bool got = (uint32_t)j < n;
+        out.pos[j] = got ? list[(size_t)j].pos : kNoIdx;
+        out.d2[j] = got ? __uint_as_float(list[(size_t)j].d2) : bound;
+    }
+    out.lb7 = n > 6u ? fminf(__uint_as_float(list[6].d2), bound) : bound;
+    cert_out = make_cert(out, a);
+    for (int j = 0; j < 6; ++j) pos_out[j] = out.pos[j];
+    return true;
 }
 
 extern "C" {
@@ -163,6 +196,8 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
 void emu_index_free(void *p) { delete (EmuIndex *)p; }
 // the searches of emu_linearize: 1 = row sweep (as k_lin), 0 = ring walk (as -DDCREG_RING_WALK; the two must agree bit for bit)
 void emu_index_set_sweep(void *p, int32_t on) { ((EmuIndex *)p)->sweep = on != 0; }
+void emu_index_set_team(void *p, int32_t on) { ((EmuIndex *)p)->team = on != 0; }
+int64_t emu_index_team_served(void *p) { return ((EmuIndex *)p)->team_served; }
 void emu_index_info(void *p, double *h, int32_t dims[3], int64_t *n_cells, int32_t *gap_cap) {
     EmuIndex *E = (EmuIndex *)p;
     *h = E->g.h; dims[0] = E->g.nx; dims[1] = E->g.ny; dims[2] = E->g.nz; *n_cells = E->n_cells; *gap_cap = E->g.gap_cap;
@@ -282,8 +317,22 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         if (need) {
             if (old && warm) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             uint32_t c2;
-            if (E->sweep) lin_search6<true>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
-            else lin_search6<false>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
+            bool by_team = false;
+            if (E->team && old && warm && pos6[5] != kNoIdx) {      // the queries k_lin hands to team_search6 in a sparse wave
+                bool tight = false;
+                const float tb = team_bound(g, a, pos6, qx, qy, qz, tight);
+                uint32_t tpos[6];
+                if (tight && team_search_host(g, a, qx, qy, qz, tb, tpos, c2)) {
+                    by_team = true;
+                    for (int j = 0; j < 6; ++j) s6.pos[j] = tpos[j];
+                    s6.n_eval = 0; s6.n_shell = 1;
+                    ++E->team_served;
+                }
+            }
+            if (!by_team) {
+                if (E->sweep) lin_search6<true>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
+                else lin_search6<false>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
+            }
             cert = c2;
             for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
             if (state) for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = s6.pos[j];

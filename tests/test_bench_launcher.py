@@ -37,6 +37,15 @@ def test_self_spawn_two_ranks_dry_run():
     assert j["dry_run"] is True and j["n_gpus"] == 2 and j["steps"] == 20 and j["warmup"] == 5
     assert j["ranks"] == [0, 1] and j["rank_seeds"] == [100, 101]     # one record per rank, every rank its own pair
     assert all(t >= 0.02 for t in j["block_times_s"])                 # max over ranks: rank 1 sleeps twice as long as rank 0
+    _check_c5_leg(j, 2)
+
+
+def _check_c5_leg(j, world):
+    """the strong-scaling leg of a multi-rank run: every trial of the 5000 ran on exactly one rank (k = rank mod world), the records of
+    all ranks reached rank 0 through the one gather, the statistics are those of the whole experiment"""
+    c5 = j["c5_montecarlo_5000"]
+    assert c5["n_gpus"] == world and c5["scaling"] == "strong" and c5["trials"] == 5000 and c5["rccl_ranks_seen"] == world
+    assert c5["iterations"] == sum(10 + k % 7 for k in range(5000)) and c5["converged_runs"] == sum(1 for k in range(5000) if k % 4)
 
 
 @pytest.mark.timeout(600)
@@ -50,6 +59,10 @@ def test_self_spawn_eight_ranks_dry_run():
     assert j["ranks"] == list(range(8)) and j["rank_seeds"] == [100 + r for r in range(8)]
     assert all(t >= 0.08 for t in j["block_times_s"])                 # max over ranks: rank 7 sleeps 8 x 10 ms
     assert j["host_threads_per_rank"] >= 1 and len(set(j["host_threads"])) == 1 and j["host_threads"][0] == j["host_threads_per_rank"]
+    # the share is taken from the CPUs the job was started with, not from a rank's slice of them
+    from dcreg_amd import hostinfo
+    assert j["host_threads_per_rank"] == hostinfo.threads_per_rank(8)
+    _check_c5_leg(j, 8)
 
 
 def test_refuses_a_job_it_cannot_run():

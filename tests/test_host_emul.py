@@ -174,6 +174,74 @@ def test_certificate_torture():
         assert max(searched[1:]) <= len(src)
 
 
+def test_team_search_algorithm_keeps_the_sums_and_its_certificates_hold():
+    """search.hpp team_search6 (what a sparse wave of k_lin runs for the queries whose warm bound lies inside their 27-cell block):
+    the scalar replay of its algorithm - rows cut by team_row, every point inside the bound ranked by (distance bits, index), the
+    seventh distance as the lower bound of the certificate - takes those queries instead of the lock-step search.  Walks that mix
+    micrometre steps with steps of several neighbour spacings, on scenes with ties, duplicates, OUT points and coordinates far from
+    the origin: after every step per-point results == oracle and sums bitwise == the all-search path; the certificates the team
+    writes are used by the later steps, so a lower bound that claimed too much would surface there."""
+    rng = np.random.default_rng(99)
+    g = np.arange(0, 10, dtype=np.float32) * 0.3
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    lattice = np.concatenate([lattice, lattice[::7]])
+    cases = {
+        "cylinder": (h.scene_cylinder(6000, seed=15, noise=0.01), 1.0),
+        "fixture": (h.cylinder_cloud(), 1.0),
+        "lattice_dups": (lattice, 0.7),
+        "far_corridor": ((h.scene_corridor(8000, seed=16, length=20.0).astype(np.float64) + np.array([3.0e4, -2.0e4, 500.0])).astype(np.float32), 0.8),
+        "planes": (h.scene_planes(9000, seed=3), 0.6),
+    }
+    served_total = 0
+    for name, (tgt, radius) in cases.items():
+        src = (tgt[::2] + rng.normal(0, 0.004, tgt[::2].shape)).astype(np.float32)
+        if name == "lattice_dups":
+            src = (tgt[::3] + np.float32(0.11)).astype(np.float32)
+        idx, tree = emul.Index(tgt, radius), po.KdTree(tgt)
+        idx.set_team(True)
+        St, Sf = emul.Source(src), emul.Source(src)
+        c = src.astype(np.float64).mean(axis=0)
+        T = np.eye(4)
+        steps = [1e-6, 1e-4, 1e-3, 3e-3, -3e-3, 1e-2, 2e-2, 1e-5, 4e-2, -4e-2, 1e-3, 8e-2, 1e-6, 5e-3, 0.15, 1e-4, 1e-3]
+        for k, sz in enumerate(steps):
+            ang = sz / max(np.linalg.norm(src.astype(np.float64) - c, axis=1).max(), 1.0)
+            dT = h.pose6d_matrix(sz * 0.6, -sz * 0.3, sz * 0.2, ang * 0.5, -ang * 0.3, ang)
+            shift = np.eye(4); shift[:3, 3] = c
+            T = shift @ dT @ np.linalg.inv(shift) @ T
+            x = emul.linearize(idx, St, T[:3, :3], T[:3, 3], radius=radius, wd=1, plan="cert", debug=True)
+            idx.set_team(False)
+            y = emul.linearize(idx, Sf, T[:3, :3], T[:3, 3], radius=radius, wd=1, plan="full")
+            idx.set_team(True)
+            ref = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(radius, 1), debug=True)
+            loose = name in ("far_corridor", "lattice_dups")
+            assert_same(x, ref, normals_atol=1e-4 if loose else 1e-8, h_rtol=1e-6 if loose else 1e-11)
+            assert x["n_eff"] == y["n_eff"] and np.array_equal(x["H_upper"], y["H_upper"]) and np.array_equal(x["g"], y["g"]), (name, k)
+        served_total += idx.team_served()
+    assert served_total > 20_000                 # the team did take most of the searches of these walks
+
+
+def test_team_rows_cover_the_ball():
+    """team_row (the cell-table phase of one row, run-time offsets): every target point closer than the bound lies in one of the nine
+    intervals whenever team_bound calls the query tight - checked through the full replay above; here the complementary property:
+    with the team on, a "cert" walk searches exactly the points the walk without it searches (certificates are as strong)."""
+    tgt = h.scene_cylinder(5000, seed=21, noise=0.01)
+    src = (tgt[::2] + np.random.default_rng(5).normal(0, 0.004, tgt[::2].shape)).astype(np.float32)
+    idx = emul.Index(tgt, 1.0)
+    Sa, Sb = emul.Source(src), emul.Source(src)
+    T = np.eye(4)
+    tot_a = tot_b = 0
+    for k, sz in enumerate([1e-5, 1e-3, 5e-3, 1e-3, 1e-2, 1e-4, 2e-3]):
+        T = h.pose6d_matrix(sz, -sz * 0.5, sz * 0.25, 0.0, 0.0, sz * 0.1) @ T
+        idx.set_team(True)
+        a = emul.linearize(idx, Sa, T[:3, :3], T[:3, 3], wd=1, plan="cert")
+        idx.set_team(False)
+        b = emul.linearize(idx, Sb, T[:3, :3], T[:3, 3], wd=1, plan="cert")
+        assert np.array_equal(a["H_upper"], b["H_upper"]) and a["n_eff"] == b["n_eff"]
+        tot_a += a["searched"]; tot_b += b["searched"]
+    # the team's seventh-neighbour bound is exact, the lock-step search's a lower bound of it: the team never searches more
+    assert tot_a <= tot_b, (tot_a, tot_b)
+
+
 def test_knn_with_ties_duplicates_and_outside_queries():
     g = np.arange(0, 12, dtype=np.float32) * 0.25
     tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
