@@ -629,12 +629,17 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     const bool fast = c->opt_fast_plane;
+    const bool lean = false;
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
     hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
                        S.d_partials, nbx, fin, dd, abort_flag)
         if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
+        else if (lean) {
+            if (fast) hipLaunchKernelGGL((k_lin<0, true, true, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
+            else hipLaunchKernelGGL((k_lin<0, true, false, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
+        }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
         else { if (fast) DCREG_LAUNCH_LIN(0, false, true); else DCREG_LAUNCH_LIN(0, false, false); }
 #undef DCREG_LAUNCH_LIN

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "search.hpp"
 
@@ -275,12 +276,13 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
 }
 
 // ---- the common tail of a block: the wave's rows -> its Gram matrix and counts in LDS (the wave's LDS staging area must be free) ...
-__device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t flag, double *stage, double (*red)[kSlots], double (*cnt)[2],
+// gm: where this wave's 8x8 Gram matrix goes (64 doubles; may be the head of its own staging area: the operand reads are over by then)
+__device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t flag, double *stage, double *gm, double (*cnt)[2],
                                                  double extra0 = 0.0, double extra1 = 0.0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double u0, u1;
     wave_gram_mfma(row, stage, lane, u0, u1);
-    double *gm = &red[0][0] + wave * 64;            // the wave's Gram matrix, M[a][b] at a * 8 + b
+    // (the wave's Gram matrix, M[a][b] at a * 8 + b)
     if ((lane & 15) < 8) {
         gm[(lane >> 4) * 8 + (lane & 7)] = u0;
         gm[32 + (lane >> 4) * 8 + (lane & 7)] = u1;
@@ -291,15 +293,17 @@ __device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t
 }
 // ... and, after a block barrier: the block partial (fixed order, no float atomics) and, for single-pose launches, the arrival at
 // the chunk's ticket: the last of its blocks sums the chunk and publishes the row to the host.  All 256 threads call.
+// gm0 / gm_stride: the waves' Gram matrices (wave w at gm0 + w * gm_stride); red: kLinBlock / 32 x kSlots doubles of scratch for the chunk
+// sum (may overlap the Gram matrices: they are consumed before)
 template <bool FUSED>
-__device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cnt)[2], int *s_role, double *my_rows, uint32_t vb,
+__device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, double (*red)[kSlots], double (*cnt)[2], int *s_role, double *my_rows, uint32_t vb,
                                               uint32_t n_blocks_x, const FinArgs &fin) {
     if (threadIdx.x < kSlots) {
         double t = 0.0;
         if (threadIdx.x < 29) {
             const int e = gram_entry_of_slot(threadIdx.x);
 #pragma unroll
-            for (int w = 0; w < kLinBlock / 64; ++w) t += (&red[0][0])[w * 64 + e];
+            for (int w = 0; w < kLinBlock / 64; ++w) t += gm0[w * gm_stride + e];
         } else if (threadIdx.x < 31) {
 #pragma unroll
             for (int w = 0; w < kLinBlock / 64; ++w) t += cnt[w][threadIdx.x - 29];
@@ -332,16 +336,44 @@ __device__ __forceinline__ void block_publish(double (*red)[kSlots], double (*cn
 }
 
 // ---------------------------------------------------------------- k_lin
-template <int MODE, bool FUSED, bool FAST>
-static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+// LEAN: the instantiation for launches in which (nearly) every certificate is expected to hold - what the host picks once the last
+// launch searched next to nothing (context.hip linearize_begin).  Compiled for twice the waves per SIMD (half the registers), with a
+// per-wave LDS of 4.6 KB instead of 9.3 KB: a settled launch is a stream of 72 B per point and streams at what its occupancy allows
+// (profiles/r03_stream_microbench.txt: 21 us at 4 waves per SIMD, 13.7 us at 8, for 1 M points).  Same levels, same code for levels
+// 2 and 3 (the plane fit spills under the smaller budget - a few hundred points per launch pay that), but level 1 only as the team
+// search: a point the team cannot take (no six old neighbours, a ball beyond its 27-cell block, more than 64 points inside the bound)
+// POISONS the launch - its row carries a NaN into the sums, its state is left alone - and the host, seeing the NaN, runs the same
+// linearisation again with the full kernel (context.hip linearize_end).  Every point the lean launch did serve got exactly what the
+// full kernel gives it, so the second launch finds their certificates in place and the sums it returns are the usual ones.
+#if !defined(DCREG_LEAN_OCC)
+#define DCREG_LEAN_OCC 8
+#endif
+template <int MODE, bool FUSED, bool FAST, bool LEAN = false>
+static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
-    __shared__ double red[kLinBlock / 32][kSlots];
+    using WaveLds = typename std::conditional<LEAN, LeanList, RunList>::type;
     __shared__ double cnt[kLinBlock / 64][2];
     __shared__ int s_role;
-    __shared__ RunList runs[kLinBlock / kWave];
+    __shared__ WaveLds runs[kLinBlock / kWave];
+    // the waves' Gram matrices and the scratch of the chunk sum: an array of their own, or (LEAN: every byte of LDS is occupancy) the
+    // waves' staging areas once the operands have been read from them
+    double (*red)[kSlots];
+    const double *gm0;
+    int gm_stride;
+    if constexpr (LEAN) {
+        static_assert(sizeof(WaveLds) >= sizeof(double) * (kLinBlock / 32) * kSlots, "the chunk sum's scratch must fit one staging area");
+        red = reinterpret_cast<double (*)[kSlots]>(&runs[0].stage[0]);
+        gm0 = &runs[0].stage[0];
+        gm_stride = (int)(sizeof(WaveLds) / sizeof(double));
+    } else {
+        __shared__ double red_[kLinBlock / 32][kSlots];
+        red = red_;
+        gm0 = &red_[0][0];
+        gm_stride = 64;
+    }
     const int wave = threadIdx.x >> 6;
     const uint32_t pose_id = blockIdx.y;
     uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
@@ -385,6 +417,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
+    bool poisoned = false;                          // LEAN: this lane needed a search the team could not give it
     KnnResult<5> nn;
     Fit fit;
     uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
@@ -413,6 +446,29 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
 #pragma unroll
                 for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
             }
+            if constexpr (LEAN) {
+                // level 1 of the lean kernel: the team, seven queries at a time; what it cannot take poisons the launch
+                float tb = 0.f;
+                bool tight = false;
+                if (warm && need && pos6[5] != kNoIdx) tb = team_bound(g, a, pos6, qx, qy, qz, tight);
+                bool served = false;
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(need && tight);
+                while (todo != 0ull) {
+                    unsigned long long sub = 0ull, m = todo;
+#pragma unroll 1
+                    for (int k = 0; k < kTeamMax && m != 0ull; ++k) { sub |= m & (0ull - m); m &= m - 1ull; }
+                    todo &= ~sub;
+                    uint32_t tpos[6], tcert;
+                    const unsigned long long ok = team_search6(g, runs[wave].team, a, sub, qx, qy, qz, tb, tpos, tcert);
+                    if (((ok >> (threadIdx.x & 63)) & 1ull) != 0ull) {
+                        served = true;
+                        cert = tcert;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) pos6[j] = tpos[j];
+                    }
+                }
+                poisoned = need && !served;
+            } else {
             bool by_team = false;                   // uniform: the team served every lane that had to be searched
             // a wave with a few lanes to search, each of them near its old neighbours: the 64 lanes serve one query at a time
             if (warm && w_search <= (uint32_t)a.team_max) {
@@ -421,7 +477,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
                 if (need && pos6[5] != kNoIdx) tb = team_bound(g, a, pos6, qx, qy, qz, tight);
                 if (!wave_any(need && !tight)) {
                     uint32_t tpos[6], tcert;
-                    by_team = team_search6(g, runs[wave], a, need_mask, qx, qy, qz, tb, tpos, tcert) == need_mask;
+                    by_team = team_search6(g, runs[wave].team, a, need_mask, qx, qy, qz, tb, tpos, tcert) == need_mask;
                     if (a.search_count && by_team && (threadIdx.x & 63) == 0)      // (statistics: the word next to the search counter)
                         atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2) + 1, (unsigned long long)w_search);
                     if (by_team && need) {
@@ -443,13 +499,14 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
                     stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
                 }
             }
-            if (need && keep) {
+            }
+            if (need && keep && !poisoned) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = pos6[j];
             }
         }
         // level 2 for the lanes that were searched and the lanes whose order may have changed
-        const bool set = have_q && !cert_is_out(cert);
+        const bool set = have_q && !cert_is_out(cert) && !poisoned;
         const bool fitnow = set && (need || refit);
         w_refit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fitnow && !need));
         if (wave_any(fitnow)) {
@@ -486,7 +543,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             fitw = st[10 * ss];
             stored_plane(w2);
         }
-        if (!set && need && keep) {                 // searched and found OUT: certificate and reference position, no fit
+        if (!set && need && keep && !poisoned) {    // searched and found OUT: certificate and reference position, no fit
             st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
             st[10 * ss] = kFitNone;
         }
@@ -496,6 +553,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
         else flag = gate == 255 ? (uint8_t)0 : gate;
     }
+    if (LEAN && poisoned) row[7] = __builtin_nan("");      // -> sum r^2 and every product with this row: the host runs the full kernel
     if (MODE == 1 && have_q) {                      // (debug launches search and fit every point: nn is this launch's list)
         const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
@@ -512,9 +570,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         if (dbg.stats) dbg.stats[oi] = stats;
     }
     // (the wave's RunList is free now: it stages the rows)
-    wave_rows_to_lds(row, flag, runs[wave].stage, red, cnt, a.count_scale * (double)w_search, a.count_scale * (double)w_refit);
+    wave_rows_to_lds(row, flag, runs[wave].stage, const_cast<double *>(gm0) + wave * gm_stride, cnt, a.count_scale * (double)w_search,
+                     a.count_scale * (double)w_refit);
     __syncthreads();
-    block_publish<FUSED>(red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
+    block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
 }
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused

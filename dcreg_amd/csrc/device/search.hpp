@@ -370,6 +370,13 @@ struct alignas(16) RunList {
         TeamLds team;
     };
 };
+// the per-wave LDS of the lean instantiation of k_lin (kernels.hpp): no run list, no pending list - its searches are team searches
+struct alignas(16) LeanList {
+    union {
+        double stage[kWave * kRowStride];
+        TeamLds team;
+    };
+};
 DCREG_DEVFN bool wave_any(bool x) {
 #if DCREG_ON_DEVICE
     return __builtin_amdgcn_ballot_w64(x) != 0ull;
@@ -1407,10 +1414,9 @@ DCREG_DEVFN float shfl_f(float v, int src) { return __uint_as_float((uint32_t)__
 // team_mask: the lanes (at most kTeamMax) whose queries (qx, qy, qz, bound: valid in those lanes) are searched.  Returns the lanes
 // that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound) and
 // the certificate of the search (make_cert).
-DCREG_DEVFN unsigned long long team_search6(const GridDev &g, RunList &rl, const LinArgs &a, unsigned long long team_mask, float qx, float qy,
+DCREG_DEVFN unsigned long long team_search6(const GridDev &g, TeamLds &T, const LinArgs &a, unsigned long long team_mask, float qx, float qy,
                                             float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out) {
     const int lane = threadIdx.x & (kWave - 1);
-    TeamLds &T = rl.team;
     // ---- the rows of all queries: lane 9 k + r = row r of the k-th query
     const int k_of = lane / 9, r_of = lane - 9 * k_of;
     int src = 0;

