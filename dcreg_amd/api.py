@@ -44,12 +44,13 @@ class LinOut(C.Structure):
 class LinDebug(C.Structure):
     _fields_ = [("nn_idx", C.POINTER(C.c_int32)), ("nn_d2", C.POINTER(C.c_float)),
                 ("flag", C.POINTER(C.c_uint8)), ("normal", C.POINTER(C.c_double)),
-                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double)), ("stats", C.POINTER(C.c_uint32))]
+                ("r", C.POINTER(C.c_double)), ("s", C.POINTER(C.c_double)), ("stats", C.POINTER(C.c_uint32)),
+                ("stamps", C.POINTER(C.c_uint64))]
 
 
 class LaunchStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("poses", C.c_int64), ("points", C.c_int64), ("points_searched", C.c_int64),
-                ("points_team", C.c_int64)]
+                ("points_team", C.c_int64), ("lean_launches", C.c_int64), ("lean_redone", C.c_int64)]
 
 
 class IndexInfo(C.Structure):
@@ -424,6 +425,21 @@ class Context:
         d = self._out_dict(out)
         d.update(keep)
         return d
+
+    def linearize_stamped(self, R, t, params=None):
+        """timing probe (dcreg_debug.h dcreg_lin_debug::stamps): a plain linearisation (certificates in use) whose waves record shader-clock
+        stamps at their phase boundaries -> (sums dict, stamps [n_waves, 8] uint64: t_start, t_loaded, t_searched, t_fitted, t_row, t_reduced,
+        lanes searched, lanes refitted; waves that skipped a phase leave its stamp 0)"""
+        params = params or default_lin_params()
+        R, t = _f64(R, 9), _f64(t, 3)
+        out = LinOut()
+        n = self.index_info().n_source
+        nw = 4 * ((n + 255) // 256)
+        st = np.zeros((nw, 8), np.uint64)
+        dbg = LinDebug()
+        dbg.stamps = st.ctypes.data_as(C.POINTER(C.c_uint64))
+        self._check(self._L.dcreg_linearize_debug(self._h, _dp(R), _dp(t), C.byref(params), C.byref(out), C.byref(dbg)), "dcreg_linearize_debug")
+        return self._out_dict(out), st
 
     def linearize_raw(self, R, t, params, out):
         """Hot-loop variant: caller-owned float64 arrays / structs, no allocation."""

@@ -428,8 +428,12 @@ static int estimate_dispatch_order(dcreg_ctx *c, const double *R9, const double 
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
 // _gate_abort decide its fate)
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
-                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host, bool gated = false) {
+                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host, bool gated = false, bool force_full = false) {
     if (!c) return DCREG_E_INVALID;
+    static_assert(sizeof(dcreg_lin_params) <= sizeof(dcreg_lin_params_copy::bytes), "dcreg_lin_params_copy is too small");
+    // a timing probe, not a dump (dcreg_debug.h dcreg_lin_debug::stamps): certificates in use, only the stamps come back
+    const bool stamps_only = dbg_host && dbg_host->stamps && !dbg_host->nn_idx && !dbg_host->nn_d2 && !dbg_host->flag && !dbg_host->normal &&
+                             !dbg_host->r && !dbg_host->s && !dbg_host->stats;
     // nothing may be queued behind a gate that still waits: it would wait with it
     if (c->gate_slot >= 0) { c->fail("a gated linearisation still waits for its pose (dcreg_linearize_gate_open / _gate_abort first)"); return DCREG_E_STATE; }
     if (gated) {
@@ -583,7 +587,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         d_poses = (const PoseArg *)S.d_poses;
         if (use_states) { a.state = c->d_state_batch; a.state_stride = (uint32_t)c->state_batch_stride; }
     }
-    a.use_cert = (dbg_host || !c->opt_use_cert) ? 0 : 1;          // a debug dump searches every point (its statistics are those of the searches)
+    a.use_cert = ((dbg_host && !stamps_only) || !c->opt_use_cert) ? 0 : 1;   // a debug dump searches every point (its statistics are those of the searches)
     a.search_count = c->opt_count_searches ? c->d_search_count : nullptr;
     DebugDev dd{};
     free_tmp(S);
@@ -603,13 +607,15 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (dbg_host->r) dd.r = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->s) dd.s = (double *)alloc(sizeof(double) * n, 0);
         if (dbg_host->stats) dd.stats = (uint32_t *)alloc(sizeof(uint32_t) * n, 0);
+        if (dbg_host->stamps) dd.stamps = (unsigned long long *)alloc(sizeof(unsigned long long) * 8 * (kLinBlock / 64) * (size_t)nbx, 0);
         if (oom) { free_tmp(S); drop_warm(c); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
     FinArgs fin{S.d_tickets, S.d_out, seq, direct ? 1u : 0u};
     if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
     // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
-    const bool timed = slot == 0 && c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
+    bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
+    if (timed && !S.ev0) timed = hipEventCreate(&S.ev0) == hipSuccess && hipEventCreate(&S.ev1) == hipSuccess;
     const uint32_t *abort_flag = nullptr;
     // a launch that was queued and must not run after all (errors below): call the gate off, forget what the states were about to hold
     auto bail = [&](const char *what, hipError_t e) {
@@ -625,17 +631,26 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         abort_flag = c->d_gate_abort;
     }
     if (timed) {                           // after the gate: the events bracket the linearisation, not the wait for the pose
-        const hipError_t ee = hipEventRecord(c->ev0, c->stream);
+        const hipError_t ee = hipEventRecord(S.ev0, c->stream);
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     const bool fast = c->opt_fast_plane;
-    const bool lean = false;
+    // the lean instantiation (kernels.hpp k_lin<.., LEAN>): a single-pose launch of more query blocks than the device holds at once,
+    // on a state whose last launch - of this very cloud - searched and refitted next to nothing.  A lean launch that meets a point it
+    // cannot serve says so in its sums (NaN) and is run again in full (linearize_end).
+    const bool lean = c->opt_lean && !force_full && fused && !direct && (!dbg_host || stamps_only) && uses_state && one.fresh == 0u && a.use_cert != 0 &&
+                      a.warm != 0 && nbx > 4u * (uint32_t)c->n_cus && c->last_points == n && c->last_searched >= 0 && c->last_refitted >= 0 &&
+                      (double)c->last_searched * c->opt_lean_search_div <= (double)n && (double)c->last_refitted * c->opt_lean_refit_div <= (double)n;
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
     hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
                        S.d_partials, nbx, fin, dd, abort_flag)
-        if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
+        if (stamps_only) {
+            if (lean) hipLaunchKernelGGL((k_lin<2, true, true, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
+            else DCREG_LAUNCH_LIN(2, true, true);
+        }
+        else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (lean) {
             if (fast) hipLaunchKernelGGL((k_lin<0, true, true, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
             else hipLaunchKernelGGL((k_lin<0, true, false, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
@@ -654,7 +669,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (le != hipSuccess) return bail("k_finalize launch", le);
     }
     if (timed) {                           // brackets the linearisation's kernels
-        const hipError_t ee = hipEventRecord(c->ev1, c->stream);
+        const hipError_t ee = hipEventRecord(S.ev1, c->stream);
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     if (dbg_host) {
@@ -667,6 +682,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         back(dbg_host->r, dd.r, sizeof(double) * n);
         back(dbg_host->s, dd.s, sizeof(double) * n);
         back(dbg_host->stats, dd.stats, sizeof(uint32_t) * n);
+        back(dbg_host->stamps, dd.stamps, sizeof(unsigned long long) * 8 * (kLinBlock / 64) * (size_t)nbx);
         if (ce != hipSuccess) {
             (void)hipStreamSynchronize(c->stream);
             return bail("copying the debug dump back", ce);
@@ -676,6 +692,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (uses_state) c->state_valid = true;          // once this launch has run, the state holds a search of the current clouds
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
+    S.lean = lean; S.stamps_only = stamps_only;
+    if (lean) {
+        c->n_lean_launches += 1;
+        std::memcpy(S.prm.bytes, p, sizeof(*p)); S.prm.set = true;
+        if (!gated) { std::memcpy(S.R, R9, sizeof(S.R)); std::memcpy(S.t, t3, sizeof(S.t)); }       // (gated: dcreg_linearize_gate_open)
+    }
     if (gated) {
         c->gate_slot = slot;
         c->gate_uses_state = uses_state; c->gate_state_was_valid = state_was_valid;
@@ -762,8 +784,8 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
     float launch_ms = -1.f;
     if (S.timed) {
         float ms = 0.f;
-        hipError_t te = hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        if (te == hipErrorNotReady) { HIP_TRY(c, hipEventSynchronize(c->ev1)); te = hipEventElapsedTime(&ms, c->ev0, c->ev1); }
+        hipError_t te = hipEventElapsedTime(&ms, S.ev0, S.ev1);
+        if (te == hipErrorNotReady) { HIP_TRY(c, hipEventSynchronize(S.ev1)); te = hipEventElapsedTime(&ms, S.ev0, S.ev1); }
         HIP_TRY(c, te);
         c->kernel_ms_total += ms; c->kernel_launches += 1;
         launch_ms = ms;
@@ -787,6 +809,19 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
             const double *row = S.h_rows.data() + (size_t)ch * kSlots;
             for (int k = 0; k < 31; ++k) total[k] += row[k];
         }
+    }
+    if (S.lean && S.fused && std::isnan(total[27])) {
+        // the lean kernel met a point whose search it cannot do (kernels.hpp): the same linearisation again, in full.  Nothing may wait
+        // behind a gate meanwhile (the caller's next launch: the engine then starts it the plain way).
+        c->n_lean_redone += 1;
+        if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);
+        dcreg_lin_params prm;
+        std::memcpy(&prm, S.prm.bytes, sizeof(prm));
+        double R[9], t[3];
+        std::memcpy(R, S.R, sizeof(R)); std::memcpy(t, S.t, sizeof(t));
+        rc = linearize_begin(c, slot, 1, R, t, nullptr, &prm, nullptr, false, true);
+        if (rc != DCREG_OK) return rc;
+        return linearize_end(c, slot, outs);
     }
     // the count slots carry two numbers each when the launch was asked to report what it did (LinArgs::count_scale): exact integers
     const bool coded = c->n_src <= ((int64_t)1 << 26);
@@ -932,6 +967,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
         for (void *b : S.tmp_dev) (void)hipFree(b);
+        if (S.ev0) (void)hipEventDestroy(S.ev0);
+        if (S.ev1) (void)hipEventDestroy(S.ev1);
         if (S.h_out) (void)hipHostFree(S.h_out);
         if (S.h_poses) (void)hipHostFree(S.h_poses);
     }
@@ -976,6 +1013,9 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
+    else if (k == "lean_kernel") c->opt_lean = v != 0.0;          // kernels.hpp k_lin<.., LEAN> for launches expected to search next to nothing
+    else if (k == "lean_search_div") c->opt_lean_search_div = v > 1.0 ? v : 1.0;
+    else if (k == "lean_refit_div") c->opt_lean_refit_div = v > 1.0 ? v : 1.0;
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host
@@ -1033,6 +1073,7 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
 int dcreg_hint_misalignment(dcreg_ctx *c, double metres) {
     if (!c) return DCREG_E_INVALID;
     c->hint_misalign = metres >= 0.0 ? metres : 1e300;       // (NaN: no knowledge)
+    if (!(metres >= 0.0)) c->last_searched = -1;             // ... about the next pose either: the next launch is a full one
     return DCREG_OK;
 }
 int dcreg_reset_warm_state(dcreg_ctx *c, int64_t state_id) {
@@ -1049,6 +1090,10 @@ int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
     gate_publish(c, c->gate_seq << 1, R, t);
+    {   // (kept with the slot: a lean launch may have to be run again with this pose)
+        LinSlot &S = c->slots[c->gate_slot];
+        std::memcpy(S.R, R, sizeof(S.R)); std::memcpy(S.t, t, sizeof(S.t));
+    }
     c->gate_slot = -1;
     return DCREG_OK;
 }
@@ -1098,6 +1143,7 @@ int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
     if (!c || !st) return DCREG_E_INVALID;
     st->launches = c->n_launches; st->poses = c->n_poses_launched; st->points = c->n_points_launched;
     st->points_searched = -1; st->points_team = -1;
+    st->lean_launches = c->n_lean_launches; st->lean_redone = c->n_lean_redone;
     if (c->opt_count_searches && c->d_search_count) {      // synchronous: every launch so far has finished when this returns
         std::vector<unsigned long long> v(kSearchCountBytes / sizeof(unsigned long long));
         HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_search_count, kSearchCountBytes, hipMemcpyDeviceToHost, c->stream));
@@ -1108,7 +1154,7 @@ int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
         st->points_team = (int64_t)team;
         if (reset) HIP_TRY(c, hipMemsetAsync(c->d_search_count, 0, kSearchCountBytes, c->stream));
     }
-    if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; }
+    if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; c->n_lean_launches = 0; c->n_lean_redone = 0; }
     return DCREG_OK;
 }
 

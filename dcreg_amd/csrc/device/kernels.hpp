@@ -147,6 +147,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n, uint32_t c
 struct DebugDev {
     int32_t *nn_idx; float *nn_d2; uint8_t *flag; double *normal; double *r; double *s;
     uint32_t *stats;   // per point: candidates evaluated | outermost shell << 16
+    unsigned long long *stamps;   // MODE 2: per wave (query block x 4 + wave) eight words - shader-clock stamps at the phase boundaries of
+                                  // k_lin (start, state loaded + tests, search done, fit done, row done, reduction done) and the wave's
+                                  // searched / refitted lane counts (scripts/wave_phases.py)
 };
 
 // Single-pose launches finish inside the kernel (no second launch): blocks are grouped in chunks of kChunk consecutive
@@ -346,7 +349,7 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
 // linearisation again with the full kernel (context.hip linearize_end).  Every point the lean launch did serve got exactly what the
 // full kernel gives it, so the second launch finds their certificates in place and the sums it returns are the usual ones.
 #if !defined(DCREG_LEAN_OCC)
-#define DCREG_LEAN_OCC 8
+#define DCREG_LEAN_OCC 5
 #endif
 template <int MODE, bool FUSED, bool FAST, bool LEAN = false>
 static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
@@ -386,27 +389,35 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
         }
     }
     const uint32_t i = vb * kLinBlock + threadIdx.x;
+    auto stamp = [&](int k, unsigned long long v) {       // MODE 2 only (timing probe): one store by lane 0, nothing kept in registers
+        if constexpr (MODE == 2) {
+            if ((threadIdx.x & 63) == 0 && dbg.stamps) dbg.stamps[((size_t)vb * (kLinBlock / 64) + wave) * 8 + k] = v;
+        }
+    };
+    stamp(0, __builtin_readcyclecounter());
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
-    double row[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) row[k] = 0.0;
     uint8_t flag = 0;
     const bool have_q = i < n_src;
     const bool keep = a.state != nullptr && P.state != kNoIdx;              // the pose owns a state
     const bool old = keep && P.fresh == 0u;                                 // ... that holds the results of earlier launches
     const bool CERT = old && a.use_cert != 0;                               // ... whose certificates are to be used (uniform)
-    uint32_t *st = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride + i : nullptr;
+    // the groups of this pose's state (search.hpp kStateRows: V0, V1, V2, W3 = what the fast path reads; X, Y = the six positions)
+    uint32_t *const sbase = keep ? a.state + (size_t)P.state * kStateRows * a.state_stride : nullptr;
     const size_t ss = a.state_stride;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    uint4 *const SV0 = reinterpret_cast<uint4 *>(sbase + kStV0 * ss), *const SX = reinterpret_cast<uint4 *>(sbase + kStX * ss);
+    dbl2 *const SV1 = reinterpret_cast<dbl2 *>(sbase + kStV1 * ss), *const SV2 = reinterpret_cast<dbl2 *>(sbase + kStV2 * ss);
+    uint32_t *const SW3 = sbase + kStW3 * ss;
+    uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     // what the fast path needs, in one batch of loads: certificate, reference position, fit word, plane (56 B + the 16 B of the point)
-    uint32_t cert = kCertSearch, fitw = kFitNone, q0[3] = {0u, 0u, 0u}, pw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t cert = kCertSearch, fitw = kFitNone, q0[3] = {0u, 0u, 0u};
+    dbl2 p01 = {0.0, 0.0}, p23 = {0.0, 0.0};
     if (CERT && have_q) {
-        cert = st[6 * ss]; fitw = st[10 * ss];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) q0[k] = st[(size_t)(7 + k) * ss];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pw[k] = st[(size_t)(11 + k) * ss];
+        const uint4 v0 = SV0[i];
+        p01 = SV1[i]; p23 = SV2[i];
+        cert = v0.x; fitw = v0.y; q0[0] = v0.z; q0[1] = v0.w; q0[2] = SW3[i];
     }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
@@ -422,20 +433,38 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
     Fit fit;
     uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
     const bool level3 = have_q && !need && !refit && !cert_is_out(cert);
-    auto stored_plane = [&](const uint32_t (&w)[8]) {
+    auto stored_plane = [&](const dbl2 &a01, const dbl2 &a23) {
         gate = (uint8_t)(fitw & 3u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fit.plane[k] = __longlong_as_double((long long)(((unsigned long long)w[2 * k + 1] << 32) | w[2 * k]));
+        fit.plane[0] = a01.x; fit.plane[1] = a01.y; fit.plane[2] = a23.x; fit.plane[3] = a23.y;
     };
+    double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
+    double row[8];
+    // the row from the plane: called at the end of EITHER branch below (two copies of ~150 instructions), so that the plane words of
+    // the fast path die inside its own block - as one tail after the join they were live around the whole search in the allocator's
+    // eyes, and a pair of them went through scratch on the path that does nothing else
+    auto make_row = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = 0.0;
+        if (have_q) {
+            if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
+            else flag = gate == 255 ? (uint8_t)0 : gate;
+        }
+    };
+    if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(1, __builtin_readcyclecounter()); }
     if (!wave_any(need || refit)) {
         // the whole wave is at level 3 (or OUT): the plane words loaded up front are all it needs.  (They are consumed HERE and not
         // below: kept alive across the search they would cost a dozen registers at its peak, i.e. scratch spills; the waves that do
         // search load them a second time afterwards - from the cache.)
-        if (level3) stored_plane(pw);
+        if (level3) stored_plane(p01, p23);
+        make_row();
     } else {
         uint32_t pos6[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
+        // the index the state WRITES of this branch are addressed with: the same number behind a compiler barrier, so that their
+        // addresses are formed where they are used (kept from the top of the kernel, five 64-bit addresses ride through the search)
+        uint32_t iw = i;
+        asm volatile("" : "+v"(iw));
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
         w_search = (uint32_t)__builtin_popcountll(need_mask);
         if (need_mask != 0ull) {
@@ -443,8 +472,9 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
                 atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)__builtin_popcountll(need_mask));
             const bool warm = old && a.warm != 0;
             if (warm && need) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
+                const uint4 x = SX[i];
+                const uint2 y = SY[i];
+                pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
             }
             if constexpr (LEAN) {
                 // level 1 of the lean kernel: the team, seven queries at a time; what it cannot take poisons the launch
@@ -501,10 +531,11 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
             }
             }
             if (need && keep && !poisoned) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = pos6[j];
+                SX[iw] = make_uint4(pos6[0], pos6[1], pos6[2], pos6[3]);
+                SY[iw] = make_uint2(pos6[4], pos6[5]);
             }
         }
+        if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2, __builtin_readcyclecounter()); stamp(6, (unsigned long long)w_search); }
         // level 2 for the lanes that were searched and the lanes whose order may have changed
         const bool set = have_q && !cert_is_out(cert) && !poisoned;
         const bool fitnow = set && (need || refit);
@@ -516,43 +547,40 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
             const bool six = wave_any(use6);
             const bool presorted = !wave_any(fitnow && !need);     // every lane that fits was searched just now: its six are in order
             if (fitnow && !need) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) pos6[j] = (j < 5 || use6) ? st[(size_t)j * ss] : kNoIdx;
+                const uint4 x = SX[iw];
+                const uint2 y = SY[iw];
+                pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
             }
             if (!use6) pos6[5] = kNoIdx;
             if (fitnow) {
                 const uint8_t in_r = fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted);
                 gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
                 if (keep) {                         // the new reference position, the certificate as seen from there, the fit
-                    if (!need)                      // (the old reference position is read again: three registers less across the search)
-                        cert = cert_rebased(cert, __uint_as_float(st[7 * ss]), __uint_as_float(st[8 * ss]), __uint_as_float(st[9 * ss]), qx, qy, qz);
-                    st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
-                    st[10 * ss] = fit.word;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned long long b = (unsigned long long)__double_as_longlong(fit.plane[k]);
-                        st[(size_t)(11 + 2 * k) * ss] = (uint32_t)b; st[(size_t)(12 + 2 * k) * ss] = (uint32_t)(b >> 32);
+                    if (!need) {                    // (the old reference position is read again: three registers less across the search)
+                        const uint4 o0 = SV0[iw];
+                        const uint32_t o1 = SW3[iw];
+                        cert = cert_rebased(cert, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz);
                     }
+                    SV0[iw] = make_uint4(cert, fit.word, __float_as_uint(qx), __float_as_uint(qy));
+                    SV1[iw] = dbl2{fit.plane[0], fit.plane[1]};
+                    SV2[iw] = dbl2{fit.plane[2], fit.plane[3]};
+                    SW3[iw] = __float_as_uint(qz);
                 }
             }
         }
+        if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3, __builtin_readcyclecounter()); stamp(7, (unsigned long long)w_refit); }
         if (level3) {                               // the lanes of this wave that needed neither: their stored plane, loaded again
-            uint32_t w2[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w2[k] = st[(size_t)(11 + k) * ss];
-            fitw = st[10 * ss];
-            stored_plane(w2);
+            const dbl2 b01 = SV1[iw], b23 = SV2[iw];
+            fitw = reinterpret_cast<const uint32_t *>(SV0 + iw)[1];
+            stored_plane(b01, b23);
         }
         if (!set && need && keep && !poisoned) {    // searched and found OUT: certificate and reference position, no fit
-            st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
-            st[10 * ss] = kFitNone;
+            SV0[iw] = make_uint4(cert, kFitNone, __float_as_uint(qx), __float_as_uint(qy));
+            SW3[iw] = __float_as_uint(qz);
         }
+        make_row();
     }
-    double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
-    if (have_q) {
-        if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
-        else flag = gate == 255 ? (uint8_t)0 : gate;
-    }
+    stamp(4, __builtin_readcyclecounter());
     if (LEAN && poisoned) row[7] = __builtin_nan("");      // -> sum r^2 and every product with this row: the host runs the full kernel
     if (MODE == 1 && have_q) {                      // (debug launches search and fit every point: nn is this launch's list)
         const uint32_t oi = __float_as_uint(s4.w);
@@ -572,6 +600,7 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
     // (the wave's RunList is free now: it stages the rows)
     wave_rows_to_lds(row, flag, runs[wave].stage, const_cast<double *>(gm0) + wave * gm_stride, cnt, a.count_scale * (double)w_search,
                      a.count_scale * (double)w_refit);
+    stamp(5, __builtin_readcyclecounter());
     __syncthreads();
     block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
 }

@@ -93,8 +93,26 @@ struct PoseArg {
 // Nothing of a state changes between two searches of a query, and the test is on the two stored float positions themselves (their
 // difference is exact), so neither the length of a trajectory nor the rounding of the float store wears a certificate down.
 //                                 row 10: the FIT word, rows 11-18: the plane of the last fit (four doubles as eight words): FitCert below
+// IN MEMORY the nineteen words of a point are grouped so that a lane fetches them with five wide loads instead of nineteen narrow ones
+// (every load in flight holds a 64-bit address in two registers: thirteen of them at the top of the kernel were the largest single
+// block of its register budget).  With S = stride (words per row, a multiple of 64) one state is 19 S words:
+//     V0 [S] x 16 B : certificate (row 6), fit word (10), q0.x (7), q0.y (8)
+//     V1 [S] x 16 B : plane[0], plane[1] as two doubles (rows 11-14): they land in aligned register pairs, nothing to assemble
+//     V2 [S] x 16 B : plane[2], plane[3] (rows 15-18)
+//     W3 [S] x  4 B : q0.z (row 9)                                 -- V0, V1, V2, W3 = the 52 B the fast path reads
+//     X  [S] x 16 B : positions 0-3 (rows 0-3)
+//     Y  [S] x  8 B : positions 4-5 (rows 4-5)
+// state_word_index(row, i, S) is the word of `row` of point i (host replay and odd accesses; the kernels use the vector forms).
 constexpr int kStateRows = 19;
 constexpr uint32_t kCertSearch = 0xFFFFFFFFu;      // (a NaN: no certificate)
+constexpr int kStV0 = 0, kStV1 = 4, kStV2 = 8, kStW3 = 12, kStX = 13, kStY = 17;      // group bases in units of S words
+DCREG_DEVFN size_t state_word_index(int row, size_t i, size_t S) {
+    //                      row:   0   1   2   3   4   5   6  7  8   9 10 11 12 13 14 15 16 17 18
+    constexpr uint8_t grp[19] = {13, 13, 13, 13, 17, 17,  0, 0, 0, 12, 0, 4, 4, 4, 4, 8, 8, 8, 8};
+    constexpr uint8_t wpe[19] = { 4,  4,  4,  4,  2,  2,  4, 4, 4,  1, 4, 4, 4, 4, 4, 4, 4, 4, 4};
+    constexpr uint8_t sub[19] = { 0,  1,  2,  3,  0,  1,  0, 2, 3,  0, 1, 0, 1, 2, 3, 0, 1, 2, 3};
+    return (size_t)grp[row] * S + i * wpe[row] + sub[row];
+}
 
 struct LinArgs {
     double radius_sq;             // R^2 in double (gate :1726)

@@ -23,6 +23,9 @@ typedef struct dcreg_lin_debug {
     double *r;       /* [n] */
     double *s;       /* [n] */
     uint32_t *stats; /* [n] search statistics: candidates evaluated | outermost shell << 16 */
+    uint64_t *stamps; /* [8 * 4 * ceil(n / 256)] timing probe: per wave (query block x 4 + wave) shader-clock stamps at the phase boundaries
+                         of the linearisation kernel + its searched / refitted lane counts.  With ONLY this pointer set the call is not a
+                         dump: certificates are used as in a plain call and nothing else is copied back (scripts/wave_phases.py) */
 } dcreg_lin_debug;
 
 /* dcreg_linearize with the dump; always searches every point (k_full), shares the ctx's neighbour state with the plain calls */
@@ -43,6 +46,8 @@ typedef struct dcreg_launch_stats {
     int64_t points_searched;   /* ... of which went through the 6-NN search (the others' certificates held) */
     int64_t points_team;       /* ... of which were searched by a whole wave at a time (search.hpp team_search6: waves with a few
                                   lanes to search), the rest in lock-step; -1 like points_searched */
+    int64_t lean_launches;     /* launches that ran the high-occupancy instantiation of the kernel (option "lean_kernel") ... */
+    int64_t lean_redone;       /* ... and how many of them met a point they could not serve and were run again in full */
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
 
@@ -77,7 +82,11 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "direct_rows"        1 (default) = a single-pose launch of at most 64 blocks publishes its block rows straight to pinned memory and
  *                        the host adds them (in the device's association); 0 = chunk rows as for larger launches;
  *   "count_searches"     see dcreg_launch_stats;
- *   "record_launches"    see dcreg_launch_series. */
+ *   "record_launches"    see dcreg_launch_series;
+ *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
+ *   "lean_kernel"        1 (default) = single-pose launches of more query blocks than the device holds at once use the high-occupancy
+ *                        instantiation of the kernel when the last launch of the same cloud searched at most n / "lean_search_div" (2048)
+ *                        points and refitted at most n / "lean_refit_div" (64); 0 = always the full kernel. */
 
 #ifdef __cplusplus
 }

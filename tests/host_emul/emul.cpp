@@ -304,18 +304,19 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         uint32_t cert = kCertSearch, fitw = kFitNone, pos6[6];
         for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
         const bool old = state && !fresh;
-        uint32_t *st = state ? state + i : nullptr;
+        uint32_t *st = state;                    // word `row` of this query: ST(row) (search.hpp state_word_index)
         const size_t ss = (size_t)stride;
+#define ST(row) (st[state_word_index((row), (size_t)i, ss)])
         float q0x = 0.f, q0y = 0.f, q0z = 0.f;
         if (certify) {                           // what the fast path reads
-            cert = st[6 * ss]; fitw = st[10 * ss];
-            q0x = __uint_as_float(st[7 * ss]); q0y = __uint_as_float(st[8 * ss]); q0z = __uint_as_float(st[9 * ss]);
+            cert = ST(6); fitw = ST(10);
+            q0x = __uint_as_float(ST(7)); q0y = __uint_as_float(ST(8)); q0z = __uint_as_float(ST(9));
         }
         const bool need = !(certify && cert_holds(cert, q0x, q0y, q0z, qx, qy, qz));                 // level 1: search
         const bool refit = !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);   // level 2: gather, order, fit
         Set6 s6{};
         if (need) {
-            if (old && warm) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
+            if (old && warm) for (int j = 0; j < 6; ++j) pos6[j] = ST(j);
             uint32_t c2;
             bool by_team = false;
             if (E->team && old && warm && pos6[5] != kNoIdx) {      // the queries k_lin hands to team_search6 in a sparse wave
@@ -335,7 +336,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
             }
             cert = c2;
             for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
-            if (state) for (int j = 0; j < 6; ++j) st[(size_t)j * ss] = s6.pos[j];
+            if (state) for (int j = 0; j < 6; ++j) ST(j) = s6.pos[j];
             ++n_searched;
         }
         if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
@@ -347,24 +348,24 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         const bool fitnow = set && (need || refit);
         if (fitnow) {
             const bool six = cert_is_set6(cert);      // (then the fit certificate has to cover the 5th / 6th gap itself)
-            if (!need) for (int j = 0; j < 6; ++j) pos6[j] = st[(size_t)j * ss];
+            if (!need) for (int j = 0; j < 6; ++j) pos6[j] = ST(j);
             if (!six) pos6[5] = kNoIdx;
             const bool presorted = need;                   // (k_lin: uniform over the wave; a wave of one lane here)
             const uint8_t in_r = p->fast_plane_fit ? fit_from_set<true>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted) : fit_from_set<false>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted);
             gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
             if (state) {
                 if (!need) cert = cert_rebased(cert, q0x, q0y, q0z, qx, qy, qz);
-                st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
-                st[10 * ss] = fit.word;
-                for (int k = 0; k < 4; ++k) { uint64_t b; std::memcpy(&b, &fit.plane[k], 8); st[(size_t)(11 + 2 * k) * ss] = (uint32_t)b; st[(size_t)(12 + 2 * k) * ss] = (uint32_t)(b >> 32); }
+                ST(6) = cert; ST(7) = __float_as_uint(qx); ST(8) = __float_as_uint(qy); ST(9) = __float_as_uint(qz);
+                ST(10) = fit.word;
+                for (int k = 0; k < 4; ++k) { uint64_t b; std::memcpy(&b, &fit.plane[k], 8); ST(11 + 2 * k) = (uint32_t)b; ST(12 + 2 * k) = (uint32_t)(b >> 32); }
             }
             ++n_fitted;
         } else if (set) {                        // level 3: the stored plane
             gate = (uint8_t)(fitw & 3u);
-            for (int k = 0; k < 4; ++k) { const uint64_t b = ((uint64_t)st[(size_t)(12 + 2 * k) * ss] << 32) | st[(size_t)(11 + 2 * k) * ss]; std::memcpy(&fit.plane[k], &b, 8); }
+            for (int k = 0; k < 4; ++k) { const uint64_t b = ((uint64_t)ST(12 + 2 * k) << 32) | ST(11 + 2 * k); std::memcpy(&fit.plane[k], &b, 8); }
         } else if (need && state) {
-            st[6 * ss] = cert; st[7 * ss] = __float_as_uint(qx); st[8 * ss] = __float_as_uint(qy); st[9 * ss] = __float_as_uint(qz);
-            st[10 * ss] = kFitNone;
+            ST(6) = cert; ST(7) = __float_as_uint(qx); ST(8) = __float_as_uint(qy); ST(9) = __float_as_uint(qz);
+            ST(10) = kFitNone;
         }
         if (gate == 0) fl = p->fast_plane_fit ? row_of_plane<true>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, rr, ss_) : row_of_plane<false>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, rr, ss_);
         else fl = gate == 255 ? 0 : gate;
@@ -385,6 +386,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
             s[5] = emu_stats.trips; s[6] = emu_stats.faces; s[7] = emu_stats.face_skips;
         }
     }
+#undef ST
     for (int j = 0; j < 31; ++j) out32[j] = tot[j];
     out32[31] = 0.0;
     if (counts) { counts[0] = n_searched; counts[1] = n_fitted; }
