@@ -428,9 +428,8 @@ static int estimate_dispatch_order(dcreg_ctx *c, const double *R9, const double 
 // gated = true: a single-pose launch whose pose arrives later through the gate (R9, t3 ignored; dcreg_linearize_gate_open /
 // _gate_abort decide its fate)
 static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9, const double *t3, const int32_t *state_ids,
-                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host, bool gated = false, bool force_full = false) {
+                           const dcreg_lin_params *p, dcreg_lin_debug *dbg_host, bool gated = false) {
     if (!c) return DCREG_E_INVALID;
-    static_assert(sizeof(dcreg_lin_params) <= sizeof(dcreg_lin_params_copy::bytes), "dcreg_lin_params_copy is too small");
     // a timing probe, not a dump (dcreg_debug.h dcreg_lin_debug::stamps): certificates in use, only the stamps come back
     const bool stamps_only = dbg_host && dbg_host->stamps && !dbg_host->nn_idx && !dbg_host->nn_d2 && !dbg_host->flag && !dbg_host->normal &&
                              !dbg_host->r && !dbg_host->s && !dbg_host->stats;
@@ -461,14 +460,16 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const uint32_t nbx = blocks_for(c->n_src, kLinBlock);
     if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
-    const bool fused = (n_poses == 1);
     const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
+    // ... and so do batches whose poses are one chunk each (the Monte-Carlo batches: 30 blocks per pose): the last block of a pose sums
+    // the pose's rows - block_sum_rows, as k_finalize would - and publishes the pose's result row
+    const bool fused = (n_poses == 1) || (n_chunks == 1 && c->opt_fused_batches);
     // a launch of one chunk's worth of blocks: the blocks publish their rows themselves and the host adds them (kernels.hpp FinArgs)
-    const bool direct = fused && nbx <= (uint32_t)kChunk && c->opt_direct_rows;
-    const size_t n_rows = direct ? (size_t)nbx : (fused ? (size_t)n_chunks : (size_t)n_poses);      // result rows the host waits for
+    const bool direct = fused && n_poses == 1 && nbx <= (uint32_t)kChunk && c->opt_direct_rows;
+    const size_t n_rows = direct ? (size_t)nbx : (fused ? (size_t)n_chunks * (size_t)n_poses : (size_t)n_poses);      // result rows the host waits for
     if (fused) {   // tickets: zero when (re)allocated, afterwards every completed launch leaves them zero
         const size_t had = S.tickets_cap;
-        if (ensure(c, S.d_tickets, S.tickets_cap, (size_t)n_chunks * kCounterStride)) return DCREG_E_NOMEM;
+        if (ensure(c, S.d_tickets, S.tickets_cap, (size_t)n_chunks * (size_t)n_poses * kCounterStride)) return DCREG_E_NOMEM;
         if (S.tickets_cap != had || S.tickets_dirty) {
             HIP_TRY(c, hipMemsetAsync(S.d_tickets, 0, sizeof(unsigned int) * S.tickets_cap, c->stream));
             S.tickets_dirty = false;
@@ -611,7 +612,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (oom) { free_tmp(S); drop_warm(c); c->fail("hipMalloc of the debug dump buffers failed"); return DCREG_E_NOMEM; }
     }
     const unsigned long long seq = ++c->seq;
-    FinArgs fin{S.d_tickets, S.d_out, seq, direct ? 1u : 0u};
+    FinArgs fin{S.d_tickets, S.d_out, seq, direct ? 1u : 0u, n_chunks};
     if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
     // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
     bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
@@ -635,26 +636,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     const bool fast = c->opt_fast_plane;
-    // the lean instantiation (kernels.hpp k_lin<.., LEAN>): a single-pose launch of more query blocks than the device holds at once,
-    // on a state whose last launch - of this very cloud - searched and refitted next to nothing.  A lean launch that meets a point it
-    // cannot serve says so in its sums (NaN) and is run again in full (linearize_end).
-    const bool lean = c->opt_lean && !force_full && fused && !direct && (!dbg_host || stamps_only) && uses_state && one.fresh == 0u && a.use_cert != 0 &&
-                      a.warm != 0 && nbx > 4u * (uint32_t)c->n_cus && c->last_points == n && c->last_searched >= 0 && c->last_refitted >= 0 &&
-                      (double)c->last_searched * c->opt_lean_search_div <= (double)n && (double)c->last_refitted * c->opt_lean_refit_div <= (double)n;
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
     hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
                        S.d_partials, nbx, fin, dd, abort_flag)
-        if (stamps_only) {
-            if (lean) hipLaunchKernelGGL((k_lin<2, true, true, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
-            else DCREG_LAUNCH_LIN(2, true, true);
-        }
+        if (stamps_only) DCREG_LAUNCH_LIN(2, true, true);
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
-        else if (lean) {
-            if (fast) hipLaunchKernelGGL((k_lin<0, true, true, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
-            else hipLaunchKernelGGL((k_lin<0, true, false, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, S.d_partials, nbx, fin, dd, abort_flag);
-        }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
         else { if (fast) DCREG_LAUNCH_LIN(0, false, true); else DCREG_LAUNCH_LIN(0, false, false); }
 #undef DCREG_LAUNCH_LIN
@@ -692,12 +680,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (uses_state) c->state_valid = true;          // once this launch has run, the state holds a search of the current clouds
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
-    S.lean = lean; S.stamps_only = stamps_only;
-    if (lean) {
-        c->n_lean_launches += 1;
-        std::memcpy(S.prm.bytes, p, sizeof(*p)); S.prm.set = true;
-        if (!gated) { std::memcpy(S.R, R9, sizeof(S.R)); std::memcpy(S.t, t3, sizeof(S.t)); }       // (gated: dcreg_linearize_gate_open)
-    }
+    S.stamps_only = stamps_only;
     if (gated) {
         c->gate_slot = slot;
         c->gate_uses_state = uses_state; c->gate_state_was_valid = state_was_valid;
@@ -803,31 +786,18 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
             }
             total[k] = 0.0 + tot;                            // (the chunk total enters a sum that starts at zero, as everywhere)
         }
-    } else if (S.fused) {   // add the chunk rows in index order (fixed order: deterministic)
+    } else if (S.fused && S.n_poses == 1) {   // add the chunk rows in index order (fixed order: deterministic)
         for (int k = 0; k < 31; ++k) total[k] = 0.0;
         for (uint32_t ch = 0; ch < S.n_chunks; ++ch) {
             const double *row = S.h_rows.data() + (size_t)ch * kSlots;
             for (int k = 0; k < 31; ++k) total[k] += row[k];
         }
     }
-    if (S.lean && S.fused && std::isnan(total[27])) {
-        // the lean kernel met a point whose search it cannot do (kernels.hpp): the same linearisation again, in full.  Nothing may wait
-        // behind a gate meanwhile (the caller's next launch: the engine then starts it the plain way).
-        c->n_lean_redone += 1;
-        if (c->gate_slot >= 0) (void)dcreg_linearize_gate_abort(c);
-        dcreg_lin_params prm;
-        std::memcpy(&prm, S.prm.bytes, sizeof(prm));
-        double R[9], t[3];
-        std::memcpy(R, S.R, sizeof(R)); std::memcpy(t, S.t, sizeof(t));
-        rc = linearize_begin(c, slot, 1, R, t, nullptr, &prm, nullptr, false, true);
-        if (rc != DCREG_OK) return rc;
-        return linearize_end(c, slot, outs);
-    }
     // the count slots carry two numbers each when the launch was asked to report what it did (LinArgs::count_scale): exact integers
     const bool coded = c->n_src <= ((int64_t)1 << 26);
     int64_t searched = coded ? 0 : -1, refitted = coded ? 0 : -1;
     for (int i = 0; i < S.n_poses; ++i) {
-        const double *o = S.fused ? total : S.h_rows.data() + (size_t)i * kSlots;
+        const double *o = (S.fused && S.n_poses == 1) ? total : S.h_rows.data() + (size_t)i * kSlots;      // (batches: one row per pose)
         std::memcpy(outs[i].H_upper, o, 21 * sizeof(double));
         std::memcpy(outs[i].g, o + 21, 6 * sizeof(double));
         outs[i].sum_r2 = o[27]; outs[i].sum_b2 = o[28];
@@ -1013,9 +983,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
-    else if (k == "lean_kernel") c->opt_lean = v != 0.0;          // kernels.hpp k_lin<.., LEAN> for launches expected to search next to nothing
-    else if (k == "lean_search_div") c->opt_lean_search_div = v > 1.0 ? v : 1.0;
-    else if (k == "lean_refit_div") c->opt_lean_refit_div = v > 1.0 ? v : 1.0;
+    else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host
@@ -1073,7 +1041,6 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
 int dcreg_hint_misalignment(dcreg_ctx *c, double metres) {
     if (!c) return DCREG_E_INVALID;
     c->hint_misalign = metres >= 0.0 ? metres : 1e300;       // (NaN: no knowledge)
-    if (!(metres >= 0.0)) c->last_searched = -1;             // ... about the next pose either: the next launch is a full one
     return DCREG_OK;
 }
 int dcreg_reset_warm_state(dcreg_ctx *c, int64_t state_id) {
@@ -1090,10 +1057,6 @@ int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
     gate_publish(c, c->gate_seq << 1, R, t);
-    {   // (kept with the slot: a lean launch may have to be run again with this pose)
-        LinSlot &S = c->slots[c->gate_slot];
-        std::memcpy(S.R, R, sizeof(S.R)); std::memcpy(S.t, t, sizeof(S.t));
-    }
     c->gate_slot = -1;
     return DCREG_OK;
 }
@@ -1143,7 +1106,6 @@ int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
     if (!c || !st) return DCREG_E_INVALID;
     st->launches = c->n_launches; st->poses = c->n_poses_launched; st->points = c->n_points_launched;
     st->points_searched = -1; st->points_team = -1;
-    st->lean_launches = c->n_lean_launches; st->lean_redone = c->n_lean_redone;
     if (c->opt_count_searches && c->d_search_count) {      // synchronous: every launch so far has finished when this returns
         std::vector<unsigned long long> v(kSearchCountBytes / sizeof(unsigned long long));
         HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_search_count, kSearchCountBytes, hipMemcpyDeviceToHost, c->stream));
@@ -1154,7 +1116,7 @@ int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
         st->points_team = (int64_t)team;
         if (reset) HIP_TRY(c, hipMemsetAsync(c->d_search_count, 0, kSearchCountBytes, c->stream));
     }
-    if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; c->n_lean_launches = 0; c->n_lean_redone = 0; }
+    if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; }
     return DCREG_OK;
 }
 

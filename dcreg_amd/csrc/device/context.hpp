@@ -12,7 +12,6 @@
 struct dcreg_lin_params;
 struct dcreg_lin_out;
 struct dcreg_lin_debug;
-struct dcreg_lin_params_copy { unsigned char bytes[128]; bool set = false; };    // (dcreg.h is not included here: an opaque copy)
 
 // buffers and in-flight state of one linearisation slot
 
@@ -35,10 +34,7 @@ struct LinSlot {
     size_t n_rows = 0;
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
-    // what the launch in flight was: enough to run it again (a lean launch that met a point it cannot serve: kernels.hpp k_lin<.., LEAN>)
-    bool lean = false, stamps_only = false;
-    double R[9] = {}, t[3] = {};
-    dcreg_lin_params_copy prm;
+    bool stamps_only = false;
 };
 
 struct dcreg_ctx {
@@ -161,12 +157,7 @@ struct dcreg_ctx {
     double est_R[9] = {}, est_t[3] = {};
     int64_t est_launch = 0;         // n_launches when the estimate was made
     double hint_misalign = 1e300;   // dcreg_hint_misalignment     // source processed in groups of the curve order, the groups far from the body origin first (kernels.hpp kFarGroup)
-    // the lean instantiation of k_lin (kernels.hpp) for launches that are expected to search next to nothing: used when the last launch
-    // of the same cloud searched at most n / lean_search_div points and refitted at most n / lean_refit_div, for launches with more
-    // query blocks than the device holds at once at the full kernel's occupancy (smaller ones gain nothing from more waves per SIMD)
-    bool opt_lean = true;
-    double opt_lean_search_div = 2048.0, opt_lean_refit_div = 64.0;
-    int64_t n_lean_launches = 0, n_lean_redone = 0;
+    bool opt_fused_batches = true; // batched launches of one-chunk poses sum and publish per pose inside k_lin (kernels.hpp FinArgs::chunks_per_pose)
     int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     int64_t n_launches = 0, n_poses_launched = 0, n_points_launched = 0;    // dcreg_launch_stats

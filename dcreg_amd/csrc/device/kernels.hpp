@@ -5,7 +5,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 #include "search.hpp"
 
@@ -172,6 +171,9 @@ struct FinArgs {
     unsigned long long seq;
     unsigned int direct;           // 1: a launch of at most kChunk blocks - every block publishes its own row to out[block], the host adds
                                    //    them in block_sum_rows' order (context.hip linearize_end): no ticket, no cross-XCD read of the rows
+    unsigned int chunks_per_pose;  // tickets and chunk rows of pose p start at p * chunks_per_pose (single-pose launches: pose 0).  Batched
+                                   //    launches whose poses are ONE chunk each (<= kChunk blocks: the Monte-Carlo batches) finish in the kernel
+                                   //    like single-pose ones - the chunk row IS the pose's result row - instead of a k_finalize launch
 };
 
 // Cross-block traffic of the tree uses agent-scope (sc1, write-through / L2-coherent) relaxed atomics plus an explicit
@@ -300,7 +302,7 @@ __device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t
 // sum (may overlap the Gram matrices: they are consumed before)
 template <bool FUSED>
 __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, double (*red)[kSlots], double (*cnt)[2], int *s_role, double *my_rows, uint32_t vb,
-                                              uint32_t n_blocks_x, const FinArgs &fin) {
+                                              uint32_t n_blocks_x, const FinArgs &fin, uint32_t pose_id) {
     if (threadIdx.x < kSlots) {
         double t = 0.0;
         if (threadIdx.x < 29) {
@@ -323,60 +325,35 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
     if (FUSED && !fin.direct) {
         const uint32_t chunk = vb / kChunk;
         const uint32_t csize = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
+        const size_t gchunk = (size_t)pose_id * fin.chunks_per_pose + chunk;         // this pose's chunk among all of the launch
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[(size_t)chunk * kCounterStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[gchunk * kCounterStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_role = (prev == csize - 1) ? 1 : 0;
-            if (prev == csize - 1) __hip_atomic_store(&fin.tickets[(size_t)chunk * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == csize - 1) __hip_atomic_store(&fin.tickets[gchunk * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (*s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
             const double t = block_sum_rows(my_rows + (size_t)chunk * kChunk * kSlots, csize, red);
-            double *orow = fin.out + (size_t)chunk * kSlots;
+            double *orow = fin.out + gchunk * kSlots;
             if (threadIdx.x < 32) publish_row(orow, t, fin.seq);
         }
     }
 }
 
 // ---------------------------------------------------------------- k_lin
-// LEAN: the instantiation for launches in which (nearly) every certificate is expected to hold - what the host picks once the last
-// launch searched next to nothing (context.hip linearize_begin).  Compiled for twice the waves per SIMD (half the registers), with a
-// per-wave LDS of 4.6 KB instead of 9.3 KB: a settled launch is a stream of 72 B per point and streams at what its occupancy allows
-// (profiles/r03_stream_microbench.txt: 21 us at 4 waves per SIMD, 13.7 us at 8, for 1 M points).  Same levels, same code for levels
-// 2 and 3 (the plane fit spills under the smaller budget - a few hundred points per launch pay that), but level 1 only as the team
-// search: a point the team cannot take (no six old neighbours, a ball beyond its 27-cell block, more than 64 points inside the bound)
-// POISONS the launch - its row carries a NaN into the sums, its state is left alone - and the host, seeing the NaN, runs the same
-// linearisation again with the full kernel (context.hip linearize_end).  Every point the lean launch did serve got exactly what the
-// full kernel gives it, so the second launch finds their certificates in place and the sums it returns are the usual ones.
-#if !defined(DCREG_LEAN_OCC)
-#define DCREG_LEAN_OCC 5
-#endif
-template <int MODE, bool FUSED, bool FAST, bool LEAN = false>
-static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+template <int MODE, bool FUSED, bool FAST>
+static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
-    using WaveLds = typename std::conditional<LEAN, LeanList, RunList>::type;
+    __shared__ double red[kLinBlock / 32][kSlots];
     __shared__ double cnt[kLinBlock / 64][2];
     __shared__ int s_role;
-    __shared__ WaveLds runs[kLinBlock / kWave];
-    // the waves' Gram matrices and the scratch of the chunk sum: an array of their own, or (LEAN: every byte of LDS is occupancy) the
-    // waves' staging areas once the operands have been read from them
-    double (*red)[kSlots];
-    const double *gm0;
-    int gm_stride;
-    if constexpr (LEAN) {
-        static_assert(sizeof(WaveLds) >= sizeof(double) * (kLinBlock / 32) * kSlots, "the chunk sum's scratch must fit one staging area");
-        red = reinterpret_cast<double (*)[kSlots]>(&runs[0].stage[0]);
-        gm0 = &runs[0].stage[0];
-        gm_stride = (int)(sizeof(WaveLds) / sizeof(double));
-    } else {
-        __shared__ double red_[kLinBlock / 32][kSlots];
-        red = red_;
-        gm0 = &red_[0][0];
-        gm_stride = 64;
-    }
+    __shared__ RunList runs[kLinBlock / kWave];
+    const double *const gm0 = &red[0][0];            // the waves' 8x8 Gram matrices (wave w at gm0 + 64 w); later the scratch of the chunk sum
+    constexpr int gm_stride = 64;
     const int wave = threadIdx.x >> 6;
     const uint32_t pose_id = blockIdx.y;
     uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
@@ -428,7 +405,6 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
-    bool poisoned = false;                          // LEAN: this lane needed a search the team could not give it
     KnnResult<5> nn;
     Fit fit;
     uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
@@ -437,26 +413,12 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
         gate = (uint8_t)(fitw & 3u);
         fit.plane[0] = a01.x; fit.plane[1] = a01.y; fit.plane[2] = a23.x; fit.plane[3] = a23.y;
     };
-    double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
-    double row[8];
-    // the row from the plane: called at the end of EITHER branch below (two copies of ~150 instructions), so that the plane words of
-    // the fast path die inside its own block - as one tail after the join they were live around the whole search in the allocator's
-    // eyes, and a pair of them went through scratch on the path that does nothing else
-    auto make_row = [&]() {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) row[k] = 0.0;
-        if (have_q) {
-            if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
-            else flag = gate == 255 ? (uint8_t)0 : gate;
-        }
-    };
     if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(1, __builtin_readcyclecounter()); }
     if (!wave_any(need || refit)) {
         // the whole wave is at level 3 (or OUT): the plane words loaded up front are all it needs.  (They are consumed HERE and not
         // below: kept alive across the search they would cost a dozen registers at its peak, i.e. scratch spills; the waves that do
         // search load them a second time afterwards - from the cache.)
         if (level3) stored_plane(p01, p23);
-        make_row();
     } else {
         uint32_t pos6[6];
 #pragma unroll
@@ -476,29 +438,6 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
                 const uint2 y = SY[i];
                 pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
             }
-            if constexpr (LEAN) {
-                // level 1 of the lean kernel: the team, seven queries at a time; what it cannot take poisons the launch
-                float tb = 0.f;
-                bool tight = false;
-                if (warm && need && pos6[5] != kNoIdx) tb = team_bound(g, a, pos6, qx, qy, qz, tight);
-                bool served = false;
-                unsigned long long todo = __builtin_amdgcn_ballot_w64(need && tight);
-                while (todo != 0ull) {
-                    unsigned long long sub = 0ull, m = todo;
-#pragma unroll 1
-                    for (int k = 0; k < kTeamMax && m != 0ull; ++k) { sub |= m & (0ull - m); m &= m - 1ull; }
-                    todo &= ~sub;
-                    uint32_t tpos[6], tcert;
-                    const unsigned long long ok = team_search6(g, runs[wave].team, a, sub, qx, qy, qz, tb, tpos, tcert);
-                    if (((ok >> (threadIdx.x & 63)) & 1ull) != 0ull) {
-                        served = true;
-                        cert = tcert;
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) pos6[j] = tpos[j];
-                    }
-                }
-                poisoned = need && !served;
-            } else {
             bool by_team = false;                   // uniform: the team served every lane that had to be searched
             // a wave with a few lanes to search, each of them near its old neighbours: the 64 lanes serve one query at a time
             if (warm && w_search <= (uint32_t)a.team_max) {
@@ -529,15 +468,14 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
                     stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
                 }
             }
-            }
-            if (need && keep && !poisoned) {
+            if (need && keep) {
                 SX[iw] = make_uint4(pos6[0], pos6[1], pos6[2], pos6[3]);
                 SY[iw] = make_uint2(pos6[4], pos6[5]);
             }
         }
         if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2, __builtin_readcyclecounter()); stamp(6, (unsigned long long)w_search); }
         // level 2 for the lanes that were searched and the lanes whose order may have changed
-        const bool set = have_q && !cert_is_out(cert) && !poisoned;
+        const bool set = have_q && !cert_is_out(cert);
         const bool fitnow = set && (need || refit);
         w_refit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fitnow && !need));
         if (wave_any(fitnow)) {
@@ -574,14 +512,20 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
             fitw = reinterpret_cast<const uint32_t *>(SV0 + iw)[1];
             stored_plane(b01, b23);
         }
-        if (!set && need && keep && !poisoned) {    // searched and found OUT: certificate and reference position, no fit
+        if (!set && need && keep) {                 // searched and found OUT: certificate and reference position, no fit
             SV0[iw] = make_uint4(cert, kFitNone, __float_as_uint(qx), __float_as_uint(qy));
             SW3[iw] = __float_as_uint(qz);
         }
-        make_row();
+    }
+    double nrm[3] = {0.0, 0.0, 0.0}, r_pt = 0.0, s_pt = 0.0;
+    double row[8];                                  // (zero unless the point is effective; initialised here, not at the top: sixteen
+#pragma unroll                                      //  registers of zeros are not carried through the search)
+    for (int k = 0; k < 8; ++k) row[k] = 0.0;
+    if (have_q) {
+        if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
+        else flag = gate == 255 ? (uint8_t)0 : gate;
     }
     stamp(4, __builtin_readcyclecounter());
-    if (LEAN && poisoned) row[7] = __builtin_nan("");      // -> sum r^2 and every product with this row: the host runs the full kernel
     if (MODE == 1 && have_q) {                      // (debug launches search and fit every point: nn is this launch's list)
         const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
@@ -598,11 +542,11 @@ static __global__ __launch_bounds__(kLinBlock, LEAN ? DCREG_LEAN_OCC : DCREG_LIN
         if (dbg.stats) dbg.stats[oi] = stats;
     }
     // (the wave's RunList is free now: it stages the rows)
-    wave_rows_to_lds(row, flag, runs[wave].stage, const_cast<double *>(gm0) + wave * gm_stride, cnt, a.count_scale * (double)w_search,
+    wave_rows_to_lds(row, flag, runs[wave].stage, &red[0][0] + wave * gm_stride, cnt, a.count_scale * (double)w_search,
                      a.count_scale * (double)w_refit);
     stamp(5, __builtin_readcyclecounter());
     __syncthreads();
-    block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin);
+    block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin, pose_id);
 }
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused

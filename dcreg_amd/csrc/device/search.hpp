@@ -388,13 +388,6 @@ struct alignas(16) RunList {
         TeamLds team;
     };
 };
-// the per-wave LDS of the lean instantiation of k_lin (kernels.hpp): no run list, no pending list - its searches are team searches
-struct alignas(16) LeanList {
-    union {
-        double stage[kWave * kRowStride];
-        TeamLds team;
-    };
-};
 DCREG_DEVFN bool wave_any(bool x) {
 #if DCREG_ON_DEVICE
     return __builtin_amdgcn_ballot_w64(x) != 0ull;

@@ -307,7 +307,9 @@ static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, c
             ended[(size_t)j] = 1;
             if (lo.n_eff < 10) { tr.iterations = it + 1; tr.status = 1; continue; }          // :1847-1854
             StepOut so;
-            const int st = host_step(lo, detection, handling, *cfg, S.R, S.t, so);
+            // (defer = true and the owed part never paid: a trial record holds nothing of the full eigen-decomposition of H or the
+            // diagonal blocks - diagnostics of the per-iteration log, which a trial does not keep; mask, update and pose are the same)
+            const int st = host_step(lo, detection, handling, *cfg, S.R, S.t, so, true);
             if (st == 2) { tr.iterations = it; tr.status = 2; continue; }
             tr.iterations = it + 1;
             tr.final_rmse = std::sqrt(lo.sum_r2 / (double)lo.n_eff);

@@ -46,8 +46,6 @@ typedef struct dcreg_launch_stats {
     int64_t points_searched;   /* ... of which went through the 6-NN search (the others' certificates held) */
     int64_t points_team;       /* ... of which were searched by a whole wave at a time (search.hpp team_search6: waves with a few
                                   lanes to search), the rest in lock-step; -1 like points_searched */
-    int64_t lean_launches;     /* launches that ran the high-occupancy instantiation of the kernel (option "lean_kernel") ... */
-    int64_t lean_redone;       /* ... and how many of them met a point they could not serve and were run again in full */
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
 
@@ -84,9 +82,8 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "count_searches"     see dcreg_launch_stats;
  *   "record_launches"    see dcreg_launch_series;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
- *   "lean_kernel"        1 (default) = single-pose launches of more query blocks than the device holds at once use the high-occupancy
- *                        instantiation of the kernel when the last launch of the same cloud searched at most n / "lean_search_div" (2048)
- *                        points and refitted at most n / "lean_refit_div" (64); 0 = always the full kernel. */
+ *   "fused_batches"      1 (default) = a batched launch whose poses have at most 64 query blocks each finishes inside the kernel (the last block
+ *                        of a pose sums and publishes the pose's row); 0 = a k_finalize launch behind it, as for larger poses. */
 
 #ifdef __cplusplus
 }

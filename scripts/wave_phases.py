@@ -55,5 +55,3 @@ for k, T in enumerate(poses):
     cls(heavy & (ns >= 3) & (ns <= 7), "search 3-7")
     cls(heavy & (ns >= 8) & (ns <= 32), "search 8-32")
     cls(heavy & (ns > 32), "search > 32")
-st = ctx.launch_stats()
-print("lean launches %d, redone %d" % (st["lean_launches"], st["lean_redone"]))

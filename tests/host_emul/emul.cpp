@@ -428,6 +428,15 @@ int emu_knn(void *idx, const float *q_xyz, int64_t n, int k, double max_radius, 
     return 0;
 }
 
+// the nine cell-table intervals [s, e) of each query's 27-cell block for a given bound (team_row = knn_search's phase A): design data
+// for wave-level candidate tiles (scripts/tile_union_model.py)
+void emu_block_rows(void *idx, const float *q_xyz, const float *bounds, int64_t n, uint32_t *out) {
+    EmuIndex *E = (EmuIndex *)idx;
+    for (int64_t i = 0; i < n; ++i)
+        for (int r = 0; r < 9; ++r)
+            team_row(E->g, q_xyz[3 * i], q_xyz[3 * i + 1], q_xyz[3 * i + 2], bounds[i], r % 3 - 1, r / 3 - 1, out[(i * 9 + r) * 2], out[(i * 9 + r) * 2 + 1]);
+}
+
 // plane fit alone: Q = 5 neighbours (row-major 5x3); fast = 1 -> plane_fit_qr_fast
 void emu_plane_fit(const double *Q, int fast, double x[3]) {
     double qx[5], qy[5], qz[5];
