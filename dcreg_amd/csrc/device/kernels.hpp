@@ -195,32 +195,21 @@ __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)
 // host takes the row when the word fits the 31 values it sees next to it - whatever order the link delivered the stores in.  No
 // "data, wait for the acknowledgement, then flag": one PCIe round trip less on every result.  Called by threads 0 .. 31 of the block.
 __host__ __device__ inline unsigned long long row_check_mult(int i) { return 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 3); }
-// the check word of a row, from its 31 values (lane l < 31 of a 32-lane group holds the bit pattern of slot l; lane 31's argument is
-// ignored) and the launch number: returned in all 32 lanes
-__device__ __forceinline__ unsigned long long row_check_word(unsigned long long bits, unsigned long long seq) {
-    const int l = threadIdx.x & 31;
+__device__ __forceinline__ void publish_row(double *orow, double value, unsigned long long seq) {
+    const int l = threadIdx.x;                      // 0 .. 31; lane 31 carries no value
+    const unsigned long long bits = l < 31 ? (unsigned long long)__double_as_longlong(value) : 0ull;
     unsigned long long c = l < 31 ? bits * row_check_mult(l) : seq * row_check_mult(31);
 #pragma unroll
     for (int m = 1; m < 32; m <<= 1) {
         const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)c, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(c >> 32), m);
         c += ((unsigned long long)hi << 32) | lo;
     }
-    return c;
-}
-__device__ __forceinline__ void publish_row(double *orow, double value, unsigned long long seq) {
-    const int l = threadIdx.x;                      // 0 .. 31; lane 31 carries no value
-    const unsigned long long bits = l < 31 ? (unsigned long long)__double_as_longlong(value) : 0ull;
-    const unsigned long long c = row_check_word(bits, seq);
     __hip_atomic_store((unsigned long long *)(orow + l), l < 31 ? bits : c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // sum of `count` (<= kChunk) rows of kSlots doubles, fixed order: lane group g (of G = kLinBlock / 32) adds rows g, g + G, ... then the
 // G group sums are added in order.  All kLinBlock threads call; threads < 31 return the total of their slot.
-// CHECKED: the rows were written by other blocks of THIS launch, each with a check word in slot 31 (block_publish) and without waiting
-// for the stores to land before taking its ticket: a row is used when its word fits the 31 values next to it and the launch number -
-// a stale or half-arrived row fails and is read again (it is on its way: its block's ticket has been counted).
-template <bool CHECKED>
-__device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t count, double (*sm)[kSlots], unsigned long long seq = 0ull) {
+__device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t count, double (*sm)[kSlots]) {
     constexpr int G = kLinBlock / 32;               // lane groups of 32: one slot each
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double v[kChunk / G];
@@ -228,23 +217,6 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
     for (int u = 0; u < kChunk / G; ++u) {
         const uint32_t r = (uint32_t)grp + (uint32_t)G * u;
         v[u] = r < count ? ld_agent(rows + (size_t)r * kSlots + j) : 0.0;
-    }
-    if constexpr (CHECKED) {
-        for (unsigned tries = 0;; ++tries) {
-            bool bad = false;
-#pragma unroll
-            for (int u = 0; u < kChunk / G; ++u) {
-                const uint32_t r = (uint32_t)grp + (uint32_t)G * u;
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(v[u]);
-                const unsigned long long c = row_check_word(bits, seq);
-                const uint32_t wlo = (uint32_t)__shfl((int)(uint32_t)bits, 31, 32), whi = (uint32_t)__shfl((int)(uint32_t)(bits >> 32), 31, 32);
-                const bool ok = r >= count || c == (((unsigned long long)whi << 32) | wlo);      // (uniform over the 32 lanes of the group)
-                if (!ok) { v[u] = ld_agent(rows + (size_t)r * kSlots + j); bad = true; }
-            }
-            if (!bad) break;
-            if (tries > (1u << 22)) __builtin_trap();       // a row that never arrives: a device fault, not a silent wrong sum
-            __builtin_amdgcn_s_sleep(1);
-        }
     }
     double t = 0.0;
 #pragma unroll
@@ -344,12 +316,8 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
         if (FUSED && fin.direct) {
             publish_row(fin.out + (size_t)vb * kSlots, t, fin.seq);
         } else if (FUSED) {
-            // the row with its check word (slot 31): the ticket below is taken without waiting for these stores to land - the block that
-            // sums the chunk verifies every row it reads (block_sum_rows<true>): one store round trip less in the tail of every block
-            const unsigned long long bits = threadIdx.x < 31 ? (unsigned long long)__double_as_longlong(t) : 0ull;
-            const unsigned long long c = row_check_word(bits, fin.seq);
-            __hip_atomic_store((unsigned long long *)(my_rows + (size_t)vb * kSlots + threadIdx.x), threadIdx.x < 31 ? bits : c, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            st_agent(my_rows + (size_t)vb * kSlots + threadIdx.x, t);
+            wait_stores();                                 // the row is at the coherence point before the ticket is taken
         } else {
             my_rows[(size_t)vb * kSlots + threadIdx.x] = t;
         }
@@ -358,7 +326,7 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
         const uint32_t chunk = vb / kChunk;
         const uint32_t csize = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
         const size_t gchunk = (size_t)pose_id * fin.chunks_per_pose + chunk;         // this pose's chunk among all of the launch
-        // (thread 0 is in the wave that issued the row's stores: program order puts the ticket behind them, nothing more is needed)
+        __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned int prev = __hip_atomic_fetch_add(&fin.tickets[gchunk * kCounterStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_role = (prev == csize - 1) ? 1 : 0;
@@ -366,7 +334,7 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
         }
         __syncthreads();
         if (*s_role == 1) {                                  // last block of this chunk: sum its rows, publish to the host
-            const double t = block_sum_rows<true>(my_rows + (size_t)chunk * kChunk * kSlots, csize, red, fin.seq);
+            const double t = block_sum_rows(my_rows + (size_t)chunk * kChunk * kSlots, csize, red);
             double *orow = fin.out + gchunk * kSlots;
             if (threadIdx.x < 32) publish_row(orow, t, fin.seq);
         }
@@ -418,7 +386,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     uint4 *const SV0 = reinterpret_cast<uint4 *>(sbase + kStV0 * ss), *const SX = reinterpret_cast<uint4 *>(sbase + kStX * ss);
     dbl2 *const SV1 = reinterpret_cast<dbl2 *>(sbase + kStV1 * ss), *const SV2 = reinterpret_cast<dbl2 *>(sbase + kStV2 * ss);
     uint32_t *const SW3 = sbase + kStW3 * ss;
-    uint4 *const SY = reinterpret_cast<uint4 *>(sbase + kStY * ss);
+    uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     // what the fast path needs, in one batch of loads: certificate, reference position, fit word, plane (56 B + the 16 B of the point)
     uint32_t cert = kCertSearch, fitw = kFitNone, q0[3] = {0u, 0u, 0u};
@@ -465,33 +433,24 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             if (a.search_count && (threadIdx.x & 63) == 0)       // 64 counters on lines of their own (kCounterStride): see there
                 atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)__builtin_popcountll(need_mask));
             const bool warm = old && a.warm != 0;
-            // the start bound of a warm search: from the state's bound of the sixth stored neighbour's distance and the move since
-            // (search.hpp warm_bound_ub) - no gather of the old neighbours in front of the search
-            float wb = __builtin_inff();
             if (warm && need) {
-                const uint4 y = SY[i];
-                float r0x = q0x, r0y = q0y, r0z = q0z;
-                if (!CERT) {                        // (a launch that does not use the certificates has not loaded the reference position)
-                    const uint4 o0 = SV0[i];
-                    r0x = __uint_as_float(o0.z); r0y = __uint_as_float(o0.w); r0z = __uint_as_float(SW3[i]);
-                }
-                if (y.y != kNoIdx) wb = warm_bound_ub(__uint_as_float(y.z), r0x, r0y, r0z, qx, qy, qz, wb);
+                const uint4 x = SX[i];
+                const uint2 y = SY[i];
+                pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
             }
-            float d6 = __builtin_inff();            // squared distance of the sixth neighbour found (the next bound starts from it)
             bool by_team = false;                   // uniform: the team served every lane that had to be searched
             // a wave with a few lanes to search, each of them near its old neighbours: the 64 lanes serve one query at a time
             if (warm && w_search <= (uint32_t)a.team_max) {
                 float tb = 0.f;
                 bool tight = false;
-                if (need && wb < __builtin_inff()) tb = team_bound(g, a, wb, qx, qy, qz, tight);
+                if (need && pos6[5] != kNoIdx) tb = team_bound(g, a, pos6, qx, qy, qz, tight);
                 if (!wave_any(need && !tight)) {
                     uint32_t tpos[6], tcert;
-                    float td6 = 0.f;
-                    by_team = team_search6(g, runs[wave].team, a, need_mask, qx, qy, qz, tb, tpos, tcert, td6) == need_mask;
+                    by_team = team_search6(g, runs[wave].team, a, need_mask, qx, qy, qz, tb, tpos, tcert) == need_mask;
                     if (a.search_count && by_team && (threadIdx.x & 63) == 0)      // (statistics: the word next to the search counter)
                         atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2) + 1, (unsigned long long)w_search);
                     if (by_team && need) {
-                        cert = tcert; d6 = td6;
+                        cert = tcert;
 #pragma unroll
                         for (int j = 0; j < 6; ++j) pos6[j] = tpos[j];
                     }
@@ -501,9 +460,9 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             if (!by_team) {
                 Set6 s6;
                 uint32_t c2;
-                lin_search6<kLinSweep>(g, runs[wave], a, need, wb, qx, qy, qz, s6, c2);
+                lin_search6<kLinSweep>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
                 if (need) {
-                    cert = c2; d6 = s6.d2[5];
+                    cert = c2;
 #pragma unroll
                     for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
                     stats = (s6.n_eval & 0xFFFFu) | ((s6.n_shell & 0x7FFFu) << 16);
@@ -511,7 +470,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             }
             if (need && keep) {
                 SX[iw] = make_uint4(pos6[0], pos6[1], pos6[2], pos6[3]);
-                SY[iw] = make_uint4(pos6[4], pos6[5], __float_as_uint(pos6[5] != kNoIdx ? d6 : __builtin_inff()), 0u);
+                SY[iw] = make_uint2(pos6[4], pos6[5]);
             }
         }
         if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2, __builtin_readcyclecounter()); stamp(6, (unsigned long long)w_search); }
@@ -525,12 +484,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             const bool use6 = fitnow && cert_is_set6(cert);
             const bool six = wave_any(use6);
             const bool presorted = !wave_any(fitnow && !need);     // every lane that fits was searched just now: its six are in order
-            float ub6 = 0.f;                        // (lanes that only refit: the state's bound, to be re-based with the reference position)
             if (fitnow && !need) {
                 const uint4 x = SX[iw];
-                const uint4 y = SY[iw];
+                const uint2 y = SY[iw];
                 pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
-                ub6 = __uint_as_float(y.z);
             }
             if (!use6) pos6[5] = kNoIdx;
             if (fitnow) {
@@ -541,8 +498,6 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
                         const uint4 o0 = SV0[iw];
                         const uint32_t o1 = SW3[iw];
                         cert = cert_rebased(cert, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz);
-                        reinterpret_cast<uint32_t *>(SY + iw)[2] =
-                            __float_as_uint(rebased_ub(ub6, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz));
                     }
                     SV0[iw] = make_uint4(cert, fit.word, __float_as_uint(qx), __float_as_uint(qy));
                     SV1[iw] = dbl2{fit.plane[0], fit.plane[1]};
@@ -605,7 +560,7 @@ static __global__ __launch_bounds__(kLinBlock) void k_finalize(const double *__r
     const double *base = partials + (size_t)pose_id * n_blocks * kSlots;
     double tot = 0.0;
     for (uint32_t c0 = 0; c0 < n_blocks; c0 += kChunk)
-        tot += block_sum_rows<false>(base + (size_t)c0 * kSlots, min((uint32_t)kChunk, n_blocks - c0), sm);
+        tot += block_sum_rows(base + (size_t)c0 * kSlots, min((uint32_t)kChunk, n_blocks - c0), sm);
     double *orow = out + (size_t)pose_id * kSlots;
     if (threadIdx.x < 32) publish_row(orow, tot, seq);
 }

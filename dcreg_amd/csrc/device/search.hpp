@@ -101,22 +101,16 @@ struct PoseArg {
 //     V2 [S] x 16 B : plane[2], plane[3] (rows 15-18)
 //     W3 [S] x  4 B : q0.z (row 9)                                 -- V0, V1, V2, W3 = the 52 B the fast path reads
 //     X  [S] x 16 B : positions 0-3 (rows 0-3)
-//     Y  [S] x 16 B : positions 4-5 (rows 4-5), row 19 = UB6 (below), one spare word
-// Row 19, UB6: an upper bound (squared, float bits) of the distance from q0 to the farthest of the six stored neighbours: the 6th
-// distance of the search, grown by every later move of q0 (a refit re-bases q0: the triangle inequality keeps the bound true).  A later
-// search of the point starts from (sqrt(UB6) + |q - q0|)^2 - six real points lie inside that ball - without gathering the old
-// neighbours first: one dependent memory round trip less in front of every warm search (profiles/r04_wave_phases_c4.txt: ~2 k cycles
-// each at this kernel's occupancy).
+//     Y  [S] x  8 B : positions 4-5 (rows 4-5)
 // state_word_index(row, i, S) is the word of `row` of point i (host replay and odd accesses; the kernels use the vector forms).
-constexpr int kStateRows = 21;                      // in units of S words: the size of one state
-constexpr int kStateFields = 20;
+constexpr int kStateRows = 19;
 constexpr uint32_t kCertSearch = 0xFFFFFFFFu;      // (a NaN: no certificate)
 constexpr int kStV0 = 0, kStV1 = 4, kStV2 = 8, kStW3 = 12, kStX = 13, kStY = 17;      // group bases in units of S words
 DCREG_DEVFN size_t state_word_index(int row, size_t i, size_t S) {
-    //                             row:   0   1   2   3   4   5   6  7  8   9 10 11 12 13 14 15 16 17 18  19
-    constexpr uint8_t grp[kStateFields] = {13, 13, 13, 13, 17, 17,  0, 0, 0, 12, 0, 4, 4, 4, 4, 8, 8, 8, 8, 17};
-    constexpr uint8_t wpe[kStateFields] = { 4,  4,  4,  4,  4,  4,  4, 4, 4,  1, 4, 4, 4, 4, 4, 4, 4, 4, 4,  4};
-    constexpr uint8_t sub[kStateFields] = { 0,  1,  2,  3,  0,  1,  0, 2, 3,  0, 1, 0, 1, 2, 3, 0, 1, 2, 3,  2};
+    //                      row:   0   1   2   3   4   5   6  7  8   9 10 11 12 13 14 15 16 17 18
+    constexpr uint8_t grp[19] = {13, 13, 13, 13, 17, 17,  0, 0, 0, 12, 0, 4, 4, 4, 4, 8, 8, 8, 8};
+    constexpr uint8_t wpe[19] = { 4,  4,  4,  4,  2,  2,  4, 4, 4,  1, 4, 4, 4, 4, 4, 4, 4, 4, 4};
+    constexpr uint8_t sub[19] = { 0,  1,  2,  3,  0,  1,  0, 2, 3,  0, 1, 0, 1, 2, 3, 0, 1, 2, 3};
     return (size_t)grp[row] * S + i * wpe[row] + sub[row];
 }
 
@@ -1282,28 +1276,25 @@ DCREG_DEVFN bool cert_holds(uint32_t cert, float q0x, float q0y, float q0z, floa
     return m2 < s * s;
 }
 
-// Bound of a search from what the state knows (row 19, UB6): the six stored neighbours lie within sqrt(ub6) of q0, hence within
-// sqrt(ub6) + |q - q0| of q - the 6th-neighbour distance at q is at most that.  Rounded up by relative margins far above what the float
-// arithmetic can lose (1 ulp square roots, 3e-7 on the sums), and never zero (an inclusive bound for a strict '<' heap: six duplicates
-// of the query itself must still pass).
-DCREG_DEVFN float warm_bound_ub(float ub6, float q0x, float q0y, float q0z, float qx, float qy, float qz, float bound) {
-    const float dx = qx - q0x, dy = qy - q0y, dz = qz - q0z;
-    const float m = sqrt_approx(dx * dx + dy * dy + dz * dz) * 1.00001f;
-    const float r = sqrt_approx(ub6) * 1.00001f + m;
-    const float b = fmaxf(r * r * 1.00001f, 1.17549435e-38f);
-    return fminf(bound, b);
-}
-// ... and what a refit that moves the reference position from q0 to q leaves in row 19: the bound seen from the new position
-DCREG_DEVFN float rebased_ub(float ub6, float q0x, float q0y, float q0z, float qx, float qy, float qz) {
-    return warm_bound_ub(ub6, q0x, q0y, q0z, qx, qy, qz, __builtin_inff());
+// Bound of a search from what the last one found: the 6th-neighbour distance is at most the largest distance to ANY six distinct
+// target points.  oldpos = the state's six positions (all valid).  Inclusive bound for a strict '<' heap: the next float up.
+DCREG_DEVFN float warm_bound6(const GridDev &g, const uint32_t (&oldpos)[6], float qx, float qy, float qz, float bound) {
+    float4 pv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pv[j] = g.pts[oldpos[j]];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m = fmaxf(m, dist2_nofma(qx, qy, qz, pv[j]));
+    const float incl = fmaxf(__uint_as_float(__float_as_uint(m) + 1u), 1.17549435e-38f);
+    return fminf(bound, incl);
 }
 
 // search of one query inside a linearisation: bound (warm or cold), reach test, 6-NN, certificate
-// wbound: the lane's start bound (warm_bound_ub, or the search radius where nothing is known)
 template <bool SWEEP>
-DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, bool have_q, float wbound,
+DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, bool have_q, bool warm, const uint32_t (&oldpos)[6],
                              float qx, float qy, float qz, Set6 &st, uint32_t &cert) {
-    float bound = fminf(a.radius_sq_f, wbound);
+    float bound = a.radius_sq_f;
+    if (warm && oldpos[5] != kNoIdx) bound = warm_bound6(g, oldpos, qx, qy, qz, bound);
     // a search whose ball is small (the query sits among its neighbours: the regime in which certificates get used) looks a little
     // further than it must - bound and pruning distance inflated alike (HeapFast::worst_d2), so that what lies beyond is a useful
     // lower bound for the 7th neighbour; a search over many cells (a query far from the surface it belongs to) is expensive enough
@@ -1406,11 +1397,11 @@ DCREG_DEVFN void team_row(const GridDev &g, float qx, float qy, float qz, float 
     e_out = g.cell_start[ok ? row + (uint32_t)x1 : 0u];
 }
 
-// the bound a warm search of the linearisation starts from when nothing about it is loose (lin_search6: the state's bound,
+// the bound a warm search of the linearisation starts from when nothing about it is loose (lin_search6: old neighbours' distances,
 // inflated like the pruning distance), and whether the ball of that bound provably lies inside the query's 27-cell block and the
 // query close enough to the grid: such a search ends with the cell-table phase (knn_shells' first test), which is all the team does
-DCREG_DEVFN float team_bound(const GridDev &g, const LinArgs &a, float wbound, float qx, float qy, float qz, bool &tight) {
-    float bound = fminf(a.radius_sq_f, wbound);
+DCREG_DEVFN float team_bound(const GridDev &g, const LinArgs &a, const uint32_t (&oldpos)[6], float qx, float qy, float qz, bool &tight) {
+    float bound = warm_bound6(g, oldpos, qx, qy, qz, a.radius_sq_f);
     const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
     bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
     const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
@@ -1432,10 +1423,10 @@ DCREG_DEVFN uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_
 DCREG_DEVFN float shfl_f(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)__float_as_uint(v))); }
 
 // team_mask: the lanes (at most kTeamMax) whose queries (qx, qy, qz, bound: valid in those lanes) are searched.  Returns the lanes
-// that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound), the
-// certificate of the search (make_cert) and the squared distance of the sixth.
+// that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound) and
+// the certificate of the search (make_cert).
 DCREG_DEVFN unsigned long long team_search6(const GridDev &g, TeamLds &T, const LinArgs &a, unsigned long long team_mask, float qx, float qy,
-                                            float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out, float &d6_out) {
+                                            float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out) {
     const int lane = threadIdx.x & (kWave - 1);
     // ---- the rows of all queries: lane 9 k + r = row r of the k-th query
     const int k_of = lane / 9, r_of = lane - 9 * k_of;
@@ -1531,7 +1522,6 @@ DCREG_DEVFN unsigned long long team_search6(const GridDev &g, TeamLds &T, const 
             out.lb7 = n > 6u ? fminf(__uint_as_float(T.out_d2[6]), ub) : ub;
             out.n_eval = 0; out.n_shell = 1;
             cert_out = make_cert(out, a);
-            d6_out = out.d2[5];
 #pragma unroll
             for (int j = 0; j < 6; ++j) pos_out[j] = out.pos[j];
         }

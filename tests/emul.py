@@ -145,7 +145,7 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
     n = source.n
     fresh = source.state is None or source.prev_index is not index      # a new target voids positions and certificates
     if warm and fresh:
-        source.state = np.full(21 * source.stride, 0xA5A5A5A5, np.uint32)      # garbage on purpose: a fresh state is never read
+        source.state = np.full(19 * source.stride, 0xA5A5A5A5, np.uint32)      # garbage on purpose: a fresh state is never read
         source.prev_pose, source.prev_index = None, index
     state = source.state if warm else None
     R = np.ascontiguousarray(R, np.float64).reshape(9)

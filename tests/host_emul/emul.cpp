@@ -82,8 +82,7 @@ static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, con
 // 27-cell block cut by team_row, every point of them with a float distance below the bound, ranked by (distance bits, original
 // index); the first six + the seventh's distance -> positions and certificate.  false: more than 64 points inside the bound (the
 // device leaves such a query to the lock-step search).
-static bool team_search_host(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out,
-                             float &d6_out) {
+static bool team_search_host(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out) {
     struct Ent { uint64_t key; uint32_t pos, d2; };
     std::vector<Ent> list;
     for (int r = 0; r < 9; ++r) {
@@ -106,7 +105,6 @@ static bool team_search_host(const GridDev &g, const LinArgs &a, float qx, float
     }
     out.lb7 = n > 6u ? fminf(__uint_as_float(list[6].d2), bound) : bound;
     cert_out = make_cert(out, a);
-    d6_out = out.d2[5];
     for (int j = 0; j < 6; ++j) pos_out[j] = out.pos[j];
     return true;
 }
@@ -318,17 +316,14 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         const bool refit = !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);   // level 2: gather, order, fit
         Set6 s6{};
         if (need) {
-            // the start bound of a warm search, as k_lin forms it (search.hpp warm_bound_ub)
-            float wb = INFINITY;
-            if (old && warm && ST(5) != kNoIdx)
-                wb = warm_bound_ub(__uint_as_float(ST(19)), __uint_as_float(ST(7)), __uint_as_float(ST(8)), __uint_as_float(ST(9)), qx, qy, qz, wb);
+            if (old && warm) for (int j = 0; j < 6; ++j) pos6[j] = ST(j);
             uint32_t c2;
             bool by_team = false;
-            if (E->team && old && warm && wb < INFINITY) {      // the queries k_lin hands to team_search6 in a sparse wave
+            if (E->team && old && warm && pos6[5] != kNoIdx) {      // the queries k_lin hands to team_search6 in a sparse wave
                 bool tight = false;
-                const float tb = team_bound(g, a, wb, qx, qy, qz, tight);
+                const float tb = team_bound(g, a, pos6, qx, qy, qz, tight);
                 uint32_t tpos[6];
-                if (tight && team_search_host(g, a, qx, qy, qz, tb, tpos, c2, s6.d2[5])) {
+                if (tight && team_search_host(g, a, qx, qy, qz, tb, tpos, c2)) {
                     by_team = true;
                     for (int j = 0; j < 6; ++j) s6.pos[j] = tpos[j];
                     s6.n_eval = 0; s6.n_shell = 1;
@@ -336,15 +331,12 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
                 }
             }
             if (!by_team) {
-                if (E->sweep) lin_search6<true>(g, runs, a, true, wb, qx, qy, qz, s6, c2);
-                else lin_search6<false>(g, runs, a, true, wb, qx, qy, qz, s6, c2);
+                if (E->sweep) lin_search6<true>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
+                else lin_search6<false>(g, runs, a, true, warm && old, pos6, qx, qy, qz, s6, c2);
             }
             cert = c2;
             for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
-            if (state) {
-                for (int j = 0; j < 6; ++j) ST(j) = s6.pos[j];
-                ST(19) = __float_as_uint(s6.pos[5] != kNoIdx ? s6.d2[5] : INFINITY);
-            }
+            if (state) for (int j = 0; j < 6; ++j) ST(j) = s6.pos[j];
             ++n_searched;
         }
         if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
@@ -362,10 +354,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
             const uint8_t in_r = p->fast_plane_fit ? fit_from_set<true>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted) : fit_from_set<false>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted);
             gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
             if (state) {
-                if (!need) {
-                    cert = cert_rebased(cert, q0x, q0y, q0z, qx, qy, qz);
-                    ST(19) = __float_as_uint(rebased_ub(__uint_as_float(ST(19)), q0x, q0y, q0z, qx, qy, qz));
-                }
+                if (!need) cert = cert_rebased(cert, q0x, q0y, q0z, qx, qy, qz);
                 ST(6) = cert; ST(7) = __float_as_uint(qx); ST(8) = __float_as_uint(qy); ST(9) = __float_as_uint(qz);
                 ST(10) = fit.word;
                 for (int k = 0; k < 4; ++k) { uint64_t b; std::memcpy(&b, &fit.plane[k], 8); ST(11 + 2 * k) = (uint32_t)b; ST(12 + 2 * k) = (uint32_t)(b >> 32); }
