@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -440,6 +441,11 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         R9 = eye; t3 = zero; n_poses = 1; state_ids = nullptr; dbg_host = nullptr;
         // results must arrive through the pinned flags: a stream synchronise would wait for the gate, i.e. for its own caller
         if (!c->opt_spin) { c->fail("gated launches need the \"spin\" option (results through pinned flags)"); return DCREG_E_STATE; }
+        // a launch that is to be TIMED (option "time_kernels": HIP events around it) is not gated: a gated kernel waits for its pose
+        // inside, and that wait is the host's time, not the kernel's.  The caller starts it the plain way once the pose exists.
+        if (c->opt_time_kernels > 0 && (c->launch_counter % (uint64_t)c->opt_time_kernels) == 0) {
+            c->fail("the next launch is a timed one: not gated"); return DCREG_E_STATE;
+        }
     }
     if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
     LinSlot &S = c->slots[slot];
@@ -531,23 +537,21 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         }
         if (gated) {
             if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
-                GateHost *hg = nullptr; PoseArg *dp = nullptr; uint32_t *da = nullptr;
+                GateHost *hg = nullptr; GateDev *gd = nullptr;
                 bool ok = hipHostMalloc((void **)&hg, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-                ok = ok && hipMalloc((void **)&dp, sizeof(PoseArg)) == hipSuccess && hipMalloc((void **)&da, sizeof(uint32_t)) == hipSuccess;
+                ok = ok && hipMalloc((void **)&gd, sizeof(GateDev)) == hipSuccess && hipMemset(gd, 0, sizeof(GateDev)) == hipSuccess;
                 void *dgh = nullptr;
                 ok = ok && hipHostGetDevicePointer(&dgh, hg, 0) == hipSuccess;
                 if (!ok) {
                     if (hg) (void)hipHostFree(hg);
-                    if (dp) (void)hipFree(dp);
-                    if (da) (void)hipFree(da);
+                    if (gd) (void)hipFree(gd);
                     c->state_valid = state_was_valid;
                     c->fail("allocating the launch gate failed");
                     return DCREG_E_NOMEM;
                 }
                 std::memset(hg, 0, sizeof(GateHost));
-                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_pose = dp; c->d_gate_abort = da;
+                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_dev = gd;
             }
-            d_poses = c->d_gate_pose;
         }
     } else {
         // batched poses: each may own one of the reserved states (dcreg_reserve_warm_states); -1 = search cold, keep nothing
@@ -617,7 +621,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
     bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
     if (timed && !S.ev0) timed = hipEventCreate(&S.ev0) == hipSuccess && hipEventCreate(&S.ev1) == hipSuccess;
-    const uint32_t *abort_flag = nullptr;
+    GateArgs gt{nullptr, nullptr, 0ull};
     // a launch that was queued and must not run after all (errors below): call the gate off, forget what the states were about to hold
     auto bail = [&](const char *what, hipError_t e) {
         free_tmp(S);
@@ -626,12 +630,8 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         c->fail("%s failed: %s", what, hipGetErrorString(e));
         return DCREG_E_DEVICE;
     };
-    if (gated) {
-        const unsigned long long want = ++c->gate_seq;
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, one.fresh, c->d_gate_abort);
-        abort_flag = c->d_gate_abort;
-    }
-    if (timed) {                           // after the gate: the events bracket the linearisation, not the wait for the pose
+    if (gated) gt = GateArgs{c->d_gate_host, c->d_gate_dev, ++c->gate_seq};      // the launch waits for its pose itself (kernels.hpp gate_wait)
+    if (timed) {
         const hipError_t ee = hipEventRecord(S.ev0, c->stream);
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
@@ -640,7 +640,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
     hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
-                       S.d_partials, nbx, fin, dd, abort_flag)
+                       S.d_partials, nbx, fin, dd, gt)
         if (stamps_only) DCREG_LAUNCH_LIN(2, true, true);
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
@@ -926,8 +926,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->h_gate) (void)hipHostFree(c->h_gate);
     if (c->h_euler) (void)hipHostFree(c->h_euler);
     if (c->d_euler) (void)hipFree(c->d_euler);
-    if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
-    if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
+    if (c->d_gate_dev) (void)hipFree(c->d_gate_dev);
     if (c->d_group_est) (void)hipFree(c->d_group_est);
     kdtree_free(c->kd); c->kd = nullptr;
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
@@ -1133,6 +1132,23 @@ int dcreg_launch_series(dcreg_ctx *c, double *ms, int64_t *searched, int64_t *re
     const int64_t total = (int64_t)c->launch_series.size();
     if (reset) c->launch_series.clear();
     return (int)std::min<int64_t>(total, 0x7FFFFFFF);
+}
+
+int dcreg_gate_wait(dcreg_ctx *c, double *us_total, int64_t *launches, int reset) {
+    if (!c) return DCREG_E_INVALID;
+    if (us_total) *us_total = 0.0;
+    if (launches) *launches = 0;
+    if (!c->d_gate_dev) return DCREG_OK;
+    if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it first"); return DCREG_E_STATE; }
+    GateDev g;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(&g, c->d_gate_dev, sizeof(g), hipMemcpyDeviceToHost));
+    if (us_total) *us_total = (double)g.wait_ticks * 0.01;       // 100 MHz wall clock
+    if (launches) *launches = (int64_t)g.waits;
+    if (reset) {
+        HIP_TRY(c, hipMemset((char *)c->d_gate_dev + offsetof(GateDev, wait_ticks), 0, 2 * sizeof(unsigned long long)));
+    }
+    return DCREG_OK;
 }
 
 int dcreg_kernel_time(dcreg_ctx *c, double *ms_total, int64_t *launches, int reset) {

@@ -235,13 +235,16 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // ---------------------------------------------------------------- the gate of a pipelined launch
 // An ICP loop alternates one linearisation and a 3 us host step, and every launch costs ~4 us of host time plus ~2 us until the
 // device starts: idle time for a device that has nothing else queued.  A GATED linearisation is queued while its predecessor still
-// runs, before its pose exists: k_gate (one wave) sits in the stream in front of it and polls a small record in pinned host
-// memory; when the host publishes the pose there, the gate copies it into the device-resident PoseArg the linearisation reads,
-// and retires.  The host can also call the launch off (abort bit): the kernels behind the gate then return at once.
+// runs, before its pose exists, and waits for it ON THE DEVICE, inside k_lin: the first wave of the first block polls a small record in
+// pinned host memory; when the host publishes the pose there, that wave copies it into a device-resident record and raises the
+// launch's number in it; every other wave of the launch - resident by then, its point and state loads issued: they do not depend on
+// the pose - spins on that number in L2 and goes on.  The host can also call the launch off (abort bit): every wave then returns.
+// (Round 2-3 had the gate as a one-wave kernel of its own in front of the linearisation: a kernel boundary - 2-3 us - between "pose on
+// the device" and the first useful instruction of every iteration, and the loads behind it.)
 // A gate that waits longer than kGateTimeoutTicks (wall clock, 100 MHz; far longer than the host ever waits for a result) aborts by
-// itself, so a vanished host cannot leave the queue spinning.
+// itself, so a vanished host cannot leave the device spinning.
 // The gate record: 14 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
-// patterns of doubles), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The gate reads all words with ONE load
+// patterns of doubles), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The polling wave reads all words with ONE load
 // per lane and accepts them only if the number is the awaited one AND the checksum holds: the loads of one poll may be served in
 // any order relative to the host's stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip
 // between "pose published" and "pose on the device", whatever the read granularity of the link.
@@ -249,35 +252,69 @@ constexpr int kGateWords = 14;
 constexpr unsigned long long kGateTimeoutTicks = 12000000000ull;     // 120 s
 struct alignas(128) GateHost { unsigned long long w[32]; };
 constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
-static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
-                                                   uint32_t fresh, uint32_t *__restrict__ abort_flag) {
-    const int lane = threadIdx.x;
-    const unsigned long long t0 = wall_clock64();
-    unsigned long long v = 0, seq = 0;
-    for (;;) {
-        v = lane < kGateWords ? __hip_atomic_load(&hg->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-        // x = xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
-        unsigned long long x = v;
+// the device side of the gate: written by the polling wave, read by every wave of the launch (agent scope)
+struct alignas(128) GateDev {
+    unsigned long long seq_done;       // number of the last gated launch whose pose (or abort) has reached the device
+    unsigned long long abort;          // ... and whether it was called off
+    double pose[12];                   // R (9), t (3) of that launch
+    unsigned long long wait_ticks, waits;   // statistics: wall-clock ticks (100 MHz) the polling waves spent between kernel start and pose
+};
+struct GateArgs {
+    const GateHost *host;              // null: not a gated launch (the pose travels with the kernel arguments)
+    GateDev *dev;
+    unsigned long long want;           // this launch's number
+};
+// called by every wave of a gated launch, after its pose-independent loads are in flight.  Returns false when the launch was called off.
+__device__ __forceinline__ bool gate_wait(const GateArgs &gt, PoseArg &P) {
+    const int lane = threadIdx.x & 63;
+    GateDev *gd = gt.dev;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long v = 0, seq = 0;
+        for (;;) {
+            v = lane < kGateWords ? __hip_atomic_load(&gt.host->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            // x = xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
+            unsigned long long x = v;
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
-            x ^= ((unsigned long long)hi << 32) | lo;
+            for (int m = 1; m < 32; m <<= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+                x ^= ((unsigned long long)hi << 32) | lo;
+            }
+            const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            seq = ((unsigned long long)shi << 32) | slo;                        // lane 0's word
+            const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+            const bool whole = (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
+            if ((seq >> 1) == gt.want && whole) break;
+            // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this wave ever ran
+            if ((seq >> 1) > gt.want && whole) { seq = (gt.want << 1) | 1ull; break; }
+            if (wall_clock64() - t0 > kGateTimeoutTicks) { seq = (gt.want << 1) | 1ull; break; }     // nobody opens - give up
+            __builtin_amdgcn_s_sleep(2);
         }
-        const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        seq = ((unsigned long long)shi << 32) | slo;                        // lane 0's word
-        const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-        const bool whole = (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
-        if ((seq >> 1) == want && whole) break;
-        // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this gate ever ran
-        if ((seq >> 1) > want && whole) { seq = (want << 1) | 1ull; break; }
-        if (wall_clock64() - t0 > kGateTimeoutTicks) { seq = (want << 1) | 1ull; break; }     // nobody opens - give up
-        __builtin_amdgcn_s_sleep(2);
+        if (lane >= 1 && lane <= 12) __hip_atomic_store((unsigned long long *)&gd->pose[lane - 1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(&gd->abort, seq & 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gd->wait_ticks += wall_clock64() - t0; gd->waits += 1ull;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // pose and abort word are at the coherence point before the number is
+        if (lane == 0) __hip_atomic_store(&gd->seq_done, gt.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane >= 1 && lane <= 12) {
-        const double d = __longlong_as_double((long long)v);
-        if (lane <= 9) dst->R[lane - 1] = d; else dst->t[lane - 10] = d;
+    // every wave (the polling one included): wait for the number, then take the pose
+    for (;;) {
+        const unsigned long long d = __hip_atomic_load(&gd->seq_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t dlo = __builtin_amdgcn_readfirstlane((uint32_t)d), dhi = __builtin_amdgcn_readfirstlane((uint32_t)(d >> 32));
+        if ((((unsigned long long)dhi << 32) | dlo) >= gt.want) break;
+        __builtin_amdgcn_s_sleep(1);
     }
-    if (lane == 0) { dst->state = 0; dst->fresh = fresh; *abort_flag = (uint32_t)(seq & 1ull); }
+    const unsigned long long ab = __hip_atomic_load(&gd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_readfirstlane((uint32_t)ab) != 0u) return false;
+    const unsigned long long w = lane < 12 ? __hip_atomic_load((unsigned long long *)&gd->pose[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), k);
+        const double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        if (k < 9) P.R[k] = d; else P.t[k - 9] = d;
+    }
+    return true;
 }
 
 // ---- the common tail of a block: the wave's rows -> its Gram matrix and counts in LDS (the wave's LDS staging area must be free) ...
@@ -346,8 +383,7 @@ template <int MODE, bool FUSED, bool FAST>
 static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
-                                                          DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
-    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
+                                                          DebugDev dbg, GateArgs gt) {
     __shared__ double red[kLinBlock / 32][kSlots];
     __shared__ double cnt[kLinBlock / 64][2];
     __shared__ int s_role;
@@ -395,6 +431,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         const uint4 v0 = SV0[i];
         p01 = SV1[i]; p23 = SV2[i];
         cert = v0.x; fitw = v0.y; q0[0] = v0.z; q0[1] = v0.w; q0[2] = SW3[i];
+    }
+    // a gated launch: the pose arrives now (the loads above are in flight meanwhile); pose1 carried state / fresh only
+    if (gt.host != nullptr) {
+        if (!gate_wait(gt, P)) return;              // called off: every wave of the launch returns here, before any barrier
     }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
