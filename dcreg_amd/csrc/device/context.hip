@@ -59,12 +59,26 @@ static int sort_pairs_u32(dcreg_ctx *c, uint32_t *keys_in, uint32_t *keys_out, u
     HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, bits, c->stream));
     return DCREG_OK;
 }
-static int sort_pairs_u64(dcreg_ctx *c, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n) {
+// sorts by the bits [lo_bit, 63) of the keys only (stable: equal prefixes keep their order)
+static int sort_pairs_u64(dcreg_ctx *c, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n, int lo_bit = 0) {
     size_t tmp = 0;
-    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, 63, c->stream));
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, n, lo_bit, 63, c->stream));
     if (ensure(c, c->sort_tmp, c->sort_tmp_cap, tmp) != DCREG_OK) return DCREG_E_NOMEM;
-    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, n, 0, 63, c->stream));
+    HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp, tmp, keys_in, keys_out, vals_in, vals_out, n, lo_bit, 63, c->stream));
     return DCREG_OK;
+}
+
+// bounding box of a cloud the caller handed over in HOST memory, for clouds small enough that a loop over them costs less than the
+// kernel + copy + stream synchronise of device_bounds (a frame of a few thousand points: the per-registration path)
+static bool host_bounds(const float *xyz, int64_t n, int64_t stride, double mn[3], double mx[3]) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool finite = true;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *p = xyz + i * stride;
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); finite = finite && std::isfinite(p[a]); }
+    }
+    for (int a = 0; a < 3; ++a) { mn[a] = lo[a]; mx[a] = hi[a]; }
+    return finite;
 }
 
 static int device_bounds(dcreg_ctx *c, const float4 *pts, int64_t n, double mn[3], double mx[3]) {
@@ -271,8 +285,13 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) return rc;
     // Hilbert-curve order in the body frame (pose independent: a rigid motion keeps neighbours neighbours)
     double mn[3], mx[3];
-    rc = device_bounds(c, c->d_src_raw, n, mn, mx);
-    if (rc) return rc;
+    const bool small_host = !on_device && n <= 65536;        // a frame from a host buffer: the registration path (icp_test_runner.cpp:442-461)
+    if (small_host) {
+        (void)host_bounds(xyz, n, stride, mn, mx);            // (non-finite coordinates: treated as by the device path - they order somewhere)
+    } else {
+        rc = device_bounds(c, c->d_src_raw, n, mn, mx);
+        if (rc) return rc;
+    }
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
     const double inv_q = 2097151.0 / ext * 0.999999;
     {   // farthest corner of the bounding box: no point is farther from the body-frame origin
@@ -288,11 +307,18 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         HIP_TRY(c, hipMemcpyAsync(c->d_src, c->d_src_raw, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
     } else {
         hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
-        rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n);
+        // the curve is resolved as far as the cloud can tell cells apart: log8(n) levels + 4 (a 4096-fold finer grid than one point
+        // per cell) - 27 key bits for an 8 k-point frame instead of 63, i.e. half the radix passes; points that share the prefix keep
+        // their input order (the sort is stable)
+        int levels = 4;
+        while (levels < 21 && ((int64_t)1 << (3 * (levels - 4))) < n) ++levels;
+        rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n, 63 - 3 * levels);
         if (rc) return rc;
         hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (a small frame from a host buffer: no stream synchronise - the first linearisation queues behind the sort, the staging copy of the
+    // caller's buffer is over when hipMemcpyAsync returns, and a device fault surfaces at that linearisation)
+    if (!small_host) HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
     {   // dispatch groups of the single-pose launches (kernels.hpp k_group_cost): multiples of 16 query blocks, at most kMaxGroups of them
@@ -539,7 +565,9 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
                 GateHost *hg = nullptr; GateDev *gd = nullptr;
                 bool ok = hipHostMalloc((void **)&hg, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-                ok = ok && hipMalloc((void **)&gd, sizeof(GateDev)) == hipSuccess && hipMemset(gd, 0, sizeof(GateDev)) == hipSuccess;
+                // (cleared IN THE STREAM: the ctx stream does not synchronise with the null stream, and a memset that lands after the
+                // first gated launch has written the record would wipe the pose from under its waves)
+                ok = ok && hipMalloc((void **)&gd, sizeof(GateDev)) == hipSuccess && hipMemsetAsync(gd, 0, sizeof(GateDev), c->stream) == hipSuccess;
                 void *dgh = nullptr;
                 ok = ok && hipHostGetDevicePointer(&dgh, hg, 0) == hipSuccess;
                 if (!ok) {
@@ -1142,11 +1170,12 @@ int dcreg_gate_wait(dcreg_ctx *c, double *us_total, int64_t *launches, int reset
     if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it first"); return DCREG_E_STATE; }
     GateDev g;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(&g, c->d_gate_dev, sizeof(g), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(&g, c->d_gate_dev, sizeof(g), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (us_total) *us_total = (double)g.wait_ticks * 0.01;       // 100 MHz wall clock
     if (launches) *launches = (int64_t)g.waits;
     if (reset) {
-        HIP_TRY(c, hipMemset((char *)c->d_gate_dev + offsetof(GateDev, wait_ticks), 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync((char *)c->d_gate_dev + offsetof(GateDev, wait_ticks), 0, 2 * sizeof(unsigned long long), c->stream));
     }
     return DCREG_OK;
 }

@@ -252,11 +252,10 @@ constexpr int kGateWords = 14;
 constexpr unsigned long long kGateTimeoutTicks = 12000000000ull;     // 120 s
 struct alignas(128) GateHost { unsigned long long w[32]; };
 constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
-// the device side of the gate: written by the polling wave, read by every wave of the launch (agent scope)
+// the device side of the gate: a replica of the host record (same 14 words, same checksum), written by the polling wave and read by
+// every wave of the launch with agent-scope loads
 struct alignas(128) GateDev {
-    unsigned long long seq_done;       // number of the last gated launch whose pose (or abort) has reached the device
-    unsigned long long abort;          // ... and whether it was called off
-    double pose[12];                   // R (9), t (3) of that launch
+    unsigned long long w[16];          // w[0] = (launch number << 1) | abort, w[1..12] = R, t, w[13] = kGateSalt ^ w[0] ^ ... ^ w[12]
     unsigned long long wait_ticks, waits;   // statistics: wall-clock ticks (100 MHz) the polling waves spent between kernel start and pose
 };
 struct GateArgs {
@@ -264,53 +263,67 @@ struct GateArgs {
     GateDev *dev;
     unsigned long long want;           // this launch's number
 };
-// called by every wave of a gated launch, after its pose-independent loads are in flight.  Returns false when the launch was called off.
-__device__ __forceinline__ bool gate_wait(const GateArgs &gt, PoseArg &P) {
+// one lane-parallel read of a 14-word gate record (host or device copy): the words (lane l < 14 holds w[l]) and whether they form a
+// whole record (checksum) - uniform results in `seq` (w[0]) and the return value
+template <int SCOPE>
+__device__ __forceinline__ bool gate_read(const unsigned long long *rec, unsigned long long &v, unsigned long long &seq) {
+    const int lane = threadIdx.x & 63;
+    v = lane < kGateWords ? __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, SCOPE) : 0ull;
+    unsigned long long x = v;          // xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+        x ^= ((unsigned long long)hi << 32) | lo;
+    }
+    const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    seq = ((unsigned long long)shi << 32) | slo;
+    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
+}
+// Called by every wave of a gated launch once its pose-independent loads are in flight; `v` / `seq` / `whole` = the wave's read of the
+// DEVICE record, requested together with those loads (gate_read<agent> at the top of k_lin): a wave dispatched after the pose has
+// reached the device - all but the first wave-load of a launch - finds the record whole and its own, and pays no memory round trip for
+// the gate at all.  Returns false when the launch was called off.
+__device__ __forceinline__ bool gate_wait(const GateArgs &gt, unsigned long long v, unsigned long long seq, bool whole, PoseArg &P) {
     const int lane = threadIdx.x & 63;
     GateDev *gd = gt.dev;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
-        const unsigned long long t0 = wall_clock64();
-        unsigned long long v = 0, seq = 0;
-        for (;;) {
-            v = lane < kGateWords ? __hip_atomic_load(&gt.host->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-            // x = xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
-            unsigned long long x = v;
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) {
-                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
-                x ^= ((unsigned long long)hi << 32) | lo;
+    if (!(whole && (seq >> 1) == gt.want)) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+            // the polling wave: host record -> device record
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long hv = 0, hseq = 0;
+            bool call_off = false;
+            for (;;) {
+                const bool hw = gate_read<__HIP_MEMORY_SCOPE_SYSTEM>(gt.host->w, hv, hseq);
+                if ((hseq >> 1) == gt.want && hw) break;
+                // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this wave ever ran
+                if (((hseq >> 1) > gt.want && hw) || wall_clock64() - t0 > kGateTimeoutTicks) { call_off = true; break; }     // (or nobody opens)
+                __builtin_amdgcn_s_sleep(2);
             }
-            const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-            seq = ((unsigned long long)shi << 32) | slo;                        // lane 0's word
-            const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-            const bool whole = (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
-            if ((seq >> 1) == gt.want && whole) break;
-            // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this wave ever ran
-            if ((seq >> 1) > gt.want && whole) { seq = (gt.want << 1) | 1ull; break; }
-            if (wall_clock64() - t0 > kGateTimeoutTicks) { seq = (gt.want << 1) | 1ull; break; }     // nobody opens - give up
-            __builtin_amdgcn_s_sleep(2);
+            if (call_off) {             // an abort record of this launch's number (the pose words are whatever they were: nobody reads them)
+                hv = lane == 0 ? ((gt.want << 1) | 1ull) : (lane < kGateWords - 1 ? hv : 0ull);
+                unsigned long long x = lane < kGateWords - 1 ? hv : 0ull;
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+                    x ^= ((unsigned long long)hi << 32) | lo;
+                }
+                if (lane == kGateWords - 1) hv = x ^ kGateSalt;
+            }
+            if (lane < kGateWords) __hip_atomic_store(&gd->w[lane], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) { gd->wait_ticks += wall_clock64() - t0; gd->waits += 1ull; }
         }
-        if (lane >= 1 && lane <= 12) __hip_atomic_store((unsigned long long *)&gd->pose[lane - 1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) {
-            __hip_atomic_store(&gd->abort, seq & 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gd->wait_ticks += wall_clock64() - t0; gd->waits += 1ull;
+        // every wave that came too early (the polling one included): until the device record is whole and this launch's
+        for (;;) {
+            whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gd->w, v, seq);
+            if (whole && (seq >> 1) == gt.want) break;
+            __builtin_amdgcn_s_sleep(8);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // pose and abort word are at the coherence point before the number is
-        if (lane == 0) __hip_atomic_store(&gd->seq_done, gt.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // every wave (the polling one included): wait for the number, then take the pose
-    for (;;) {
-        const unsigned long long d = __hip_atomic_load(&gd->seq_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t dlo = __builtin_amdgcn_readfirstlane((uint32_t)d), dhi = __builtin_amdgcn_readfirstlane((uint32_t)(d >> 32));
-        if ((((unsigned long long)dhi << 32) | dlo) >= gt.want) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    const unsigned long long ab = __hip_atomic_load(&gd->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_amdgcn_readfirstlane((uint32_t)ab) != 0u) return false;
-    const unsigned long long w = lane < 12 ? __hip_atomic_load((unsigned long long *)&gd->pose[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if ((seq & 1ull) != 0ull) return false;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), k);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k + 1), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k + 1);
         const double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
         if (k < 9) P.R[k] = d; else P.t[k - 9] = d;
     }
@@ -424,6 +437,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     uint32_t *const SW3 = sbase + kStW3 * ss;
     uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (a gated launch: the device copy of the gate record, requested with the loads above - see gate_wait)
+    unsigned long long gate_v = 0ull, gate_seq = 0ull;
+    bool gate_whole = false;
+    if (gt.host != nullptr) gate_whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gt.dev->w, gate_v, gate_seq);
     // what the fast path needs, in one batch of loads: certificate, reference position, fit word, plane (56 B + the 16 B of the point)
     uint32_t cert = kCertSearch, fitw = kFitNone, q0[3] = {0u, 0u, 0u};
     dbl2 p01 = {0.0, 0.0}, p23 = {0.0, 0.0};
@@ -434,7 +451,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     }
     // a gated launch: the pose arrives now (the loads above are in flight meanwhile); pose1 carried state / fresh only
     if (gt.host != nullptr) {
-        if (!gate_wait(gt, P)) return;              // called off: every wave of the launch returns here, before any barrier
+        if (!gate_wait(gt, gate_v, gate_seq, gate_whole, P)) return;    // called off: every wave of the launch returns here, before any barrier
     }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
