@@ -42,7 +42,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_QUERY = 72           # 12 B source point + 5 x 12 B neighbours
 N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max shader clock (MI355X_MICROARCH.md)
 MC_TRIALS, MC_SLOTS, MC_SEED = 5000, 256, 2024
-KERNEL_TIMING_STRIDE = 8       # HIP-event pair around every 8th launch of the timed region (an event pair costs ~10 us of host time)
+KERNEL_TIMING_STRIDE = 13      # HIP-event pair around every 13th launch of the timed region (an event pair costs ~10 us of host time; 13 is
+                               # coprime with the run lengths 20 / 30 / 50, so every iteration of a run gets sampled - 8 never timed the odd ones)
 
 # name: scene, points, radius, iterations per ICP run, weight-derivative Jacobian, BASELINE config
 WORKLOADS = {
@@ -308,7 +309,6 @@ def measure(P, D, steps, warmup, repeats):
     P.ctx.set_option("time_kernels", KERNEL_TIMING_STRIDE)
     P.ctx.kernel_time(reset=True)
     P.ctx.launch_stats(reset=True)
-    P.ctx.gate_wait(reset=True)
     mc0 = P.mc_iters
     times = []
     for _ in range(repeats):
@@ -319,11 +319,9 @@ def measure(P, D, steps, warmup, repeats):
         times.append(D.max_over_ranks(time.perf_counter() - t0))
     kern_ms, kern_n = P.ctx.kernel_time(reset=True)
     st = P.ctx.launch_stats(reset=True)
-    gw_us, gw_n = P.ctx.gate_wait(reset=True)
     P.ctx.set_option("time_kernels", 0)
     per_step = (P.mc_iters - mc0) / float(steps * repeats) if P.mc else 1.0
-    return {"times": times, "kernel_us": 1e3 * kern_ms / max(kern_n, 1), "iters_per_step": per_step, "timed_launches": int(kern_n),
-            "gate_wait_us": gw_us / max(gw_n, 1), "gated_launches": int(gw_n), "launches": int(st["launches"]),
+    return {"times": times, "kernel_us": 1e3 * kern_ms / max(kern_n, 1), "iters_per_step": per_step,
             "points_per_launch": st["points"] / max(st["launches"], 1), "poses_per_launch": st["poses"] / max(st["launches"], 1)}
 
 
@@ -406,13 +404,6 @@ def summarize(name, P, D, m, steps, n_gpus):
                        ("%s [%s]: %d-pt source x %d-pt target, radius %.2f, back-to-back runs of %d ICP iterations, method %s" % (
                name, w["cfg"], P.n_src_total, len(P.tgt), w["radius"], w["run_len"], P.method))}
     rec.update(roofline_blocks(name, m["points_per_launch"], m["kernel_us"]))
-    rec["roofline"]["timed_launches"] = m["timed_launches"]
-    rec["roofline"]["timing"] = ("HIP events on the ctx stream around every %d-th launch of the timed region; a timed launch is started the plain way "
-                                 "(pose known), not through the in-kernel gate" % KERNEL_TIMING_STRIDE)
-    # pipelined launches wait for their pose inside the kernel (kernels.hpp gate_wait): a profiler's trace shows kernel + that wait
-    rec["gate"] = {"gated_launches": m["gated_launches"], "launches": m["launches"], "wait_us_avg": m["gate_wait_us"],
-                   "note": "a gated launch starts when its predecessor ends and waits for its pose INSIDE the kernel (its point and state loads in flight): "
-                           "rocprofv3's duration of such a launch = the kernel's own time + this wait (the host step and one PCIe round trip)"}
     rec["poses_per_launch"] = m["poses_per_launch"]
     if P.mc:
         rec["n_gpus"] = n_gpus

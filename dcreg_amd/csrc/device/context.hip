@@ -4,7 +4,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
-#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -70,15 +69,13 @@ static int sort_pairs_u64(dcreg_ctx *c, uint64_t *keys_in, uint64_t *keys_out, u
 
 // bounding box of a cloud the caller handed over in HOST memory, for clouds small enough that a loop over them costs less than the
 // kernel + copy + stream synchronise of device_bounds (a frame of a few thousand points: the per-registration path)
-static bool host_bounds(const float *xyz, int64_t n, int64_t stride, double mn[3], double mx[3]) {
+static void host_bounds(const float *xyz, int64_t n, int64_t stride, double mn[3], double mx[3]) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    bool finite = true;
     for (int64_t i = 0; i < n; ++i) {
         const float *p = xyz + i * stride;
-        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); finite = finite && std::isfinite(p[a]); }
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
     }
     for (int a = 0; a < 3; ++a) { mn[a] = lo[a]; mx[a] = hi[a]; }
-    return finite;
 }
 
 static int device_bounds(dcreg_ctx *c, const float4 *pts, int64_t n, double mn[3], double mx[3]) {
@@ -287,7 +284,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     double mn[3], mx[3];
     const bool small_host = !on_device && n <= 65536;        // a frame from a host buffer: the registration path (icp_test_runner.cpp:442-461)
     if (small_host) {
-        (void)host_bounds(xyz, n, stride, mn, mx);            // (non-finite coordinates: treated as by the device path - they order somewhere)
+        host_bounds(xyz, n, stride, mn, mx);
     } else {
         rc = device_bounds(c, c->d_src_raw, n, mn, mx);
         if (rc) return rc;
@@ -467,11 +464,6 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         R9 = eye; t3 = zero; n_poses = 1; state_ids = nullptr; dbg_host = nullptr;
         // results must arrive through the pinned flags: a stream synchronise would wait for the gate, i.e. for its own caller
         if (!c->opt_spin) { c->fail("gated launches need the \"spin\" option (results through pinned flags)"); return DCREG_E_STATE; }
-        // a launch that is to be TIMED (option "time_kernels": HIP events around it) is not gated: a gated kernel waits for its pose
-        // inside, and that wait is the host's time, not the kernel's.  The caller starts it the plain way once the pose exists.
-        if (c->opt_time_kernels > 0 && (c->launch_counter % (uint64_t)c->opt_time_kernels) == 0) {
-            c->fail("the next launch is a timed one: not gated"); return DCREG_E_STATE;
-        }
     }
     if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
     LinSlot &S = c->slots[slot];
@@ -563,23 +555,23 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         }
         if (gated) {
             if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
-                GateHost *hg = nullptr; GateDev *gd = nullptr;
+                GateHost *hg = nullptr; PoseArg *dp = nullptr; uint32_t *da = nullptr;
                 bool ok = hipHostMalloc((void **)&hg, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-                // (cleared IN THE STREAM: the ctx stream does not synchronise with the null stream, and a memset that lands after the
-                // first gated launch has written the record would wipe the pose from under its waves)
-                ok = ok && hipMalloc((void **)&gd, sizeof(GateDev)) == hipSuccess && hipMemsetAsync(gd, 0, sizeof(GateDev), c->stream) == hipSuccess;
+                ok = ok && hipMalloc((void **)&dp, sizeof(PoseArg)) == hipSuccess && hipMalloc((void **)&da, sizeof(uint32_t)) == hipSuccess;
                 void *dgh = nullptr;
                 ok = ok && hipHostGetDevicePointer(&dgh, hg, 0) == hipSuccess;
                 if (!ok) {
                     if (hg) (void)hipHostFree(hg);
-                    if (gd) (void)hipFree(gd);
+                    if (dp) (void)hipFree(dp);
+                    if (da) (void)hipFree(da);
                     c->state_valid = state_was_valid;
                     c->fail("allocating the launch gate failed");
                     return DCREG_E_NOMEM;
                 }
                 std::memset(hg, 0, sizeof(GateHost));
-                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_dev = gd;
+                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_pose = dp; c->d_gate_abort = da;
             }
+            d_poses = c->d_gate_pose;
         }
     } else {
         // batched poses: each may own one of the reserved states (dcreg_reserve_warm_states); -1 = search cold, keep nothing
@@ -649,7 +641,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
     bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
     if (timed && !S.ev0) timed = hipEventCreate(&S.ev0) == hipSuccess && hipEventCreate(&S.ev1) == hipSuccess;
-    GateArgs gt{nullptr, nullptr, 0ull};
+    const uint32_t *abort_flag = nullptr;
     // a launch that was queued and must not run after all (errors below): call the gate off, forget what the states were about to hold
     auto bail = [&](const char *what, hipError_t e) {
         free_tmp(S);
@@ -658,8 +650,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         c->fail("%s failed: %s", what, hipGetErrorString(e));
         return DCREG_E_DEVICE;
     };
-    if (gated) gt = GateArgs{c->d_gate_host, c->d_gate_dev, ++c->gate_seq};      // the launch waits for its pose itself (kernels.hpp gate_wait)
-    if (timed) {
+    if (gated) {
+        const unsigned long long want = ++c->gate_seq;
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, one.fresh, c->d_gate_abort);
+        abort_flag = c->d_gate_abort;
+    }
+    if (timed) {                           // after the gate: the events bracket the linearisation, not the wait for the pose
         const hipError_t ee = hipEventRecord(S.ev0, c->stream);
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
@@ -668,7 +664,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
     hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
-                       S.d_partials, nbx, fin, dd, gt)
+                       S.d_partials, nbx, fin, dd, abort_flag)
         if (stamps_only) DCREG_LAUNCH_LIN(2, true, true);
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
@@ -954,7 +950,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->h_gate) (void)hipHostFree(c->h_gate);
     if (c->h_euler) (void)hipHostFree(c->h_euler);
     if (c->d_euler) (void)hipFree(c->d_euler);
-    if (c->d_gate_dev) (void)hipFree(c->d_gate_dev);
+    if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
+    if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
     if (c->d_group_est) (void)hipFree(c->d_group_est);
     kdtree_free(c->kd); c->kd = nullptr;
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
@@ -1160,24 +1157,6 @@ int dcreg_launch_series(dcreg_ctx *c, double *ms, int64_t *searched, int64_t *re
     const int64_t total = (int64_t)c->launch_series.size();
     if (reset) c->launch_series.clear();
     return (int)std::min<int64_t>(total, 0x7FFFFFFF);
-}
-
-int dcreg_gate_wait(dcreg_ctx *c, double *us_total, int64_t *launches, int reset) {
-    if (!c) return DCREG_E_INVALID;
-    if (us_total) *us_total = 0.0;
-    if (launches) *launches = 0;
-    if (!c->d_gate_dev) return DCREG_OK;
-    if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it first"); return DCREG_E_STATE; }
-    GateDev g;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&g, c->d_gate_dev, sizeof(g), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (us_total) *us_total = (double)g.wait_ticks * 0.01;       // 100 MHz wall clock
-    if (launches) *launches = (int64_t)g.waits;
-    if (reset) {
-        HIP_TRY(c, hipMemsetAsync((char *)c->d_gate_dev + offsetof(GateDev, wait_ticks), 0, 2 * sizeof(unsigned long long), c->stream));
-    }
-    return DCREG_OK;
 }
 
 int dcreg_kernel_time(dcreg_ctx *c, double *ms_total, int64_t *launches, int reset) {

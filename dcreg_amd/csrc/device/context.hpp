@@ -104,7 +104,8 @@ struct dcreg_ctx {
     // linearisation: per-slot buffers (see linearize_begin / linearize_end)
     // gate of pipelined launches (kernels.hpp k_gate): pinned sequence number + pose, the device-resident pose it fills, abort word
     dcreg::GateHost *h_gate = nullptr, *d_gate_host = nullptr;
-    dcreg::GateDev *d_gate_dev = nullptr;  // ... and the device-resident record the polling wave fills for the rest of the launch
+    dcreg::PoseArg *d_gate_pose = nullptr;
+    uint32_t *d_gate_abort = nullptr;
     unsigned long long gate_seq = 0;       // number of the gated launch last queued
     int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)
     bool gate_uses_state = false;          // what the queued launch was built with: it reads / writes the ctx's own state,

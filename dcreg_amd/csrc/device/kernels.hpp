@@ -235,16 +235,13 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // ---------------------------------------------------------------- the gate of a pipelined launch
 // An ICP loop alternates one linearisation and a 3 us host step, and every launch costs ~4 us of host time plus ~2 us until the
 // device starts: idle time for a device that has nothing else queued.  A GATED linearisation is queued while its predecessor still
-// runs, before its pose exists, and waits for it ON THE DEVICE, inside k_lin: the first wave of the first block polls a small record in
-// pinned host memory; when the host publishes the pose there, that wave copies it into a device-resident record and raises the
-// launch's number in it; every other wave of the launch - resident by then, its point and state loads issued: they do not depend on
-// the pose - spins on that number in L2 and goes on.  The host can also call the launch off (abort bit): every wave then returns.
-// (Round 2-3 had the gate as a one-wave kernel of its own in front of the linearisation: a kernel boundary - 2-3 us - between "pose on
-// the device" and the first useful instruction of every iteration, and the loads behind it.)
+// runs, before its pose exists: k_gate (one wave) sits in the stream in front of it and polls a small record in pinned host
+// memory; when the host publishes the pose there, the gate copies it into the device-resident PoseArg the linearisation reads,
+// and retires.  The host can also call the launch off (abort bit): the kernels behind the gate then return at once.
 // A gate that waits longer than kGateTimeoutTicks (wall clock, 100 MHz; far longer than the host ever waits for a result) aborts by
-// itself, so a vanished host cannot leave the device spinning.
+// itself, so a vanished host cannot leave the queue spinning.
 // The gate record: 14 words of pinned, host-coherent memory.  w[0] = (launch number << 1) | abort, w[1..9] = R, w[10..12] = t (bit
-// patterns of doubles), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The polling wave reads all words with ONE load
+// patterns of doubles), w[13] = kGateSalt ^ w[0] ^ ... ^ w[12].  The gate reads all words with ONE load
 // per lane and accepts them only if the number is the awaited one AND the checksum holds: the loads of one poll may be served in
 // any order relative to the host's stores, a torn snapshot fails the checksum and is simply polled again - one PCIe round trip
 // between "pose published" and "pose on the device", whatever the read granularity of the link.
@@ -252,82 +249,35 @@ constexpr int kGateWords = 14;
 constexpr unsigned long long kGateTimeoutTicks = 12000000000ull;     // 120 s
 struct alignas(128) GateHost { unsigned long long w[32]; };
 constexpr unsigned long long kGateSalt = 0x9E3779B97F4A7C15ull;
-// the device side of the gate: a replica of the host record (same 14 words, same checksum), written by the polling wave and read by
-// every wave of the launch with agent-scope loads
-struct alignas(128) GateDev {
-    unsigned long long w[16];          // w[0] = (launch number << 1) | abort, w[1..12] = R, t, w[13] = kGateSalt ^ w[0] ^ ... ^ w[12]
-    unsigned long long wait_ticks, waits;   // statistics: wall-clock ticks (100 MHz) the polling waves spent between kernel start and pose
-};
-struct GateArgs {
-    const GateHost *host;              // null: not a gated launch (the pose travels with the kernel arguments)
-    GateDev *dev;
-    unsigned long long want;           // this launch's number
-};
-// one lane-parallel read of a 14-word gate record (host or device copy): the words (lane l < 14 holds w[l]) and whether they form a
-// whole record (checksum) - uniform results in `seq` (w[0]) and the return value
-template <int SCOPE>
-__device__ __forceinline__ bool gate_read(const unsigned long long *rec, unsigned long long &v, unsigned long long &seq) {
-    const int lane = threadIdx.x & 63;
-    v = lane < kGateWords ? __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, SCOPE) : 0ull;
-    unsigned long long x = v;          // xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
+static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__ hg, unsigned long long want, PoseArg *__restrict__ dst,
+                                                   uint32_t fresh, uint32_t *__restrict__ abort_flag) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long v = 0, seq = 0;
+    for (;;) {
+        v = lane < kGateWords ? __hip_atomic_load(&hg->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        // x = xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
+        unsigned long long x = v;
 #pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
-        x ^= ((unsigned long long)hi << 32) | lo;
-    }
-    const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    seq = ((unsigned long long)shi << 32) | slo;
-    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-    return (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
-}
-// Called by every wave of a gated launch once its pose-independent loads are in flight; `v` / `seq` / `whole` = the wave's read of the
-// DEVICE record, requested together with those loads (gate_read<agent> at the top of k_lin): a wave dispatched after the pose has
-// reached the device - all but the first wave-load of a launch - finds the record whole and its own, and pays no memory round trip for
-// the gate at all.  Returns false when the launch was called off.
-__device__ __forceinline__ bool gate_wait(const GateArgs &gt, unsigned long long v, unsigned long long seq, bool whole, PoseArg &P) {
-    const int lane = threadIdx.x & 63;
-    GateDev *gd = gt.dev;
-    if (!(whole && (seq >> 1) == gt.want)) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
-            // the polling wave: host record -> device record
-            const unsigned long long t0 = wall_clock64();
-            unsigned long long hv = 0, hseq = 0;
-            bool call_off = false;
-            for (;;) {
-                const bool hw = gate_read<__HIP_MEMORY_SCOPE_SYSTEM>(gt.host->w, hv, hseq);
-                if ((hseq >> 1) == gt.want && hw) break;
-                // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this wave ever ran
-                if (((hseq >> 1) > gt.want && hw) || wall_clock64() - t0 > kGateTimeoutTicks) { call_off = true; break; }     // (or nobody opens)
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (call_off) {             // an abort record of this launch's number (the pose words are whatever they were: nobody reads them)
-                hv = lane == 0 ? ((gt.want << 1) | 1ull) : (lane < kGateWords - 1 ? hv : 0ull);
-                unsigned long long x = lane < kGateWords - 1 ? hv : 0ull;
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) {
-                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
-                    x ^= ((unsigned long long)hi << 32) | lo;
-                }
-                if (lane == kGateWords - 1) hv = x ^ kGateSalt;
-            }
-            if (lane < kGateWords) __hip_atomic_store(&gd->w[lane], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) { gd->wait_ticks += wall_clock64() - t0; gd->waits += 1ull; }
+        for (int m = 1; m < 32; m <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+            x ^= ((unsigned long long)hi << 32) | lo;
         }
-        // every wave that came too early (the polling one included): until the device record is whole and this launch's
-        for (;;) {
-            whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gd->w, v, seq);
-            if (whole && (seq >> 1) == gt.want) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
+        const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        seq = ((unsigned long long)shi << 32) | slo;                        // lane 0's word
+        const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+        const bool whole = (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
+        if ((seq >> 1) == want && whole) break;
+        // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this gate ever ran
+        if ((seq >> 1) > want && whole) { seq = (want << 1) | 1ull; break; }
+        if (wall_clock64() - t0 > kGateTimeoutTicks) { seq = (want << 1) | 1ull; break; }     // nobody opens - give up
+        __builtin_amdgcn_s_sleep(2);
     }
-    if ((seq & 1ull) != 0ull) return false;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k + 1), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k + 1);
-        const double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-        if (k < 9) P.R[k] = d; else P.t[k - 9] = d;
+    if (lane >= 1 && lane <= 12) {
+        const double d = __longlong_as_double((long long)v);
+        if (lane <= 9) dst->R[lane - 1] = d; else dst->t[lane - 10] = d;
     }
-    return true;
+    if (lane == 0) { dst->state = 0; dst->fresh = fresh; *abort_flag = (uint32_t)(seq & 1ull); }
 }
 
 // ---- the common tail of a block: the wave's rows -> its Gram matrix and counts in LDS (the wave's LDS staging area must be free) ...
@@ -396,7 +346,8 @@ template <int MODE, bool FUSED, bool FAST>
 static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
-                                                          DebugDev dbg, GateArgs gt) {
+                                                          DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
     __shared__ double red[kLinBlock / 32][kSlots];
     __shared__ double cnt[kLinBlock / 64][2];
     __shared__ int s_role;
@@ -437,10 +388,6 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     uint32_t *const SW3 = sbase + kStW3 * ss;
     uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
     const float4 s4 = have_q ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // (a gated launch: the device copy of the gate record, requested with the loads above - see gate_wait)
-    unsigned long long gate_v = 0ull, gate_seq = 0ull;
-    bool gate_whole = false;
-    if (gt.host != nullptr) gate_whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gt.dev->w, gate_v, gate_seq);
     // what the fast path needs, in one batch of loads: certificate, reference position, fit word, plane (56 B + the 16 B of the point)
     uint32_t cert = kCertSearch, fitw = kFitNone, q0[3] = {0u, 0u, 0u};
     dbl2 p01 = {0.0, 0.0}, p23 = {0.0, 0.0};
@@ -448,10 +395,6 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         const uint4 v0 = SV0[i];
         p01 = SV1[i]; p23 = SV2[i];
         cert = v0.x; fitw = v0.y; q0[0] = v0.z; q0[1] = v0.w; q0[2] = SW3[i];
-    }
-    // a gated launch: the pose arrives now (the loads above are in flight meanwhile); pose1 carried state / fresh only
-    if (gt.host != nullptr) {
-        if (!gate_wait(gt, gate_v, gate_seq, gate_whole, P)) return;    // called off: every wave of the launch returns here, before any barrier
     }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);

@@ -37,12 +37,6 @@ int dcreg_linearize_debug(dcreg_ctx *, const double R[9], const double t[3], con
  * of host time), 0 = off */
 int dcreg_kernel_time(dcreg_ctx *, double *ms_total, int64_t *launches, int reset);
 
-/* Gated launches (dcreg_linearize_gated_begin) wait for their pose INSIDE the linearisation kernel: its duration in a profiler's trace
- * contains that wait.  This returns the time (us, device wall clock) the launches since the last reset spent between their start and the
- * arrival of the pose, and their number - what to subtract from a traced duration to get the kernel's own time.  (Launches timed with
- * "time_kernels" are never gated: dcreg_kernel_time is the kernel's own time.) */
-int dcreg_gate_wait(dcreg_ctx *, double *us_total, int64_t *launches, int reset);
-
 /* what the linearisations since the last reset did.  points_searched needs the option "count_searches" = 1 (one atomic per searching
  * wave: off by default) and makes this call wait for the launches queued so far; -1 when the option is off. */
 typedef struct dcreg_launch_stats {

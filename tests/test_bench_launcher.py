@@ -91,3 +91,22 @@ def test_two_ranks_on_one_device_real_workload(sharding):
     assert j["final_stats"]["mean_trans_error_m"] < 0.01
     if sharding == "points":                                          # every rank holds a slice: half the queries per launch
         assert j["roofline"]["algorithmic_bytes_per_launch"] == 72 * 50_000
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_run_the_montecarlo_experiment_as_one_job():
+    """N > 1 without extra flags: after the weak-scaling measurement of the main workload the 5000-trial Monte-Carlo experiment runs ONCE
+    across the ranks (trials k = rank mod N), its trial records are gathered inside the timed region and rank 0 takes the statistics -
+    here with two ranks sharing the box's one device over gloo."""
+    p = _bench(["--gpus", "2", "--steps", "30", "--warmup", "30", "--repeats", "2", "--workload", "c1_fixture_7562", "--no-cpu-baseline",
+                "--concurrent-pairs", "0"], {"DCREG_BENCH_BACKEND": "gloo", "DCREG_BENCH_LOCAL_RANK": "0"}, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = _json_line(p)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and list(j["configs"]) == ["c5_montecarlo_5000"]
+    c5 = j["configs"]["c5_montecarlo_5000"]
+    assert c5["n_gpus"] == 2 and c5["scaling"] == "strong" and c5["rccl_ranks_seen"] == 2
+    st = c5["montecarlo"]["statistics"]
+    assert st["total_runs"] == 5000 and 0.5 < st["success_rate"] < 0.95
+    # all trials, not one rank's share: the iterations of one experiment
+    assert 60_000 < c5["icp_iterations_per_step"] < 100_000 and c5["value"] > 0
