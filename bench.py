@@ -398,6 +398,7 @@ def summarize(name, P, D, m, steps, n_gpus):
     rec = {"value": value, "unit": "iterations/s", "ms_per_step": 1e3 * float(times.sum()) / (steps * len(times)),
            "ms_per_step_median": 1e3 * float(np.median(per_step_s)), "ms_per_step_min": 1e3 * float(per_step_s.min()),
            "ms_per_step_max": 1e3 * float(per_step_s.max()), "repeats": int(len(times)), "steps": steps,
+           "slowest_repeats": [[int(i), 1e3 * float(per_step_s[i])] for i in np.argsort(per_step_s)[::-1][:3]],
            "icp_iterations_per_step": m["iters_per_step"], "correspondence_queries_per_s": value * P.n_src_total,
            "workload": ("%s [%s]: %d-pt source x %d-pt target, radius %.2f, %d trials from seeded initial poses, <= %d ICP iterations each, thresholds on, method %s" % (
                name, w["cfg"], P.n_src_total, len(P.tgt), w["radius"], MC_TRIALS, w["run_len"], P.method)) if P.mc else
@@ -701,6 +702,7 @@ def main(argv=None):
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
             "ms_per_step": main_rec["ms_per_step"], "ms_per_step_median": main_rec["ms_per_step_median"],
             "ms_per_step_min": main_rec["ms_per_step_min"], "ms_per_step_max": main_rec["ms_per_step_max"],
+            "slowest_repeats": main_rec["slowest_repeats"],
             "higher_is_better": True, "scaling": "strong" if P.by_points else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": main_rec["workload"] + (", ONE scan pair, source points split over the GPUs" if P.by_points else ", one scan pair per GPU"),

@@ -640,7 +640,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (fused) S.tickets_dirty = true;    // cleared again once this launch is known to have completed
     // kernel timing: HIP events around every opt_time_kernels-th linearisation (each timed launch costs ~10 us of host time)
     bool timed = c->opt_time_kernels > 0 && (c->launch_counter++ % (uint64_t)c->opt_time_kernels) == 0;
-    if (timed && !S.ev0) timed = hipEventCreate(&S.ev0) == hipSuccess && hipEventCreate(&S.ev1) == hipSuccess;
+    if (timed && !S.ev0) timed = false;               // (the slot's events are created with the context)
     const uint32_t *abort_flag = nullptr;
     // a launch that was queued and must not run after all (errors below): call the gate off, forget what the states were about to hold
     auto bail = [&](const char *what, hipError_t e) {
@@ -937,6 +937,8 @@ int dcreg_backend_create(dcreg_ctx **out, int device) {
         return DCREG_E_DEVICE;
     }
     c->stream = c->own_stream;
+    for (LinSlot &S : c->slots)       // "time_kernels": the events of each slot's launch (created here, not in a timed region)
+        if (hipEventCreate(&S.ev0) != hipSuccess || hipEventCreate(&S.ev1) != hipSuccess) { S.ev0 = S.ev1 = nullptr; }
     *out = c;
     return DCREG_OK;
 }
