@@ -270,6 +270,7 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) { c->n_tgt = 0; return rc; }
     drop_warm(c);            // positions and certificates refer to the old target
     c->order_valid = false;  // ... and the cost estimate of the query groups to the old map
+    c->last_pose_valid = false;
     c->n_batch_states = 0;
     return DCREG_OK;
 }
@@ -328,6 +329,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     c->aux_valid = false;
     drop_warm(c);
     c->n_batch_states = 0;
+    c->last_pose_valid = false;
     return DCREG_OK;
 }
 
@@ -464,6 +466,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         R9 = eye; t3 = zero; n_poses = 1; state_ids = nullptr; dbg_host = nullptr;
         // results must arrive through the pinned flags: a stream synchronise would wait for the gate, i.e. for its own caller
         if (!c->opt_spin) { c->fail("gated launches need the \"spin\" option (results through pinned flags)"); return DCREG_E_STATE; }
+        // A launch that is to be TIMED (option "time_kernels": HIP events around it) is not gated - the caller starts it the plain way
+        // once its pose exists.  Measured (profiles/r04_events_vs_trace.md): the event in front of a gated linearisation is stamped when
+        // the gate kernel STARTS, and that can be long before the previous linearisation ends (its last blocks leave most of the device
+        // idle): events reported 324 us for a launch the kernel trace gives 228 us.
+        if (c->opt_time_kernels > 0 && (c->launch_counter % (uint64_t)c->opt_time_kernels) == 0) {
+            c->fail("the next launch is a timed one: not gated"); return DCREG_E_STATE;
+        }
     }
     if (slot < 0 || slot >= dcreg_ctx::kLinSlots) { c->fail("invalid slot"); return DCREG_E_INVALID; }
     LinSlot &S = c->slots[slot];
@@ -512,6 +521,17 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     const int64_t n = c->n_src;
     a.state = nullptr; a.state_stride = 0;
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
+    if (n_poses == 1 && !state_ids && !gated) {
+        if (c->hint_unknown && c->last_pose_valid) {
+            double dr = 0.0, dt = 0.0;
+            for (int k = 0; k < 9; ++k) dr += (R9[k] - c->last_R[k]) * (R9[k] - c->last_R[k]);
+            for (int k = 0; k < 3; ++k) dt += (t3[k] - c->last_t[k]) * (t3[k] - c->last_t[k]);
+            if (std::sqrt(dr) * c->src_radius + std::sqrt(dt) <= 0.5 * c->grid.h) c->hint_misalign = c->hint_last;      // the same trajectory, continued
+        }
+        c->hint_unknown = false;
+        std::memcpy(c->last_R, R9, sizeof(c->last_R)); std::memcpy(c->last_t, t3, sizeof(c->last_t));
+        c->last_pose_valid = true;
+    }
     {   // heavy groups first: single-pose launches of at least two groups, once the order has been estimated (a gated launch does not
         // know its pose yet: it uses the order there is)
         // (a launch whose blocks are all resident at once - 4 per CU - has no order to speak of)
@@ -1066,7 +1086,8 @@ int dcreg_reserve_warm_states(dcreg_ctx *c, int64_t n_states) {
 }
 int dcreg_hint_misalignment(dcreg_ctx *c, double metres) {
     if (!c) return DCREG_E_INVALID;
-    c->hint_misalign = metres >= 0.0 ? metres : 1e300;       // (NaN: no knowledge)
+    if (metres >= 0.0) { c->hint_misalign = metres; c->hint_last = metres; c->hint_unknown = false; }
+    else { c->hint_misalign = 1e300; c->hint_unknown = true; }            // (also NaN: no knowledge - resolved in linearize_begin)
     return DCREG_OK;
 }
 int dcreg_reset_warm_state(dcreg_ctx *c, int64_t state_id) {
@@ -1083,6 +1104,8 @@ int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
     gate_publish(c, c->gate_seq << 1, R, t);
+    std::memcpy(c->last_R, R, sizeof(c->last_R)); std::memcpy(c->last_t, t, sizeof(c->last_t));
+    c->last_pose_valid = true;
     c->gate_slot = -1;
     return DCREG_OK;
 }

@@ -156,7 +156,13 @@ struct dcreg_ctx {
     bool order_uneven = false;
     double est_R[9] = {}, est_t[3] = {};
     int64_t est_launch = 0;         // n_launches when the estimate was made
-    double hint_misalign = 1e300;   // dcreg_hint_misalignment     // source processed in groups of the curve order, the groups far from the body origin first (kernels.hpp kFarGroup)
+    double hint_misalign = 1e300;   // dcreg_hint_misalignment
+    // "nothing known" (a negative hint: what the engines say at the start of a run) is resolved at the next launch whose pose is known up
+    // front: a pose within half a cell of the last linearised one continues that trajectory - the last hint still describes it (a run
+    // that is stepped through in several engine calls does not pay a cost estimate at the start of each)
+    bool hint_unknown = false;
+    double hint_last = 1e300, last_R[9] = {}, last_t[3] = {};
+    bool last_pose_valid = false;
     bool opt_fused_batches = true; // batched launches of one-chunk poses sum and publish per pose inside k_lin (kernels.hpp FinArgs::chunks_per_pose)
     int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
