@@ -15,7 +15,7 @@ ALL_LIN = "dcreg::k_lin (all instantiations)"
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
-      "Command: `python bench.py --steps 50 --warmup 50 --repeats 4 --no-cpu-baseline --no-configs --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
+      "Command: `python bench.py --steps 50 --warmup 50 --repeats 4 --no-cpu-baseline --no-configs --no-regimes --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
       "`rocprofv3 --kernel-trace --stats` and separate `--pmc` passes (scripts/collect_profiles.sh).", ""]
 md[2] = md[2] % wl
 bp = os.path.join(src, "bench_plain.json")
