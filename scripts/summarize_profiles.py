@@ -22,6 +22,7 @@ bp = os.path.join(src, "bench_plain.json")
 if os.path.exists(bp) and os.path.getsize(bp):
     try:
         b = json.loads(open(bp).read().strip().split("\n")[-1])
+        md[2] = md[2].replace("--steps 50 --warmup 50 --repeats 4", "--steps %d --warmup %d --repeats %d" % (b.get("steps", 50), b.get("warmup", 50), b.get("repeats", 4)))
         out["bench_unprofiled"] = {k: b[k] for k in ("value", "ms_per_step", "roofline", "correspondence_queries_per_s") if k in b}
         md += ["Un-profiled bench line: value %.1f it/s, %.3f ms/step, kernel (HIP events) %.2f us, roofline frac %.4f" % (
             b["value"], b["ms_per_step"], b["roofline"]["kernel_us_avg"], b["roofline"]["frac"]), ""]
