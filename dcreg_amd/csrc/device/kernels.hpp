@@ -405,7 +405,6 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
-    bool keep_plane = false;                        // this lane was searched and its five nearest are the set of its stored plane
     KnnResult<5> nn;
     Fit fit;
     uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
@@ -447,25 +446,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
                 if (need && pos6[5] != kNoIdx) tb = team_bound(g, a, pos6, qx, qy, qz, tight);
                 if (!wave_any(need && !tight)) {
                     uint32_t tpos[6], tcert;
-                    float td4 = 0.f, td5 = 0.f;
-                    by_team = team_search6(g, runs[wave].team, a, need_mask, qx, qy, qz, tb, tpos, tcert, td4, td5) == need_mask;
+                    by_team = team_search6(g, runs[wave].team, a, need_mask, qx, qy, qz, tb, tpos, tcert) == need_mask;
                     if (a.search_count && by_team && (threadIdx.x & 63) == 0)      // (statistics: the word next to the search counter)
                         atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2) + 1, (unsigned long long)w_search);
                     if (by_team && need) {
-                        // The search that a failed certificate forces usually returns the five it knew (the certificate was short, not
-                        // wrong).  The plane is a function of that SET (fit_from_set), and the state's first five positions are the set
-                        // of its stored plane (searches and refits both leave them so): same set => same plane, bit for bit - no gather,
-                        // no factorisation, only the new certificates.
-                        bool same = CERT && fitw != kFitNone && !cert_is_out(tcert) && (double)td4 < a.radius_sq;
-#pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            bool hit = false;
-#pragma unroll
-                            for (int k = 0; k < 5; ++k) hit |= tpos[j] == pos6[k];
-                            same = same && hit && tpos[j] != kNoIdx;
-                        }
-                        keep_plane = same;
-                        if (same) fitw = fit_word_of(a, td4, td5, cert_is_set6(tcert), (uint8_t)(fitw & 3u));
                         cert = tcert;
 #pragma unroll
                         for (int j = 0; j < 6; ++j) pos6[j] = tpos[j];
@@ -492,7 +476,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2, __builtin_readcyclecounter()); stamp(6, (unsigned long long)w_search); }
         // level 2 for the lanes that were searched and the lanes whose order may have changed
         const bool set = have_q && !cert_is_out(cert);
-        const bool fitnow = set && ((need && !keep_plane) || refit);
+        const bool fitnow = set && (need || refit);
         w_refit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fitnow && !need));
         if (wave_any(fitnow)) {
             // a SET6 certificate says nothing about which five of the six are nearest: the fit certificate must then cover the gap
@@ -507,17 +491,13 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             }
             if (!use6) pos6[5] = kNoIdx;
             if (fitnow) {
-                uint32_t psort[6];
-                const uint8_t in_r = fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted, psort);
+                const uint8_t in_r = fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, presorted);
                 gate = in_r ? (uint8_t)(fit.word & 3u) : (uint8_t)255;
                 if (keep) {                         // the new reference position, the certificate as seen from there, the fit
                     if (!need) {                    // (the old reference position is read again: three registers less across the search)
                         const uint4 o0 = SV0[iw];
                         const uint32_t o1 = SW3[iw];
                         cert = cert_rebased(cert, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz);
-                        // the positions in the order of this fit: the first five are the set the new plane belongs to
-                        SX[iw] = make_uint4(psort[0], psort[1], psort[2], psort[3]);
-                        if (use6) SY[iw] = make_uint2(psort[4], psort[5]); else reinterpret_cast<uint32_t *>(SY + iw)[0] = psort[4];
                     }
                     SV0[iw] = make_uint4(cert, fit.word, __float_as_uint(qx), __float_as_uint(qy));
                     SV1[iw] = dbl2{fit.plane[0], fit.plane[1]};
@@ -527,14 +507,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             }
         }
         if constexpr (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3, __builtin_readcyclecounter()); stamp(7, (unsigned long long)w_refit); }
-        if (level3 || keep_plane) {                 // the lanes of this wave whose stored plane stands: loaded again
+        if (level3) {                               // the lanes of this wave that needed neither: their stored plane, loaded again
             const dbl2 b01 = SV1[iw], b23 = SV2[iw];
-            if (!keep_plane) fitw = reinterpret_cast<const uint32_t *>(SV0 + iw)[1];
+            fitw = reinterpret_cast<const uint32_t *>(SV0 + iw)[1];
             stored_plane(b01, b23);
-            if (keep_plane && keep) {               // searched, same set: new certificates and reference position around the old plane
-                SV0[iw] = make_uint4(cert, fitw, __float_as_uint(qx), __float_as_uint(qy));
-                SW3[iw] = __float_as_uint(qz);
-            }
         }
         if (!set && need && keep) {                 // searched and found OUT: certificate and reference position, no fit
             SV0[iw] = make_uint4(cert, kFitNone, __float_as_uint(qx), __float_as_uint(qy));

@@ -142,8 +142,6 @@ struct LinArgs {
                                   // and the host splits them again (context.hip linearize_end).  What the host does with them:
                                   // scheduling only (which instantiation the next launch uses) and the launch statistics.  0 for
                                   // clouds of more than 2^26 points.
-    float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
-                                  // reaches this many cells beyond the distance to that cell (lin_search6)
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     const double *dR;             // euler: 27 doubles in device memory - dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll),
                                   // row-major (behind a pointer: as a member the 54 words would be hoisted into registers for every launch)
@@ -1315,7 +1313,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
         bool far = false;
         uint32_t oc = kNoIdx;
         bool in_space = false;            // the query's cell is at least two cells from any occupied one: its 27-cell block is empty
-        const float loose0 = a.far_loose * (float)g.h;
+        const float loose0 = 1.5f * (float)g.h;
         // (a bound within 1.5 cells is tight wherever the query sits: the usual case once a trajectory converges - no field byte is
         // loaded for it, and a wave of such queries skips the block)
         const bool maybe = reach && bound > loose0 * loose0 && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz;
@@ -1324,7 +1322,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
                 const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
                 const int f = (int)g.gap[cell];
                 in_space = f >= 2;
-                const float loose = ((float)f + a.far_loose) * (float)g.h;
+                const float loose = ((float)f + 1.5f) * (float)g.h;
                 if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
             }
             all_in_space = !wave_any(reach && !in_space);
@@ -1425,10 +1423,10 @@ DCREG_DEVFN uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_
 DCREG_DEVFN float shfl_f(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)__float_as_uint(v))); }
 
 // team_mask: the lanes (at most kTeamMax) whose queries (qx, qy, qz, bound: valid in those lanes) are searched.  Returns the lanes
-// that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound), the
-// certificate of the search (make_cert) and the squared distances of the fifth and the sixth.
+// that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound) and
+// the certificate of the search (make_cert).
 DCREG_DEVFN unsigned long long team_search6(const GridDev &g, TeamLds &T, const LinArgs &a, unsigned long long team_mask, float qx, float qy,
-                                            float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out, float &d4_out, float &d5_out) {
+                                            float qz, float bound, uint32_t (&pos_out)[6], uint32_t &cert_out) {
     const int lane = threadIdx.x & (kWave - 1);
     // ---- the rows of all queries: lane 9 k + r = row r of the k-th query
     const int k_of = lane / 9, r_of = lane - 9 * k_of;
@@ -1524,7 +1522,6 @@ DCREG_DEVFN unsigned long long team_search6(const GridDev &g, TeamLds &T, const 
             out.lb7 = n > 6u ? fminf(__uint_as_float(T.out_d2[6]), ub) : ub;
             out.n_eval = 0; out.n_shell = 1;
             cert_out = make_cert(out, a);
-            d4_out = out.d2[4]; d5_out = out.d2[5];
 #pragma unroll
             for (int j = 0; j < 6; ++j) pos_out[j] = out.pos[j];
         }
@@ -1638,25 +1635,11 @@ struct Fit { double plane[4]; uint32_t word; };
 // search at this pose -, radius gate, plane fit, neighbour-only gates, and the fit word that says how far this all stays valid.
 // `six` is uniform over the wave; `nn` receives the ordered five (debug dumps).  Returns 0 (radius gate failed: no plane), else 1 with
 // fit.word's gate bits set.
-// the fit word of a point whose five nearest are d4 (the fifth) and - where the set is only known as "five of these six" - d5 away
-// (squared float distances at its present position), with the outcome `gate` of the neighbour-only gates: how far the SET of the five
-// and the radius gate hold beyond what the set certificate says (2e-6 relative margins on the float distances as in make_cert)
-DCREG_DEVFN uint32_t fit_word_of(const LinArgs &a, float d4, float d5, bool use6, uint8_t gate) {
-    const float sd4 = sqrt_approx(d4), sd5 = sqrt_approx(d5);
-    float s = a.cert_r_in - sd4 * 1.000002f;
-    if (use6) s = fminf(s, 0.5f * (sd5 * 0.999998f - sd4 * 1.000002f));
-    return (__float_as_uint(fmaxf(s, 0.f)) & ~3u) | (uint32_t)gate;
-}
-// pos_sorted (optional): the positions in the canonical order the points were put into - the first five are the set the plane is
-// fitted to (a refit writes them back, so that the state's first five positions are always the set of its stored plane)
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, const uint32_t (&pos)[6], bool six,
-                                 KnnResult<5> &nn, Fit &fit, bool presorted = false, uint32_t *pos_sorted = nullptr) {
+                                 KnnResult<5> &nn, Fit &fit, bool presorted = false) {
     float d2[6];
     float4 pt[6];
-    uint32_t ps[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) ps[j] = pos[j];
     const bool use6 = six && pos[5] != kNoIdx;
 #pragma unroll
     for (int j = 0; j < 5; ++j) pt[j] = g.pts[pos[j]];
@@ -1671,8 +1654,6 @@ DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, f
         const bool sw = ky < kx;
         const float dx = d2[x], dy = d2[y];
         const float4 px = pt[x], py = pt[y];
-        const uint32_t sx_ = ps[x], sy_ = ps[y];
-        ps[x] = sw ? sy_ : sx_; ps[y] = sw ? sx_ : sy_;
         d2[x] = sw ? dy : dx; d2[y] = sw ? dx : dy;
         pt[x].x = sw ? py.x : px.x; pt[x].y = sw ? py.y : px.y; pt[x].z = sw ? py.z : px.z; pt[x].w = sw ? py.w : px.w;
         pt[y].x = sw ? px.x : py.x; pt[y].y = sw ? px.y : py.y; pt[y].z = sw ? px.z : py.z; pt[y].w = sw ? px.w : py.w;
@@ -1697,10 +1678,6 @@ DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, f
 #pragma unroll
     for (int j = 0; j < 5; ++j) { nn.d2[j] = d2[j]; nn.pt[j] = pt[j]; nn.idx[j] = __float_as_uint(pt[j].w); nn.pos[j] = 0u; }
     nn.full = true; nn.n_eval = 0; nn.n_shell = 0;
-    if (pos_sorted) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) pos_sorted[j] = ps[j];
-    }
     fit.word = 0u;                                                               // (s = 0: nothing to reuse)
     fit.plane[0] = fit.plane[1] = fit.plane[2] = fit.plane[3] = 0.0;
     if (!((double)d2[4] < a.radius_sq)) return 0;                                // :1726
@@ -1724,9 +1701,12 @@ DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, f
     }
     const uint8_t gate = plane_of_set<FASTMATH>(a, byidx, fit.plane);
     // how far the SET of the five - and the radius gate - hold beyond what the set certificate says: the room of the fifth below the
-    // radius and, when the set is "five of these six", half the gap between the fifth and the sixth.  (Equal fifth and sixth distances
-    // give 0: such a query is refitted every time.)
-    fit.word = fit_word_of(a, d2[4], d2[5], use6, gate);
+    // radius and, when the set is "five of these six", half the gap between the fifth and the sixth; 2e-6 relative margins on the float
+    // distances as in make_cert.  (Equal fifth and sixth distances give 0: such a query is refitted every time.)
+    const float sd4 = sqrt_approx(d2[4]), sd5 = sqrt_approx(d2[5]);
+    float s = a.cert_r_in - sd4 * 1.000002f;
+    if (use6) s = fminf(s, 0.5f * (sd5 * 0.999998f - sd4 * 1.000002f));
+    fit.word = (__float_as_uint(fmaxf(s, 0.f)) & ~3u) | (uint32_t)gate;
     return 1;
 }
 DCREG_DEVFN bool fit_holds(uint32_t word, float q0x, float q0y, float q0z, float qx, float qy, float qz) {

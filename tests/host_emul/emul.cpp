@@ -282,7 +282,6 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     while (k < 100000) { const double safe = (double)k * g.h * (1.0 - 1e-9); if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break; ++k; }
     a.max_ring = k;
     a.warm = warm;
-    a.far_loose = 1.5f;
     a.prune_infl = (float)((1.0 + p->cert_inflate) * (1.0 + p->cert_inflate));
     a.infl_max_d2 = (float)(4.0 * g.h * g.h);
     a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0; a.dR = nullptr;
