@@ -354,6 +354,7 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     a.w_slope = p->weight_slope; a.w_min = p->weight_min; a.use_wd = p->use_weight_derivative;
     a.warm = c->opt_warm ? 1 : 0;
     a.team_max = std::min(std::max(c->opt_team_max, 0), kTeamMax);
+    a.far_loose = (float)c->opt_far_loose;
     a.prune_infl = (float)((1.0 + c->opt_cert_inflate) * (1.0 + c->opt_cert_inflate));
     a.infl_max_d2 = (float)(4.0 * c->grid.h * c->grid.h);
     int k = 1;
@@ -1030,6 +1031,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
+    else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host

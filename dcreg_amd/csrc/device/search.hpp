@@ -142,6 +142,8 @@ struct LinArgs {
                                   // and the host splits them again (context.hip linearize_end).  What the host does with them:
                                   // scheduling only (which instantiation the next launch uses) and the launch statistics.  0 for
                                   // clouds of more than 2^26 points.
+    float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
+                                  // reaches this many cells beyond the distance to that cell (lin_search6)
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
     const double *dR;             // euler: 27 doubles in device memory - dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll),
                                   // row-major (behind a pointer: as a member the 54 words would be hoisted into registers for every launch)
@@ -352,13 +354,8 @@ DCREG_DEVFN float sqrt_approx(float x) {
 }
 
 struct RunList;
-<<<<<<< Updated upstream
 template <class H, bool SWEEP, bool NOTE>
 DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, float qz, int cx, int cy, int cz,
-=======
-template <class H>
-DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, int tid, float qx, float qy, float qz, int cx, int cy, int cz,
->>>>>>> Stashed changes
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp);
 
 // Per-thread list of the non-empty x-runs of the 3x3x3 block, kept in LDS ([slot][thread]: conflict-free).
@@ -421,7 +418,6 @@ DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, fl
     }
 }
 
-<<<<<<< Updated upstream
 // The same run with DEFERRED insertion (the rows of the sweep: a far query scans hundreds of candidates of which a few per cent can
 // still enter once the first rows have tightened the ball): a candidate is filtered against the pruning bound as of the last flush
 // - one compare instead of the sorted insertion - and, if it passes, parked in the lane's pending list; the list
@@ -546,18 +542,11 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
     // ---- phase B: flattened walk over the runs (the wave iterates max-over-lanes of the total, not the
     // sum of per-row maxima), 4 candidates in flight per trip
     if (!empty_block) {
-=======
-// Flattened, software-pipelined scan of the `nrun` runs listed for this lane in rl (the 9 rows of the centre block, or a batch of
-// ring rows): the wave iterates max-over-lanes of the TOTAL trip count, not the sum of per-row maxima - a lane whose run sits
-// in row 3 and a lane whose run sits in row 7 scan side by side.  4 candidates in flight per trip, deferred insertion.
-template <class H>
-DCREG_DEVFN void scan_listed_runs(const GridDev &g, RunList &rl, int tid, int nrun, float qx, float qy, float qz, H &hp) {
->>>>>>> Stashed changes
         int ri = 0;
         uint32_t p = 0, e = 0;
         // deferred insertion state: lim = the lane's filter bound (the heap's K-th best as of the last flush: nothing at or
         // beyond it can enter), om = smallest distance among the candidates filtered out, cnt = pending entries
-        float lim = hp.worst_d2(), om = __builtin_inff();
+        float lim = bound_f, om = __builtin_inff();
         int cnt = 0;
         // switch to the next listed row (one per call, no inner loop: a row that the K-th best has meanwhile put out
         // of reach becomes an empty run and costs one idle trip, which is rare once the search is bounded)
@@ -631,70 +620,7 @@ DCREG_DEVFN void scan_listed_runs(const GridDev &g, RunList &rl, int tid, int nr
             flush();
             hp.note_outside(om);
         }
-}
-
-// Exact K nearest neighbours of q among points closer than sqrt(bound) ; returns with the heap filled.
-// Ring k covers all cells at Chebyshev distance <= k from the query's cell; after ring k every point
-// closer than k*h is in the heap, so the search stops as soon as the K-th best is inside that ball or
-// the ball covers the search radius.
-template <class H>
-DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
-                                           int max_ring, H &hp, unsigned long long *stamp = nullptr) {   // max_ring < 0: unbounded
-    hp.init(bound_f);
-    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
-    const double lim = (double)max_ring + 1.0;
-    if (max_ring >= 0) {
-        // bounded search: a query farther than max_ring cells from the grid has no neighbour inside the radius
-        if (fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim) return;
     }
-    const double big = 1.0e9;
-    const double flx = floor(fmin(fmax(fx, -big), big)), fly = floor(fmin(fmax(fy, -big), big)), flz = floor(fmin(fmax(fz, -big), big));
-    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
-    const int nx = g.nx, ny = g.ny, nz = g.nz;
-    if (max_ring < 0) {   // unbounded: enough rings to sweep the whole grid from this cell
-        const int ex = max(abs(cx), abs(cx - (nx - 1))), ey = max(abs(cy), abs(cy - (ny - 1))), ez = max(abs(cz), abs(cz - (nz - 1)));
-        max_ring = max(ex, max(ey, ez)) + 1;
-    }
-
-    // ---- rings 0+1, phase A: the 9 (y,z) rows of the 3x3x3 block, each one contiguous x-run; all 18 table
-    // loads are issued together, empty / out-of-reach rows are dropped, nearest rows come first
-    const int tid = threadIdx.x;
-    int nrun = 0;
-    {
-        const float hf = (float)g.h;
-        const float frx = (float)(fx - flx), fry = (float)(fy - fly), frz = (float)(fz - flz);
-        const float gxl = frx * hf, gxh = (1.f - frx) * hf;
-        const float gyl = fry * hf, gyh = (1.f - fry) * hf, gzl = frz * hf, gzh = (1.f - frz) * hf;
-        // visiting order (dy,dz): centre, 4 edge rows, 4 corner rows
-        constexpr int DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-        constexpr int DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-        uint32_t rs[9], re[9];
-        float g2s[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const float gy = DY[r] < 0 ? gyl : (DY[r] > 0 ? gyh : 0.f), gz = DZ[r] < 0 ? gzl : (DZ[r] > 0 ? gzh : 0.f);
-            const float g2 = (gy * gy + gz * gz) * 0.99999f;
-            g2s[r] = g2;
-            // x-cells of this row the ball of radius sqrt(bound) can reach (conservative): a tight bound (warm
-            // start) trims the three-cell run to one or two cells, or drops the row
-            const float xr = sqrtf(fmaxf(bound_f - g2, 0.f)) * 1.00001f + 1e-6f * hf;
-            const int x0 = clampi(cx - (gxl <= xr ? 1 : 0), 0, nx), x1 = clampi(cx + 1 + (gxh <= xr ? 1 : 0), 0, nx);   // [x0, x1)
-            const int y = cy + DY[r], z = cz + DZ[r];
-            const bool ok = (x1 > x0) && y >= 0 && y < ny && z >= 0 && z < nz && !(g2 > bound_f);
-            const int64_t row = ok ? ((int64_t)z * ny + y) * nx : 0;
-            rs[r] = ok ? g.cell_start[row + x0] : 0u;
-            re[r] = ok ? g.cell_start[row + x1] : 0u;
-            if (ok) { DCREG_STAT(table_loads); DCREG_STAT(table_loads); }
-        }
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            if (re[r] > rs[r]) {
-                rl.s[nrun][tid] = rs[r]; rl.e[nrun][tid] = re[r]; rl.gap2h[nrun][tid] = (uint16_t)(__float_as_uint(g2s[r]) >> 16);
-                ++nrun;
-            }
-        }
-    }
-<<<<<<< Updated upstream
     knn_shells<H, SWEEP, NOTE>(g, rl, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
 }
 
@@ -714,30 +640,6 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
 //     bitmap that spares 88 % of the table lookups were all slower too: profiles/r02_ablation.md).
 template <class H, bool SWEEP, bool NOTE>
 DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, float qz, int cx, int cy, int cz,
-=======
-    if (stamp) stamp[0] = clock64();
-    // ---- phase B: flattened, pipelined scan of the listed runs
-    scan_listed_runs<H>(g, rl, tid, nrun, qx, qy, qz, hp);
-    if (stamp) stamp[1] = clock64();
-    knn_shells<H>(g, rl, tid, qx, qy, qz, cx, cy, cz, fx, fy, fz, bound_f, max_ring, hp);
-}
-
-#if !defined(DCREG_SHELLS_FACES)
-// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment).
-//   COLLECT: the (2kk+1)^2 (y,z) rows of ring kk are swept in lock-step (the loop bounds are the same for every lane of the wave);
-//            kd-tree style pruning on the grid - a row is skipped when its slab is farther than the current K-th best, its x-run is
-//            trimmed to the cells the K-th-best ball can still reach - and the surviving runs (a full row: one trimmed x-run; an
-//            interior row: its two end cells) are only APPENDED to the lane's run list in LDS, as cell indices;
-//   RESOLVE: when some lane's list is nearly full (and at the end of the ring) the cell-table entries of all listed runs are loaded
-//            together;
-//   SCAN   : the listed runs go through the same flattened, pipelined, deferred-insertion scan as the centre block.
-// Why: scanning each row where it is found costs the wave sum-over-rows of the max-lane trip count - the lanes' runs sit in
-// different rows - 57 trips per wave on C4's first iteration where the flattened scan needs 25 (host replay, scripts/emul_c4.py);
-// a face-by-face walk with empty-space culling (below, -DDCREG_SHELLS_FACES) and batching the table loads of four rows both
-// left that sum in place and were slower than the plain sweep on the GPU (profiles/r02_ablation.md).
-template <class H>
-DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, int tid, float qx, float qy, float qz, int cx, int cy, int cz,
->>>>>>> Stashed changes
                                            double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
     const int nx = g.nx, ny = g.ny, nz = g.nz;
     const float hf = (float)g.h;
@@ -755,7 +657,6 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, int tid, float qx, fl
         const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
         k0 = max(1, f - 1);
     }
-<<<<<<< Updated upstream
     auto lookup_scan = [&](int64_t c0, int64_t c1) {
         DCREG_STAT(table_loads); DCREG_STAT(table_loads); DCREG_STAT(faces);
         const uint32_t s_ = g.cell_start[c0], e_ = g.cell_start[c1];
@@ -856,124 +757,12 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, int tid, float qx, fl
                         const int bit = __builtin_ctz(m);
                         m &= m - 1;
                         sweep_row((yw << 5) + bit, z, gz);
-=======
-    constexpr int kCap = 9;                      // RunList rows
-    int nrun = 0;
-    auto process = [&]() {                       // resolve the listed cell indices to point ranges, then scan them
-        DCREG_STAT(faces);
-        uint32_t c0[kCap], c1[kCap];
-#pragma unroll
-        for (int j = 0; j < kCap; ++j) { c0[j] = j < nrun ? rl.s[j][tid] : 0u; c1[j] = j < nrun ? rl.e[j][tid] : 0u; }
-#pragma unroll
-        for (int j = 0; j < kCap; ++j) { c0[j] = g.cell_start[c0[j]]; c1[j] = g.cell_start[c1[j]]; }
-#pragma unroll
-        for (int j = 0; j < kCap; ++j) if (j < nrun) { rl.s[j][tid] = c0[j]; rl.e[j][tid] = c1[j]; }
-        scan_listed_runs<H>(g, rl, tid, nrun, qx, qy, qz, hp);
-        nrun = 0;
-    };
-    auto append = [&](uint32_t cell0, uint32_t cell1, float d2) {
-        rl.s[nrun][tid] = cell0; rl.e[nrun][tid] = cell1; rl.gap2h[nrun][tid] = (uint16_t)(__float_as_uint(d2) >> 16);
-        ++nrun;
-        DCREG_STAT(table_loads); DCREG_STAT(table_loads);
-    };
-    for (int k = k0; k < max_ring; ++k) {
-        // after ring k: every point within k*h (minus a rounding guard) has been seen
-        const double safe = (double)k * g.h * (1.0 - 1e-9);
-        const double safe2 = safe * safe * (1.0 - 1e-6);
-        if ((double)hp.worst_d2() <= safe2) return;             // K-th best already inside the covered ball
-        if (safe2 >= (double)bound_f) return;                   // covered ball contains the search radius
-        const int kk = k + 1;                                   // scan shell kk
-        hp.n_shell = (uint32_t)kk;
-        for (int dz = -kk; dz <= kk; ++dz) {
-            const int z = cz + dz;
-            const float gz = dz < 0 ? (float)(fz - (double)(z + 1)) * hf : (dz > 0 ? (float)((double)z - fz) * hf : 0.f);
-            const bool zok = z >= 0 && z < nz && !(gz * gz * 0.99999f > hp.worst_d2());
-            if (!wave_any(zok)) continue;                       // no lane of the wave reaches this slab
-            for (int dy = -kk; dy <= kk; ++dy) {
-                const int y = cy + dy;
-                const float gy = dy < 0 ? (float)(fy - (double)(y + 1)) * hf : (dy > 0 ? (float)((double)y - fy) * hf : 0.f);
-                const float dyz = (gy * gy + gz * gz) * 0.99999f;
-                const float w = hp.worst_d2();
-                const bool ok = zok && y >= 0 && y < ny && !(dyz > w);
-                if (ok) {
-                    DCREG_STAT(rows);
-                    // cells the ball of radius sqrt(w) around q can reach in this row (conservative)
-                    const float xr = sqrtf(w - dyz) * 1.00001f + 1e-6f * hf;
-                    const double xr_c = (double)xr * g.inv_h;
-                    const int xmin = (int)floor(fmax(fx - xr_c, -1.0)), xmax = (int)floor(fmin(fx + xr_c, (double)nx));
-                    const uint32_t row = (uint32_t)(((int64_t)z * ny + y) * nx);
-                    const bool full = (dz == -kk || dz == kk || dy == -kk || dy == kk);
-                    if (full) {
-                        const int x0 = max(max(cx - kk, xmin), 0), x1 = min(min(cx + kk, xmax), nx - 1) + 1;
-                        if (x1 > x0) append(row + (uint32_t)x0, row + (uint32_t)x1, dyz);
-                    } else {
-                        const int xa = cx - kk, xb = cx + kk;
-                        if (xa >= 0 && xa < nx && xa >= xmin) append(row + (uint32_t)xa, row + (uint32_t)xa + 1u, dyz);
-                        if (xb >= 0 && xb < nx && xb <= xmax) append(row + (uint32_t)xb, row + (uint32_t)xb + 1u, dyz);
->>>>>>> Stashed changes
                     }
                 }
-                if (wave_any(nrun > kCap - 2)) process();       // some lane could not take another row's two runs
             }
         }
-<<<<<<< Updated upstream
         return;
     }
-=======
-        if (wave_any(nrun > 0)) process();                      // the K-th best must be current before the next ring is judged
-    }
-}
-
-#else
-// Experiment (rejected on measurement, see above).
-// Rings k >= 2 around cell (cx,cy,cz) (sparse neighbourhoods, cloud borders, large misalignment), global loads.
-// (fx,fy,fz) = query position in cell units.  Ring kk is walked as its six FACES, not as (2kk+1)^2 rows:
-//   * a face whose cell layer lies beyond the current K-th best is dropped by arithmetic alone;
-//   * the empty-space field is read ONCE per remaining face, at the face cell under the query: if its nearest occupied
-//     cell is farther (Chebyshev) than the cap the K-th-best ball cuts out of the face, the whole cap is empty - a query
-//     hovering 6 cells off a wall asks 6 bytes per ring instead of walking ~250 empty cells;
-//   * the rows of a face are visited CENTRE-OUT (the row under the query first), so the heap holds near points before the
-//     far rows are tested, and each side stops at the first row the ball no longer reaches (distances grow monotonically);
-//   * every row's x-run is trimmed to the cells the K-th-best ball can still reach, as before.
-// Exact: a cell is skipped only when its minimal distance to the query exceeds the K-th best, or when the field proves it
-// empty.  Faces: +-z (rows y in [cy-kk, cy+kk]), +-y (rows z in (cz-kk, cz+kk)), +-x (single cells, y and z in the open range).
-// slab distance (metres, float) from the query (cell cq, cell coordinate f) to cell index c along one axis
-DCREG_DEVFN float slab_dist(int c, int cq, double f, float hf) {
-    return c < cq ? (float)(f - (double)(c + 1)) * hf : (c > cq ? (float)((double)c - f) * hf : 0.f);
-}
-
-// centre-out offsets 0, +1, -1, +2, -2, ... up to +-omax; a side is closed when its row falls outside the grid on that side
-// or the caller reports that the ball no longer reaches it
-struct CentreOut {
-    int o, omax;
-    bool plus, up, dn;      // plus: the next offset to hand out is +o (else -o)
-    DCREG_DEVFN void init(int omax_) { o = 0; omax = omax_; plus = true; up = true; dn = true; }
-    // next signed offset, or false when both sides are exhausted
-    DCREG_DEVFN bool next(int &off) {
-        for (;;) {
-            if (o == 0) { o = 1; plus = true; off = 0; return true; }
-            if (o > omax || !(up || dn)) return false;
-            if (plus) { plus = false; if (up) { off = o; return true; } }
-            else { plus = true; const int oo = o; ++o; if (dn) { off = -oo; return true; } }
-        }
-    }
-    DCREG_DEVFN void close(int off) { if (off > 0) up = false; else if (off < 0) dn = false; else { /* centre row: sides stay open */ } }
-};
-
-template <class H>
-DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, int tid, float qx, float qy, float qz, int cx, int cy, int cz,
-                                           double fx, double fy, double fz, float bound_f, int max_ring, H &hp) {
-    const int nx = g.nx, ny = g.ny, nz = g.nz;
-    const float hf = (float)g.h;
-    // empty-space skip: if the nearest occupied cell is f cells away (Chebyshev), rings 1 .. f-1 hold no point
-    int k0 = 1;
-    if (g.gap && cx >= 0 && cx < nx && cy >= 0 && cy < ny && cz >= 0 && cz < nz) {
-        const int f = min((int)g.gap[((int64_t)cz * ny + cy) * nx + cx], g.gap_cap + 1);
-        k0 = max(1, f - 1);
-    }
-    // nearer side of each axis first
-    const bool zf = (fz - (double)cz) >= 0.5, yf = (fy - (double)cy) >= 0.5, xf = (fx - (double)cx) >= 0.5;
->>>>>>> Stashed changes
     for (int k = k0; k < max_ring; ++k) {
         // after ring k: every point within k*h (minus a rounding guard) has been seen
         const double safe = (double)k * g.h * (1.0 - 1e-9);
@@ -1526,7 +1315,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
         bool far = false;
         uint32_t oc = kNoIdx;
         bool in_space = false;            // the query's cell is at least two cells from any occupied one: its 27-cell block is empty
-        const float loose0 = 1.5f * (float)g.h;
+        const float loose0 = a.far_loose * (float)g.h;
         // (a bound within 1.5 cells is tight wherever the query sits: the usual case once a trajectory converges - no field byte is
         // loaded for it, and a wave of such queries skips the block)
         const bool maybe = reach && bound > loose0 * loose0 && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz;
@@ -1535,7 +1324,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
                 const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
                 const int f = (int)g.gap[cell];
                 in_space = f >= 2;
-                const float loose = ((float)f + 1.5f) * (float)g.h;
+                const float loose = ((float)f + a.far_loose) * (float)g.h;
                 if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
             }
             all_in_space = !wave_any(reach && !in_space);

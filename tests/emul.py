@@ -45,11 +45,7 @@ def lib():
         L.emu_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.emu_hilbert_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
-<<<<<<< Updated upstream
                                     C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64, C.c_void_p]
-=======
-                                    C.c_void_p, C.c_int64] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64]
->>>>>>> Stashed changes
         L.emu_plane_fit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         _lib = L
@@ -138,12 +134,8 @@ class Source:
         self.searched = 0          # queries searched by the last linearisation
 
 
-<<<<<<< Updated upstream
 def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0, cert_move=CERT_MOVE,
               plan=None, cert_inflate=CERT_INFLATE):
-=======
-def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debug=False, stats=False, trace_cap=0):
->>>>>>> Stashed changes
     """One linearisation through the device functions on the host -> dict like Context.linearize (+ "stats" [n, 8] in
     processing order: candidates, outermost shell, table loads, rows, runs, trips, faces, face skips).
     plan: None = as context.hip decides ("full" on a fresh state / debug / a pose change that may move a point farther than cert_move
@@ -171,7 +163,6 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
                 "normal": np.zeros((n, 3)), "r": np.zeros(n), "s": np.zeros(n)}
     st = np.zeros((n, 8), np.uint32) if stats else None
     tr = np.zeros((n, trace_cap), np.uint32) if trace_cap else None
-<<<<<<< Updated upstream
     counts = np.zeros(2, np.int64)
     rc = lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(state), source.stride,
                              int(fresh), certify, int(bool(warm)),
@@ -181,13 +172,6 @@ def linearize(index, source, R, t, radius=None, wd=0, fast=True, warm=True, debu
     if warm:
         source.prev_pose = pose
     source.searched = int(counts[0])
-=======
-    R = np.ascontiguousarray(R, np.float64).reshape(9)
-    t = np.ascontiguousarray(t, np.float64).reshape(3)
-    lib().emu_linearize(index.ptr, _ptr(source.sorted), _ptr(source.order), n, _ptr(R), _ptr(t), C.byref(prm), _ptr(prev), source.stride,
-                        _ptr(out), _ptr(keep.get("nn_idx")), _ptr(keep.get("nn_d2")), _ptr(keep.get("flag")), _ptr(keep.get("normal")),
-                        _ptr(keep.get("r")), _ptr(keep.get("s")), _ptr(st), _ptr(tr), int(trace_cap))
->>>>>>> Stashed changes
     res = {"H_upper": out[:21].copy(), "g": out[21:27].copy(), "sum_r2": out[27], "sum_b2": out[28], "n_eff": int(round(out[29])),
            "n_pt": int(round(out[30])), "searched": int(counts[0]), "fitted": int(counts[1]), "plan": "cert" if certify else "full"}
     res.update(keep)

@@ -256,15 +256,10 @@ struct EmuLinParams {
 // {candidates, outermost shell, table loads, rows, runs, trips, faces, face skips}; counts[0] = queries searched, [1] = queries refitted.
 // nn_idx of a query that passed the radius gate on its stored plane (no list rebuilt in this launch) is -2.
 int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_t n, const double R[9], const double t[3],
-<<<<<<< Updated upstream
                   const EmuLinParams *p, uint32_t *state, int64_t stride, int fresh, int certify, int warm,
                   double *out32, int32_t *nn_idx, float *nn_d2,
                   uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats, uint32_t *trace, int64_t trace_cap_per_query,
                   int64_t *counts) {
-=======
-                  const EmuLinParams *p, uint32_t *prev, int64_t prev_stride, double *out32, int32_t *nn_idx, float *nn_d2,
-                  uint8_t *flag_out, double *normal, double *r_out, double *s_out, uint32_t *stats, uint32_t *trace, int64_t trace_cap_per_query) {
->>>>>>> Stashed changes
     EmuIndex *E = (EmuIndex *)idx;
     const GridDev &g = E->g;
     LinArgs a{};
@@ -287,6 +282,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     while (k < 100000) { const double safe = (double)k * g.h * (1.0 - 1e-9); if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break; ++k; }
     a.max_ring = k;
     a.warm = warm;
+    a.far_loose = 1.5f;
     a.prune_infl = (float)((1.0 + p->cert_inflate) * (1.0 + p->cert_inflate));
     a.infl_max_d2 = (float)(4.0 * g.h * g.h);
     a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0; a.dR = nullptr;
@@ -304,7 +300,6 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         const float4 s4{src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], __uint_as_float(oi)};
         emu_stats = EmuStats{};
         if (trace) { emu_trace.buf = trace + (size_t)i * (size_t)trace_cap_per_query; emu_trace.cap = (uint32_t)trace_cap_per_query - 1; emu_trace.n = 0; }
-<<<<<<< Updated upstream
         float qx, qy, qz;
         body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
         uint32_t cert = kCertSearch, fitw = kFitNone, pos6[6];
@@ -377,13 +372,6 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
         else fl = gate == 255 ? 0 : gate;
         const bool listed = fitnow;              // the neighbour list exists only where it was rebuilt in this launch
         row_products(row, fl, acc);
-=======
-        lin_search(g, runs, P, a, prev, true, s4, (uint32_t)i, q, nn, nullptr);
-        if (trace) { emu_trace.buf[trace_cap_per_query - 1] = emu_trace.n; emu_trace.buf = nullptr; }
-        double acc[31], nrm[3] = {0, 0, 0}, rr = 0.0, ss = 0.0;
-        for (double &v : acc) v = 0.0;
-        const uint8_t fl = p->fast_plane_fit ? lin_row<true>(P, a, s4, q, nn, acc, nrm, rr, ss) : lin_row<false>(P, a, s4, q, nn, acc, nrm, rr, ss);
->>>>>>> Stashed changes
         for (int j = 0; j < 31; ++j) tot[j] += acc[j];
         if (nn_idx) for (int j = 0; j < 5; ++j) nn_idx[5 * (size_t)oi + j] = (fl != 0 && listed) ? (int32_t)nn.idx[j] : (fl != 0 ? -2 : -1);
         if (nn_d2) for (int j = 0; j < 5; ++j) nn_d2[5 * (size_t)oi + j] = (fl != 0 && listed) ? nn.d2[j] : INFINITY;

@@ -302,16 +302,10 @@ def test_reduced_instruction_plane_fit_is_the_same_factorisation():
     assert worst < 1e-6
 
 
-<<<<<<< Updated upstream
 def test_ring_walk_cost_counters():
     """The visit counters the host replay exposes (candidates, rows, table loads, 4-candidate trips; tests/emul.py wave_cost) on a
     corridor misaligned by many cells - what C4's first iterations are.  They are the input of the design notes in
     profiles/r02_ablation.md; here only their consistency is pinned."""
-=======
-def test_ring_sweep_waits_once_per_batch_of_rows():
-    """Cost regression of the ring walk on a corridor misaligned by many cells (what C4's first iterations are): the table
-    entries of four rows are requested together, so a lane waits for ~1/4 as many load round trips as it issues row lookups."""
->>>>>>> Stashed changes
     tgt = h.scene_corridor(150_000, seed=100, length=30.0)
     rng = np.random.default_rng(1100)
     src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
@@ -322,7 +316,6 @@ def test_ring_sweep_waits_once_per_batch_of_rows():
     out = emul.linearize(idx, S, T[:3, :3], T[:3, 3], wd=1, stats=True, trace_cap=512)
     st = out["stats"].astype(np.int64)
     assert out["n_eff"] > 100_000
-<<<<<<< Updated upstream
     assert st[:, 0].mean() > 40 and (st[:, 1] > 1).mean() > 0.2          # the case does walk rings
     assert np.all(st[:, 5] * 4 >= st[:, 0])                              # every candidate sits in a 4-wide trip
     used = out["trace"][:, -1].astype(np.int64) // 2                      # ring rows / end cells whose cell table was looked up
@@ -355,8 +348,3 @@ def test_far_from_the_origin_and_very_dense_cells():
     bi, bd = emul.knn(idx, qd, k=5, max_radius=0.3)
     inside = od < np.float32(0.09)
     assert np.array_equal(bi[inside], oi[inside])
-=======
-    loads, batches = w[:, 2].astype(float), w[:, 6].astype(float)       # table loads / load batches, max lane per wave
-    assert loads.mean() > 40                                           # the case does walk rings
-    assert batches.mean() < 0.2 * loads.mean()                         # 18 loads of the centre block + <= 16 per batch
->>>>>>> Stashed changes
