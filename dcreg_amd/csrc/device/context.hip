@@ -304,7 +304,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (c->opt_keep_source_order) {      // experiments: the caller supplies the processing order
         HIP_TRY(c, hipMemcpyAsync(c->d_src, c->d_src_raw, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->d_mkeys, c->d_vals);
+        hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->opt_curve_x_scale, c->d_mkeys, c->d_vals);
         // the curve is resolved as far as the cloud can tell cells apart: log8(n) levels + 4 (a 4096-fold finer grid than one point
         // per cell) - 27 key bits for an 8 k-point frame instead of 63, i.e. half the radix passes; points that share the prefix keep
         // their input order (the sort is stable)
@@ -1031,6 +1031,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
+    else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;

@@ -164,6 +164,7 @@ struct dcreg_ctx {
     double hint_last = 1e300, last_R[9] = {}, last_t[3] = {};
     bool last_pose_valid = false;
     bool opt_fused_batches = true; // batched launches of one-chunk poses sum and publish per pose inside k_lin (kernels.hpp FinArgs::chunks_per_pose)
+    double opt_curve_x_scale = 1.0;  // kernels.hpp k_curve_keys: < 1 stretches the patches of the source's curve order along x
     double opt_far_loose = 1.5;    // search.hpp lin_search6: when a start bound is loose enough to be worth a probe (cells)
     int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)

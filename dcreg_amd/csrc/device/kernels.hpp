@@ -654,12 +654,14 @@ __device__ __forceinline__ uint64_t spread21(uint64_t v) {
 }
 // Hilbert-curve key (Skilling's transpose algorithm, 21 bits per axis).  Consecutive keys are always
 // spatial neighbours (no Z-order seams), which keeps the cells a wave touches close together.
-static __global__ void k_curve_keys(const float4 *__restrict__ p, int64_t n, double ox, double oy, double oz, double inv_q,
+static __global__ void k_curve_keys(const float4 *__restrict__ p, int64_t n, double ox, double oy, double oz, double inv_q, double x_scale,
                                     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 c = p[i];
-    const double fx = ((double)c.x - ox) * inv_q, fy = ((double)c.y - oy) * inv_q, fz = ((double)c.z - oz) * inv_q;
+    // (x_scale < 1: the curve's cells are 1 / x_scale times as long in x as in y and z - the patches of consecutive points stretch along
+    //  the rows of the target index)
+    const double fx = ((double)c.x - ox) * inv_q * x_scale, fy = ((double)c.y - oy) * inv_q, fz = ((double)c.z - oz) * inv_q;
     uint32_t X[3] = {(uint32_t)fmin(fmax(fx, 0.0), 2097151.0), (uint32_t)fmin(fmax(fy, 0.0), 2097151.0),
                      (uint32_t)fmin(fmax(fz, 0.0), 2097151.0)};
     const uint32_t M = 1u << 20;

@@ -84,6 +84,8 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
  *   "fused_batches"      1 (default) = a batched launch whose poses have at most 64 query blocks each finishes inside the kernel (the last block
  *                        of a pose sums and publishes the pose's row); 0 = a k_finalize launch behind it, as for larger poses;
+ *   "curve_x_scale"      next dcreg_set_source: the cells of the source's Hilbert-curve order are 1 / v times as long in x as in y and z
+ *                        (v <= 1; default 1 = cubes): experiment of profiles/r04_ablation.md section 16;
  *   "far_loose"          a query that starts with no bound (first launch, or far from the target) probes the occupied cells within this
  *                        many cell sizes of the nearest occupied one for a start bound (default 1.5: profiles/r04_ablation.md section 11). */
 
