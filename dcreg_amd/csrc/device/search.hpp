@@ -368,7 +368,11 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
 // bound ~6 of a query's ~34 candidates pass, so the insertion network runs ~10 times per wave instead of ~63 (it runs for
 // every lane whenever ANY lane has a candidate, which is always).  The pushes reach the heap in scan order, so the result -
 // neighbour set, order among ties, the exact-tie flag - is the one the immediate insertion gives (search.hpp knn_search).
-constexpr int kPend = 7;
+#if !defined(DCREG_PEND)
+#define DCREG_PEND 7
+#endif
+constexpr int kPend = DCREG_PEND;
+static_assert(kPend >= 4, "a trip parks up to four candidates: the pending list must hold them");
 constexpr int kWave = 64;
 struct PendEntry { uint32_t d2_bits, pos; };
 // One RunList per WAVE ([slot][lane]); a wave's list is private to it, so once its search is over the same LDS serves as
