@@ -3,7 +3,8 @@
   * the wave-cooperative search of sparse waves (search.hpp team_search6) and the launch log;
   * a bounded randomised parity hunt (scripts/fuzz_parity.py / fuzz_engine.py, fixed seeds) with both plane fits;
   * the Monte-Carlo engine with a full batch of 256 slots changing hands, and trials of the 5000-trial run against single runs and
-    the oracle."""
+    the oracle;
+  * the order in which the source cloud is processed only schedules."""
 import numpy as np
 import pytest
 
@@ -267,3 +268,28 @@ def test_trials_of_the_5000_trial_run_against_single_runs_and_the_oracle():
         assert np.allclose(one.R[:], ores.R[:], atol=1e-7) and np.allclose(one.t[:], ores.t[:], atol=1e-7)
     c.close()
 
+
+
+def test_the_order_of_the_source_only_schedules():
+    """The source cloud is processed in the order of a space-filling curve (dcreg_set_source); stretching the curve's cells along x
+    (debug option curve_x_scale) or keeping the caller's order changes which points share a wave and a partial row, i.e. the
+    association of the 31 sums - nothing else: counts equal, sums to rounding, and each order agrees with the oracle."""
+    tgt = h.scene_corridor(60_000, seed=21)
+    src = (tgt[::3] + np.random.default_rng(22).normal(0, 0.01, tgt[::3].shape)).astype(np.float32)
+    T = h.pose6d_matrix(0.05, -0.04, 0.02, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.3))
+    prm = api.default_lin_params(1.0, 1)
+    tree = po.KdTree(tgt)
+    ref = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(1.0, 1))
+    outs = []
+    for opt, val in (("curve_x_scale", 1.0), ("curve_x_scale", 0.0625), ("keep_source_order", 1.0)):
+        c = api.Context(0)
+        c.set_option(opt, val)
+        c.set_target(tgt, 1.0); c.set_source(src)
+        for Tk in (T, h.pose6d_matrix(0.04, -0.03, 0.02, h.deg2rad(0.15), h.deg2rad(-0.1), h.deg2rad(0.25)), T):      # cold, warm, back
+            out = c.linearize(Tk[:3, :3], Tk[:3, 3], prm)
+        outs.append(out)
+        c.close()
+        assert out["n_eff"] == ref["n_eff"] and out["n_pt"] == ref["n_pt"], (opt, val, out["n_eff"], ref["n_eff"])
+        assert h.rel_err(out["H_upper"], ref["H_upper"]) < 1e-9 and h.rel_err(out["g"], ref["g"]) < 1e-8, (opt, val)
+    for o in outs[1:]:
+        assert h.rel_err(o["H_upper"], outs[0]["H_upper"]) < 1e-12
