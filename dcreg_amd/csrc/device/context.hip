@@ -314,9 +314,18 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         if (rc) return rc;
         hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
     }
-    // (a small frame from a host buffer: no stream synchronise - the first linearisation queues behind the sort, the staging copy of the
-    // caller's buffer is over when hipMemcpyAsync returns, and a device fault surfaces at that linearisation)
-    if (!small_host) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // A small frame from a PAGEABLE host buffer: no stream synchronise - the runtime has staged the caller's buffer when hipMemcpyAsync
+    // returns, the first linearisation queues behind the sort, and a device fault surfaces at that linearisation (include/dcreg.h says
+    // so).  A pinned / registered buffer (hipHostMalloc, hipHostRegister, torch pin_memory) is read by the DMA engine asynchronously:
+    // the caller may reuse or free the frame as soon as this returns, so the call waits for the copy (the event behind it) first.
+    bool must_wait = !small_host;
+    if (small_host) {
+        hipPointerAttribute_t at{};
+        const hipError_t pe = hipPointerGetAttributes(&at, xyz);
+        if (pe != hipSuccess) (void)hipGetLastError();                     // (older runtimes: "invalid value" for plain malloc memory)
+        else if (at.type != hipMemoryTypeUnregistered) must_wait = true;   // host-registered, managed, or a device pointer after all
+    }
+    if (must_wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
     {   // dispatch groups of the single-pose launches (kernels.hpp k_group_cost): multiples of 16 query blocks, at most kMaxGroups of them
@@ -365,7 +374,7 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     }
     a.max_ring = k;
     c->last_max_ring = k;
-    a.count_scale = c->n_src <= ((int64_t)1 << 26) ? kCountScale : 0.0;
+    a.count_scale = c->n_src < ((int64_t)1 << 26) ? kCountScale : 0.0;      // (strictly below: a count of 2^26 would read as one more of the number riding above it)
     a.euler = p->parameterization == DCREG_PARAM_EULER ? 1 : 0;
     if (p->parameterization != DCREG_PARAM_SO3 && p->parameterization != DCREG_PARAM_EULER) { c->fail("unknown parameterization"); return DCREG_E_INVALID; }
     a.dR = nullptr;
@@ -686,7 +695,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
     hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
                        S.d_partials, nbx, fin, dd, abort_flag)
-        if (stamps_only) DCREG_LAUNCH_LIN(2, true, true);
+        if (stamps_only) { if (fast) DCREG_LAUNCH_LIN(2, true, true); else DCREG_LAUNCH_LIN(2, true, false); }     // (the probe writes the shared state: same fit as the plain launches)
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
         else { if (fast) DCREG_LAUNCH_LIN(0, false, true); else DCREG_LAUNCH_LIN(0, false, false); }
@@ -726,6 +735,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
     S.stamps_only = stamps_only;
+    S.coded = a.count_scale != 0.0;        // how THIS launch's count slots are to be read (the source may be replaced while it is pending)
     if (gated) {
         c->gate_slot = slot;
         c->gate_uses_state = uses_state; c->gate_state_was_valid = state_was_valid;
@@ -839,7 +849,7 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
         }
     }
     // the count slots carry two numbers each when the launch was asked to report what it did (LinArgs::count_scale): exact integers
-    const bool coded = c->n_src <= ((int64_t)1 << 26);
+    const bool coded = S.coded;
     int64_t searched = coded ? 0 : -1, refitted = coded ? 0 : -1;
     for (int i = 0; i < S.n_poses; ++i) {
         const double *o = (S.fused && S.n_poses == 1) ? total : S.h_rows.data() + (size_t)i * kSlots;      // (batches: one row per pose)

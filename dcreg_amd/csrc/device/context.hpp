@@ -35,6 +35,7 @@ struct LinSlot {
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
     bool stamps_only = false;
+    bool coded = false;            // the launch in flight reports searched / refitted counts above its count slots (LinArgs::count_scale)
 };
 
 struct dcreg_ctx {

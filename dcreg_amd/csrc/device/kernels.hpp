@@ -371,7 +371,9 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             if ((threadIdx.x & 63) == 0 && dbg.stamps) dbg.stamps[((size_t)vb * (kLinBlock / 64) + wave) * 8 + k] = v;
         }
     };
-    stamp(0, __builtin_readcyclecounter());
+    // (the counter reads sit behind the same MODE test as the stores: s_memtime has side effects the compiler does not remove, and in
+    //  the product instantiations it would also be a scheduling barrier)
+    if constexpr (MODE == 2) stamp(0, __builtin_readcyclecounter());
     PoseArg P;
     if (poses) P = poses[pose_id]; else P = pose1;
     uint8_t flag = 0;
@@ -525,7 +527,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         if (gate == 0) flag = row_of_plane<FAST>(P, a, s4, qx, qy, qz, fit.plane, row, nrm, r_pt, s_pt);
         else flag = gate == 255 ? (uint8_t)0 : gate;
     }
-    stamp(4, __builtin_readcyclecounter());
+    if constexpr (MODE == 2) stamp(4, __builtin_readcyclecounter());
     if (MODE == 1 && have_q) {                      // (debug launches search and fit every point: nn is this launch's list)
         const uint32_t oi = __float_as_uint(s4.w);
 #pragma unroll
@@ -544,7 +546,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     // (the wave's RunList is free now: it stages the rows)
     wave_rows_to_lds(row, flag, runs[wave].stage, &red[0][0] + wave * gm_stride, cnt, a.count_scale * (double)w_search,
                      a.count_scale * (double)w_refit);
-    stamp(5, __builtin_readcyclecounter());
+    if constexpr (MODE == 2) stamp(5, __builtin_readcyclecounter());
     __syncthreads();
     block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin, pose_id);
 }

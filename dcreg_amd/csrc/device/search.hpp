@@ -1627,8 +1627,9 @@ DCREG_DEVFN uint8_t row_of_plane(const PoseArg &P, const LinArgs &a, const float
 // What a query keeps of its last plane fit (state rows 10-18): the plane, and a FIT word = a float s >= 0 (bit pattern) whose two
 // lowest mantissa bits hold the outcome of the neighbour-only gates (0 ok, 2, 3): while the query stays within s metres of q0,
 //   * the SET of its five nearest cannot change (where that set is "five of these six": s <= half the gap between the fifth and the
-//     sixth), so the plane fit - a function of the set alone: the five are fitted in the order of their original index - would come out
-//     bitwise the same, gates included, and
+//     sixth), so the plane fit - a function of the set alone in the default instantiation: the five are fitted in the order of their
+//     original index - would come out bitwise the same, gates included (the parity instantiation, fast_plane_fit = 0, fits in DISTANCE
+//     order like the reference: there s also stays below half of every gap between consecutive distances, so the ORDER holds), and
 //   * the 5th neighbour stays inside the search radius (s <= R - a4), so the radius gate (:1726) still passes:
 // such a linearisation needs neither the neighbours nor the fit - it evaluates residual, weight and row on the stored plane.
 // kFitNone (a NaN): nothing stored.
@@ -1687,31 +1688,49 @@ DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, f
     fit.word = 0u;                                                               // (s = 0: nothing to reuse)
     fit.plane[0] = fit.plane[1] = fit.plane[2] = fit.plane[3] = 0.0;
     if (!((double)d2[4] < a.radius_sq)) return 0;                                // :1726
-    // The plane is fitted to the five points in the order of their ORIGINAL INDEX, not of their distance: it is then a function of the
-    // neighbour SET alone.  (The reference fits them in distance order, :1735-1747; a row permutation of the 5x3 least-squares system
-    // changes its solution by rounding only - the same few ulp its FMA-free arithmetic differs from this kernel's by anyway, and what
-    // the parity tests bound.)  What that buys: the stored plane stays valid as long as the SET does - while the five nearest merely
-    // change places among themselves, which on a converging trajectory happens five times as often as one of them being replaced,
-    // nothing has to be gathered, ordered and factorised again.
-    KnnResult<5> byidx;
+    float s;
+    uint8_t gate;
+    if constexpr (FASTMATH) {
+        // The default (fast) fit takes the five points in the order of their ORIGINAL INDEX, not of their distance: the plane is then a
+        // function of the neighbour SET alone.  (The reference fits them in distance order, :1735-1747; a row permutation of the 5x3
+        // least-squares system changes its solution by rounding only - the same few ulp this instantiation's reciprocal-based arithmetic
+        // differs from Eigen's by anyway, and what the parity tests bound.)  What that buys: the stored plane stays valid as long as the
+        // SET does - while the five nearest merely change places among themselves, which on a converging trajectory happens five times
+        // as often as one of them being replaced, nothing has to be gathered, ordered and factorised again.
+        KnnResult<5> byidx;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) byidx.pt[j] = pt[j];
-    {
-        auto iswap = [&](int x, int y) {
-            const bool sw = __float_as_uint(byidx.pt[y].w) < __float_as_uint(byidx.pt[x].w);
-            const float4 px = byidx.pt[x], py = byidx.pt[y];
-            byidx.pt[x].x = sw ? py.x : px.x; byidx.pt[x].y = sw ? py.y : px.y; byidx.pt[x].z = sw ? py.z : px.z; byidx.pt[x].w = sw ? py.w : px.w;
-            byidx.pt[y].x = sw ? px.x : py.x; byidx.pt[y].y = sw ? px.y : py.y; byidx.pt[y].z = sw ? px.z : py.z; byidx.pt[y].w = sw ? px.w : py.w;
-        };
-        iswap(0, 1); iswap(3, 4); iswap(2, 4); iswap(2, 3); iswap(0, 3); iswap(0, 2); iswap(1, 4); iswap(1, 3); iswap(1, 2);
+        for (int j = 0; j < 5; ++j) byidx.pt[j] = pt[j];
+        {
+            auto iswap = [&](int x, int y) {
+                const bool sw = __float_as_uint(byidx.pt[y].w) < __float_as_uint(byidx.pt[x].w);
+                const float4 px = byidx.pt[x], py = byidx.pt[y];
+                byidx.pt[x].x = sw ? py.x : px.x; byidx.pt[x].y = sw ? py.y : px.y; byidx.pt[x].z = sw ? py.z : px.z; byidx.pt[x].w = sw ? py.w : px.w;
+                byidx.pt[y].x = sw ? px.x : py.x; byidx.pt[y].y = sw ? px.y : py.y; byidx.pt[y].z = sw ? px.z : py.z; byidx.pt[y].w = sw ? px.w : py.w;
+            };
+            iswap(0, 1); iswap(3, 4); iswap(2, 4); iswap(2, 3); iswap(0, 3); iswap(0, 2); iswap(1, 4); iswap(1, 3); iswap(1, 2);
+        }
+        gate = plane_of_set<FASTMATH>(a, byidx, fit.plane);
+        // how far the SET of the five - and the radius gate - hold beyond what the set certificate says: the room of the fifth below the
+        // radius and, when the set is "five of these six", half the gap between the fifth and the sixth; 2e-6 relative margins on the
+        // float distances as in make_cert.  (Equal fifth and sixth distances give 0: such a query is refitted every time.)
+        const float sd4 = sqrt_approx(d2[4]), sd5 = sqrt_approx(d2[5]);
+        s = a.cert_r_in - sd4 * 1.000002f;
+        if (use6) s = fminf(s, 0.5f * (sd5 * 0.999998f - sd4 * 1.000002f));
+    } else {
+        // The parity instantiation (option fast_plane_fit = 0: the Eigen factorisation step for step) fills the rows of the 5x3 system in
+        // DISTANCE order, as the reference does (matA0, :1733-1747): the plane is then a function of the ORDERED list, and the stored
+        // plane is only reused while that order provably holds - half the smallest gap between consecutive distances (among the five,
+        // and up to the sixth when the set is "five of these six"), and the room of the fifth below the radius; margins as above.  (A
+        // pair of equal distances gives 0: such a query is refitted every time.)
+        gate = plane_of_set<FASTMATH>(a, nn, fit.plane);
+        float sd[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sd[j] = sqrt_approx(d2[j]);
+        s = a.cert_r_in - sd[4] * 1.000002f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fminf(s, 0.5f * (sd[j + 1] * 0.999998f - sd[j] * 1.000002f));
+        if (use6) s = fminf(s, 0.5f * (sd[5] * 0.999998f - sd[4] * 1.000002f));
     }
-    const uint8_t gate = plane_of_set<FASTMATH>(a, byidx, fit.plane);
-    // how far the SET of the five - and the radius gate - hold beyond what the set certificate says: the room of the fifth below the
-    // radius and, when the set is "five of these six", half the gap between the fifth and the sixth; 2e-6 relative margins on the float
-    // distances as in make_cert.  (Equal fifth and sixth distances give 0: such a query is refitted every time.)
-    const float sd4 = sqrt_approx(d2[4]), sd5 = sqrt_approx(d2[5]);
-    float s = a.cert_r_in - sd4 * 1.000002f;
-    if (use6) s = fminf(s, 0.5f * (sd5 * 0.999998f - sd4 * 1.000002f));
     fit.word = (__float_as_uint(fmaxf(s, 0.f)) & ~3u) | (uint32_t)gate;
     return 1;
 }

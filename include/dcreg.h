@@ -129,6 +129,10 @@ int dcreg_set_option(dcreg_ctx *, const char *key, double value);
  * search_radius_hint bounds the cell size (cell <= radius); pass Config::search_radius. */
 int dcreg_set_target(dcreg_ctx *, const float *xyz, int64_t n, int64_t stride_floats, double search_radius_hint);
 int dcreg_set_target_device(dcreg_ctx *, const float *d_xyz, int64_t n, int64_t stride_floats, double search_radius_hint);
+/* source ("measure") cloud: copies, orders along a space-filling curve.  The caller's buffer is consumed when the call returns - it
+ * may be reused or freed at once, pageable or pinned (for pinned / registered memory the call waits for the DMA to finish).  A frame
+ * of at most 65536 points from a PAGEABLE host buffer is queued without a stream synchronise (the registration path: the first
+ * linearisation runs behind the sort): a device fault of the upload or the sort then surfaces at that linearisation, not here. */
 int dcreg_set_source(dcreg_ctx *, const float *xyz, int64_t n, int64_t stride_floats);
 int dcreg_set_source_device(dcreg_ctx *, const float *d_xyz, int64_t n, int64_t stride_floats);
 int dcreg_default_lin_params(dcreg_lin_params *, double search_radius);
