@@ -122,7 +122,7 @@ EXPORTS = [
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
     "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn", "dcreg_kdtree_build", "dcreg_kdtree_info", "dcreg_knn_timed",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
-    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_launch_series", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
+    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_launch_series", "dcreg_launch_series_passes", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_icp_run_montecarlo", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
     "dcreg_set_host_threads", "dcreg_get_host_threads", "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
@@ -179,6 +179,7 @@ def load():
     L.dcreg_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
     L.dcreg_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     L.dcreg_launch_series.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.c_int]
+    L.dcreg_launch_series_passes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64]
     L.dcreg_default_config.restype = None
     L.dcreg_default_config.argtypes = [C.POINTER(Config)]
     L.dcreg_analyze_degeneracy.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis)]
@@ -542,8 +543,10 @@ class Context:
         n = min(n, cap)
         ms = np.empty(n, np.float64)
         se, rf, pt = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
+        adv = np.zeros(n, np.uint8)
+        self._L.dcreg_launch_series_passes(self._h, adv.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         self._L.dcreg_launch_series(self._h, _dp(ms), se.ctypes.data_as(lp), rf.ctypes.data_as(lp), pt.ctypes.data_as(lp), n, int(reset))
-        return {"ms": ms, "searched": se, "refitted": rf, "points": pt}
+        return {"ms": ms, "searched": se, "refitted": rf, "points": pt, "advanced": adv}
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()

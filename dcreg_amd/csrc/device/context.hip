@@ -644,6 +644,25 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     }
     a.use_cert = ((dbg_host && !stamps_only) || !c->opt_use_cert) ? 0 : 1;   // a debug dump searches every point (its statistics are those of the searches)
     a.search_count = c->opt_count_searches ? c->d_search_count : nullptr;
+    // The advance pass (kernels.hpp k_advance) in front of this launch?  Only where it can pay: a single pose on the ctx's own state,
+    // certificates in use, the state filled by an earlier launch; by default ("advance" = 1) a cloud whose query blocks exceed what the
+    // device holds at once (below that a launch lasts as long as one search whether its searches are dense or not) in a launch expected
+    // to search a few per cent of its points - expected = what the last completed launch reported (with the engines' pipeline that is
+    // the launch two back).  Scheduling only: the sums are the same with and without the pass.
+    bool adv = false;
+    a.adv_counts = nullptr;
+    if (n_poses == 1 && !state_ids && uses_state && one.fresh == 0u && a.use_cert && !dbg_host && a.count_scale != 0.0 && c->opt_advance != 0) {
+        if (c->opt_advance >= 2) adv = true;
+        else if (nbx >= (uint32_t)c->opt_advance_min_blocks && c->last_searched >= 0 && c->last_points == n) {
+            const double f = (double)c->last_searched / (double)n;
+            adv = f >= c->opt_advance_lo && f <= c->opt_advance_hi;
+        }
+    }
+    const uint32_t n_tiles = blocks_for(n, kAdvTile);
+    if (adv) {
+        if (ensure(c, c->d_adv_counts, c->adv_counts_cap, (size_t)2 * n_tiles)) return DCREG_E_NOMEM;
+        a.adv_counts = c->d_adv_counts;
+    }
     DebugDev dd{};
     free_tmp(S);
     if (dbg_host) {
@@ -690,6 +709,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (ee != hipSuccess) return bail("hipEventRecord", ee);
     }
     const bool fast = c->opt_fast_plane;
+    if (adv) {
+        if (fast) hipLaunchKernelGGL((k_advance<true>), dim3(n_tiles), dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag);
+        else hipLaunchKernelGGL((k_advance<false>), dim3(n_tiles), dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return bail("advance pass launch", le);
+        c->n_advance_launches += 1;
+    }
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
@@ -735,6 +761,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
     S.stamps_only = stamps_only;
+    S.advanced = adv;
     S.coded = a.count_scale != 0.0;        // how THIS launch's count slots are to be read (the source may be replaced while it is pending)
     if (gated) {
         c->gate_slot = slot;
@@ -866,7 +893,7 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
     }
     c->last_searched = searched; c->last_refitted = refitted; c->last_points = (int64_t)S.n_poses * c->n_src;
     if (c->opt_record_launches && c->launch_series.size() < ((size_t)1 << 20))
-        c->launch_series.push_back(dcreg_ctx::LaunchRec{(double)launch_ms, searched, refitted, c->last_points});
+        c->launch_series.push_back(dcreg_ctx::LaunchRec{(double)launch_ms, searched, refitted, c->last_points, S.advanced ? 1 : 0});
     return DCREG_OK;
 }
 
@@ -989,7 +1016,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     kdtree_free(c->kd); c->kd = nullptr;
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner};
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner,
+                    c->d_adv_counts};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -1043,6 +1071,10 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
+    else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
+    else if (k == "advance_lo") c->opt_advance_lo = v;           // ... rule: the last launch searched between these fractions of its points
+    else if (k == "advance_hi") c->opt_advance_hi = v;
+    else if (k == "advance_min_blocks") c->opt_advance_min_blocks = (int)v;   // ... and the cloud has at least this many query blocks
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host
@@ -1195,6 +1227,13 @@ int dcreg_launch_series(dcreg_ctx *c, double *ms, int64_t *searched, int64_t *re
     const int64_t total = (int64_t)c->launch_series.size();
     if (reset) c->launch_series.clear();
     return (int)std::min<int64_t>(total, 0x7FFFFFFF);
+}
+
+int dcreg_launch_series_passes(dcreg_ctx *c, uint8_t *advanced, int64_t cap) {
+    if (!c || cap < 0) return -1;
+    const int64_t n = std::min<int64_t>(cap, (int64_t)c->launch_series.size());
+    for (int64_t i = 0; i < n; ++i) if (advanced) advanced[i] = (uint8_t)c->launch_series[(size_t)i].advanced;
+    return (int)std::min<int64_t>((int64_t)c->launch_series.size(), 0x7FFFFFFF);
 }
 
 int dcreg_kernel_time(dcreg_ctx *c, double *ms_total, int64_t *launches, int reset) {

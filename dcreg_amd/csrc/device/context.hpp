@@ -35,6 +35,7 @@ struct LinSlot {
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
     bool stamps_only = false;
+    bool advanced = false;         // the advance pass ran in front of the launch in flight (kernels.hpp k_advance)
     bool coded = false;            // the launch in flight reports searched / refitted counts above its count slots (LinArgs::count_scale)
 };
 
@@ -167,6 +168,12 @@ struct dcreg_ctx {
     bool opt_fused_batches = true; // batched launches of one-chunk poses sum and publish per pose inside k_lin (kernels.hpp FinArgs::chunks_per_pose)
     double opt_curve_x_scale = 1.0;  // kernels.hpp k_curve_keys: < 1 stretches the patches of the source's curve order along x
     double opt_far_loose = 1.5;    // search.hpp lin_search6: when a start bound is loose enough to be worth a probe (cells)
+    // the advance pass (kernels.hpp k_advance): 0 never, 1 by the rule below, 2 whenever a launch can take it (tests)
+    int opt_advance = 1;
+    double opt_advance_lo = 0.01, opt_advance_hi = 0.45;      // ... the last completed launch searched between these fractions of its points
+    int opt_advance_min_blocks = 2048;                        // ... and the cloud has at least this many query blocks (twice what the device holds)
+    uint32_t *d_adv_counts = nullptr; size_t adv_counts_cap = 0;
+    int64_t n_advance_launches = 0;
     int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively
     bool opt_warm = true;          // bound each search by the previous neighbour set (same exact result, fewer cells)
     int64_t n_launches = 0, n_poses_launched = 0, n_points_launched = 0;    // dcreg_launch_stats
@@ -175,7 +182,7 @@ struct dcreg_ctx {
     // what the last completed launch did (decoded from the count slots of its result rows, search.hpp LinArgs::count_scale): points
     // searched / refitted, -1 = not reported.  Scheduling input of the next launches; "record_launches": every launch is also logged
     int64_t last_searched = -1, last_refitted = -1, last_points = 0;
-    struct LaunchRec { double ms; int64_t searched, refitted, points; };
+    struct LaunchRec { double ms; int64_t searched, refitted, points; int advanced; };
     bool opt_record_launches = false;
     std::vector<LaunchRec> launch_series;
 

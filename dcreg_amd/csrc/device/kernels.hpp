@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "search.hpp"
 
@@ -341,6 +342,13 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
     }
 }
 
+// points per block of the advance pass (k_advance below): kAdvTile / kLinBlock query blocks of k_lin
+#if !defined(DCREG_ADV_TILE)
+#define DCREG_ADV_TILE 1024
+#endif
+constexpr int kAdvTile = DCREG_ADV_TILE;
+static_assert(kAdvTile % kLinBlock == 0 && kAdvTile <= 65536, "a tile is a whole number of query blocks; list entries are 16-bit offsets");
+
 // ---------------------------------------------------------------- k_lin
 template <int MODE, bool FUSED, bool FAST>
 static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
@@ -407,6 +415,11 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
+    uint32_t adv_s = 0, adv_r = 0;                  // ... and what the advance pass in front of this launch did for this block's tile
+    if (a.adv_counts && wave == 0 && (vb % (uint32_t)(kAdvTile / kLinBlock)) == 0u) {
+        adv_s = a.adv_counts[2 * (vb / (uint32_t)(kAdvTile / kLinBlock))];
+        adv_r = a.adv_counts[2 * (vb / (uint32_t)(kAdvTile / kLinBlock)) + 1];
+    }
     KnnResult<5> nn;
     Fit fit;
     uint8_t gate = 255;                             // 0: plane usable; 2 / 3: neighbour-only gate failed; 255: radius gate failed / OUT
@@ -544,11 +557,151 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         if (dbg.stats) dbg.stats[oi] = stats;
     }
     // (the wave's RunList is free now: it stages the rows)
-    wave_rows_to_lds(row, flag, runs[wave].stage, &red[0][0] + wave * gm_stride, cnt, a.count_scale * (double)w_search,
-                     a.count_scale * (double)w_refit);
+    wave_rows_to_lds(row, flag, runs[wave].stage, &red[0][0] + wave * gm_stride, cnt, a.count_scale * (double)(w_search + adv_s),
+                     a.count_scale * (double)(w_refit + adv_r));
     if constexpr (MODE == 2) stamp(5, __builtin_readcyclecounter());
     __syncthreads();
     block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin, pose_id);
+}
+
+// ---------------------------------------------------------------- the advance pass: searches and refits in dense waves
+// In the launches of a converging run's TRANSITION (a few per cent of the points have left their certificates) k_lin pays the full
+// price of a search for a few lanes: a block stays as long as ONE lock-step search lasts whichever of its waves runs it, and nearly
+// every block has a lane that needs one (profiles/r04_ablation.md sections 1, 18).  k_advance takes those lanes out of k_lin: it runs
+// IN FRONT of it on the same stream, tests the certificates of a TILE of kAdvTile points per block (36 B per point: the point and the
+// two state groups the tests read), collects the points that fail in a per-block list - searches from the front, refit-only points
+// from the back - and works the list off in DENSE waves of 64: search (lin_search6, bounded by the old neighbours), plane fit, new
+// certificate, fit word, plane and reference position written to the state exactly as k_lin's levels 1 and 2 write them.  k_lin then
+// finds every certificate fresh (its reference position is the point's position at this very pose) and every wave takes the
+// stored-plane path.  Nothing else changes hands: the rows, their order and the 31 sums are k_lin's own - what the state holds never
+// changes a result (history independence), so the sums are bitwise those of a launch without the pass.  The host decides per launch
+// (context.hip: the fraction of points the last completed launch searched; clouds whose query blocks exceed what the device holds).
+// A point whose new certificate has no slack at all (exact distance ties) is searched again by k_lin - correct, merely slower.
+template <bool FAST>
+static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_advance(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
+                                                                              const PoseArg *__restrict__ poses, LinArgs a,
+                                                                              uint32_t *__restrict__ counts, const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off
+    __shared__ RunList runs[kLinBlock / kWave];
+    __shared__ uint16_t list[kAdvTile];              // offsets into the tile: points to search from the front, refit-only points from the back
+    __shared__ uint32_t n_list[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    PoseArg P;
+    if (poses) P = poses[0]; else P = pose1;
+    const size_t ss = a.state_stride;
+    uint32_t *const sbase = a.state + (size_t)P.state * kStateRows * ss;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    uint4 *const SV0 = reinterpret_cast<uint4 *>(sbase + kStV0 * ss), *const SX = reinterpret_cast<uint4 *>(sbase + kStX * ss);
+    dbl2 *const SV1 = reinterpret_cast<dbl2 *>(sbase + kStV1 * ss), *const SV2 = reinterpret_cast<dbl2 *>(sbase + kStV2 * ss);
+    uint32_t *const SW3 = sbase + kStW3 * ss;
+    uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
+    if (threadIdx.x < 2) n_list[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)kAdvTile;
+    // ---- the tests: every thread takes kAdvTile / kLinBlock points, all their loads in flight together
+    constexpr int U = kAdvTile / kLinBlock;
+    {
+        float4 s4[U];
+        uint4 v0[U];
+        uint32_t w3[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = base + (uint32_t)(u * kLinBlock) + threadIdx.x;
+            const bool have = i < n_src;
+            s4[u] = have ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v0[u] = have ? SV0[i] : make_uint4(0x80000000u | 0x7F000000u, kFitNone, 0u, 0u);      // (padding: an OUT certificate with a huge slack)
+            w3[u] = have ? SW3[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = base + (uint32_t)(u * kLinBlock) + threadIdx.x;
+            const bool have = i < n_src;
+            float qx, qy, qz;
+            body_to_global(P, (double)s4[u].x, (double)s4[u].y, (double)s4[u].z, qx, qy, qz);
+            const float q0x = __uint_as_float(v0[u].z), q0y = __uint_as_float(v0[u].w), q0z = __uint_as_float(w3[u]);
+            const bool need = have && !cert_holds(v0[u].x, q0x, q0y, q0z, qx, qy, qz);
+            const bool refit = have && !need && !cert_is_out(v0[u].x) && !fit_holds(v0[u].y, q0x, q0y, q0z, qx, qy, qz);
+            const unsigned long long ms = __builtin_amdgcn_ballot_w64(need), mr = __builtin_amdgcn_ballot_w64(refit);
+            uint32_t bs = 0, br = 0;
+            if (lane == 0) {
+                if (ms) bs = atomicAdd(&n_list[0], (uint32_t)__builtin_popcountll(ms));
+                if (mr) br = atomicAdd(&n_list[1], (uint32_t)__builtin_popcountll(mr));
+            }
+            bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs); br = (uint32_t)__builtin_amdgcn_readfirstlane((int)br);
+            const uint32_t ps = __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+            const uint32_t pr = __builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0u));
+            const uint16_t off = (uint16_t)(u * kLinBlock + (int)threadIdx.x);
+            if (need) list[bs + ps] = off;
+            if (refit) list[(uint32_t)kAdvTile - 1u - (br + pr)] = off;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_s = n_list[0], n_r = n_list[1];
+    if (threadIdx.x == 0 && counts) { counts[2 * blockIdx.x] = n_s; counts[2 * blockIdx.x + 1] = n_r; }
+    // ---- the list, 64 entries per wave at a time: the searches (waves in turn), then the refit-only points
+    const uint32_t c_s = (n_s + 63u) >> 6, c_r = (n_r + 63u) >> 6;
+    auto chunk = [&](auto searching_c, uint32_t e, bool act) {
+        constexpr bool searching = decltype(searching_c)::value;
+        const uint32_t off = act ? (uint32_t)list[searching ? e : (uint32_t)kAdvTile - 1u - e] : 0u;
+        const uint32_t i = base + off;                                      // (idle lanes read the tile's first point and write nothing)
+        const float4 s4 = src[i];
+        float qx, qy, qz;
+        body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
+        uint32_t pos6[6];
+        {
+            const uint4 x = SX[i];
+            const uint2 y = SY[i];
+            pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
+        }
+        uint32_t cert;
+        // (the state accesses behind the search are addressed with the same index behind a compiler barrier: their 64-bit addresses
+        //  are formed where they are used instead of riding through the search - as in k_lin)
+        uint32_t iw = i;
+        if constexpr (searching) {
+            Set6 s6;
+            lin_search6<kLinSweep>(g, runs[wave], a, act, a.warm != 0, pos6, qx, qy, qz, s6, cert);
+            asm volatile("" : "+v"(iw));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];
+            if (act) {
+                SX[iw] = make_uint4(pos6[0], pos6[1], pos6[2], pos6[3]);
+                SY[iw] = make_uint2(pos6[4], pos6[5]);
+            }
+        } else {
+            const uint4 o0 = SV0[i];
+            const uint32_t o1 = SW3[i];
+            cert = cert_rebased(o0.x, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz);
+        }
+        const bool set = act && !cert_is_out(cert);
+        if (wave_any(set)) {
+            const bool use6 = set && cert_is_set6(cert);
+            const bool six = wave_any(use6);
+            if (!use6) pos6[5] = kNoIdx;
+            if (set) {
+                KnnResult<5> nn;
+                Fit fit;
+                (void)fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, searching);     // (searched just now: the six are in order)
+                SV0[iw] = make_uint4(cert, fit.word, __float_as_uint(qx), __float_as_uint(qy));
+                SV1[iw] = dbl2{fit.plane[0], fit.plane[1]};
+                SV2[iw] = dbl2{fit.plane[2], fit.plane[3]};
+                SW3[iw] = __float_as_uint(qz);
+            }
+        }
+        if (act && !set) {                          // searched and found OUT: certificate and reference position, no fit
+            SV0[iw] = make_uint4(cert, kFitNone, __float_as_uint(qx), __float_as_uint(qy));
+            SW3[iw] = __float_as_uint(qz);
+        }
+    };
+    for (uint32_t k = (uint32_t)wave; k < c_s; k += (uint32_t)(kLinBlock / kWave)) {
+        const uint32_t e = k * 64u + (uint32_t)lane;
+        chunk(std::true_type{}, e, e < n_s);
+    }
+    // (the refit chunks start with the wave after the one that took the last search chunk: the work of a tile spreads over its waves)
+    for (uint32_t k = ((uint32_t)wave + (uint32_t)(kLinBlock / kWave) - c_s % (uint32_t)(kLinBlock / kWave)) % (uint32_t)(kLinBlock / kWave); k < c_r;
+         k += (uint32_t)(kLinBlock / kWave)) {
+        const uint32_t e = k * 64u + (uint32_t)lane;
+        chunk(std::false_type{}, e, e < n_r);
+    }
 }
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused

@@ -142,6 +142,9 @@ struct LinArgs {
                                   // and the host splits them again (context.hip linearize_end).  What the host does with them:
                                   // scheduling only (which instantiation the next launch uses) and the launch statistics.  0 for
                                   // clouds of more than 2^26 points.
+    const uint32_t *adv_counts;   // a launch that runs behind the advance pass (kernels.hpp k_advance): per tile of kAdvTile points the
+                                  // points that pass searched and refitted, [tile][2]; the first query block of a tile adds them to the
+                                  // counts it reports (count_scale).  null: no pass in front
     float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
                                   // reaches this many cells beyond the distance to that cell (lin_search6)
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row

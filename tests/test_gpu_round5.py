@@ -1,0 +1,144 @@
+"""GPU tests added in round 5 (run with -m gpu on an MI355X; everything through the C-ABI):
+  * the advance pass (kernels.hpp k_advance: the searches and refits of a launch in dense waves, in front of the linearisation
+    kernel) changes no sum - walks on scenes with ties, duplicates, OUT points and dense cells, whole engine runs, gated launches;
+  * the plane fit of the parity mode (fast_plane_fit = 0) takes its rows in distance order, like the reference."""
+import numpy as np
+import pytest
+
+import helpers as h
+from dcreg_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_sums(a, b):
+    return (a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
+            and a["sum_r2"] == b["sum_r2"] and a["sum_b2"] == b["sum_b2"])
+
+
+def _scene(scene, rng):
+    if scene == "cylinder_60k":
+        tgt, radius = h.scene_cylinder(60_000, seed=8, noise=0.01), 1.0
+    elif scene == "fixture":
+        tgt, radius = h.cylinder_cloud(), 1.0
+    elif scene == "planes_dense":
+        tgt, radius = h.scene_planes(80_000, seed=4), 0.4
+    elif scene == "corridor_300k":
+        tgt, radius = h.scene_corridor(300_000, seed=5), 1.0
+    else:
+        g = np.arange(0, 14, dtype=np.float32) * 0.3
+        tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        tgt, radius = np.concatenate([tgt, tgt[::7]]), 0.7
+    src = (tgt[::2] + rng.normal(0, 0.004, tgt[::2].shape)).astype(np.float32)
+    if scene == "lattice_dups":
+        src = (tgt[::3] + np.float32(0.11)).astype(np.float32)
+    if scene == "corridor_300k":
+        src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
+    return tgt, src, radius
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("scene", ["cylinder_60k", "fixture", "lattice_dups", "planes_dense", "corridor_300k"])
+def test_advance_pass_is_invisible(scene, fast):
+    """Walks that mix micrometre steps, centimetre steps and a jump: with the advance pass forced on every launch that can take it
+    ("advance" = 2), never (0), and with certificates off (every point searched inside the linearisation kernel), the 31 sums agree
+    bit for bit at every step; the pass did run, and it reports its searches through the launch's own count slots."""
+    rng = np.random.default_rng(31)
+    tgt, src, radius = _scene(scene, rng)
+    prm = api.default_lin_params(radius, 1)
+    ctxs = {}
+    for name, opts in (("adv", {"advance": 2}), ("plain", {"advance": 0}), ("all", {"use_certificates": 0, "advance": 0})):
+        c = api.Context(0)
+        c.set_option("fast_plane_fit", fast)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_option("record_launches", 1)
+        c.set_target(tgt, radius); c.set_source(src)
+        ctxs[name] = c
+    T = np.eye(4)
+    steps = [0.0, 1e-6, 1e-4, 3e-4, 1e-3, -1e-3, 2e-3, 1e-5, 4e-3, 6e-3, -6e-3, 1e-2, 1e-4, 3e-2, 0.2, 1e-3, 5e-4, 0.0]
+    ran, searched_adv, searched_plain = 0, 0, 0
+    for k, sz in enumerate(steps):
+        T = h.pose6d_matrix(sz * 0.6, -sz * 0.3, sz * 0.2, sz * 0.002, -sz * 0.001, sz * 0.004) @ T
+        outs = {name: c.linearize(T[:3, :3], T[:3, 3], prm) for name, c in ctxs.items()}
+        assert _same_sums(outs["adv"], outs["plain"]) and _same_sums(outs["adv"], outs["all"]), (scene, fast, k)
+        sa, sp = ctxs["adv"].launch_series(reset=True), ctxs["plain"].launch_series(reset=True)
+        ctxs["all"].launch_series(reset=True)
+        assert len(sa["ms"]) == 1 and sa["advanced"][0] == (1 if k > 0 else 0) and sp["advanced"][0] == 0
+        ran += int(sa["advanced"][0])
+        if k > 0:
+            searched_adv += int(sa["searched"][0]); searched_plain += int(sp["searched"][0])
+            # the pass searches the points whose certificate failed; the kernel behind it searches again only the (rare) points whose
+            # new certificate has no slack at all (exact ties) - never fewer than the plain launch, which counts those once
+            assert sa["searched"][0] >= sp["searched"][0], (scene, k, sa["searched"][0], sp["searched"][0])
+    assert ran == len(steps) - 1 and searched_adv > 0
+    if scene != "lattice_dups":                     # (a lattice is all ties: every point is searched twice there)
+        assert searched_adv <= 1.02 * searched_plain + 64, (searched_adv, searched_plain)
+    for c in ctxs.values():
+        c.close()
+
+
+def test_advance_pass_in_whole_runs_and_behind_the_gate():
+    """Engine level: 30-iteration runs of a 400 k corridor pair (the pipelined engine queues every launch behind a gate) with the pass
+    chosen by the host's rule made to fire ("advance_min_blocks" = 1), forced, and off: every iteration's H, g, counts and pose are
+    bitwise the same; the rule did pick the pass for some launches and not for others."""
+    tgt = h.scene_corridor(400_000, seed=9)
+    src = (tgt + np.random.default_rng(10).normal(0, 0.01, tgt.shape)).astype(np.float32)
+    T0 = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
+    cfg = api.default_config(search_radius=1.0, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=0.0,
+                             CONVERGENCE_THRESH_TRANS=0.0, use_weight_derivative=1, always_compute_schur=1)
+    logs, picked = {}, {}
+    for name, opts in (("rule", {"advance": 1, "advance_min_blocks": 1}), ("forced", {"advance": 2}), ("off", {"advance": 0})):
+        c = api.Context(0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_option("record_launches", 1)
+        c.set_target(tgt, 1.0); c.set_source(src)
+        runs = []
+        for rep in range(2):                       # the second run starts from the first one's converged state
+            res, lg = c.icp_run(T0, "Ours", cfg)
+            runs.append([(np.array(L.H_upper[:]), np.array(L.gradient[:]), L.effective_points, L.corr_pt_count, np.array(L.transform_matrix[:])) for L in lg[:res.iterations]])
+        logs[name] = runs
+        picked[name] = c.launch_series(reset=True)["advanced"]
+        c.close()
+    for name in ("rule", "forced"):
+        for rep in range(2):
+            assert len(logs[name][rep]) == len(logs["off"][rep]) == 30
+            for it, (x, y) in enumerate(zip(logs[name][rep], logs["off"][rep])):
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]), (name, rep, it)
+    assert picked["off"].sum() == 0 and picked["forced"].sum() >= 58
+    assert 0 < picked["rule"].sum() < 50, picked["rule"]
+
+
+def test_parity_fit_takes_its_rows_in_distance_order():
+    """fast_plane_fit = 0 is the reference's factorisation step for step, rows in DISTANCE order (icp_test_runner.cpp:1733-1747): on a
+    scene of nearly collinear / rank-deficient neighbourhoods the normals agree with the oracle's (which fits in distance order) far
+    closer than a row permutation would leave them, and walking keeps the sums those of a context that searches everything."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(77)
+    # points on a few lines and planes: many neighbourhoods are rank 2 (collinear in projection)
+    t = rng.uniform(0, 10, 6000)
+    lines = np.stack([t, 0.02 * rng.normal(size=t.shape), np.round(rng.uniform(0, 3, t.shape))], 1)
+    plane = np.stack([rng.uniform(0, 10, 6000), rng.uniform(0, 10, 6000), 5.0 + 1e-4 * rng.normal(size=6000)], 1)
+    tgt = np.concatenate([lines, plane]).astype(np.float32)
+    src = (tgt[::3] + rng.normal(0, 0.01, tgt[::3].shape)).astype(np.float32)
+    T = h.pose6d_matrix(0.01, -0.02, 0.015, h.deg2rad(0.1), 0.0, h.deg2rad(-0.1))
+    prm = api.default_lin_params(1.0, 1)
+    c = api.Context(0)
+    c.set_option("fast_plane_fit", 0)
+    c.set_target(tgt, 1.0); c.set_source(src)
+    d = c.linearize(T[:3, :3], T[:3, 3], prm, debug=True)
+    tree = po.KdTree(tgt)
+    o = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(1.0, 1), debug=True)
+    assert np.array_equal(d["flag"], o["flag"])
+    ok = (d["flag"] == 1) | (d["flag"] == 4)
+    assert ok.sum() > 500
+    assert np.max(np.abs(d["normal"][ok] - o["normal"][ok])) < 1e-9
+    # a walk with the stored planes in use equals a context that refits everything
+    f = api.Context(0)
+    f.set_option("fast_plane_fit", 0); f.set_option("use_certificates", 0)
+    f.set_target(tgt, 1.0); f.set_source(src)
+    for sz in (0.0, 1e-5, 1e-3, -1e-3, 5e-3, 1e-4):
+        T = h.pose6d_matrix(sz, -sz * 0.5, sz * 0.2, sz * 0.01, 0.0, -sz * 0.01) @ T
+        assert _same_sums(c.linearize(T[:3, :3], T[:3, 3], prm), f.linearize(T[:3, :3], T[:3, 3], prm)), sz
+    c.close(); f.close()
