@@ -34,6 +34,7 @@ struct LinSlot {
     size_t n_rows = 0;
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
+    hipEvent_t ev_poses = nullptr;  // batched launches: "this slot's poses are on the device" (recorded on the ctx's copy stream)
     bool stamps_only = false;
     bool advanced = false;         // the advance pass ran in front of the launch in flight (kernels.hpp k_advance)
     bool coded = false;            // the launch in flight reports searched / refitted counts above its count slots (LinArgs::count_scale)
@@ -42,6 +43,7 @@ struct LinSlot {
 struct dcreg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // pose uploads of batched launches (linearize_begin)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     char err[512] = {0};
 

@@ -377,6 +377,10 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
 constexpr int kPend = DCREG_PEND;
 static_assert(kPend >= 4, "a trip parks up to four candidates: the pending list must hold them");
 constexpr int kWave = 64;
+#if !defined(DCREG_SWEEP_BATCH)
+#define DCREG_SWEEP_BATCH 4
+#endif
+constexpr int kSweepBatch = DCREG_SWEEP_BATCH;   // z layers of the row sweep whose occupancy words are requested together (knn_shells)
 struct PendEntry { uint32_t d2_bits, pos; };
 // One RunList per WAVE ([slot][lane]); a wave's list is private to it, so once its search is over the same LDS serves as
 // that wave's staging area for the MFMA reduction of the rows (kernels.hpp) without a block barrier in between.
@@ -739,31 +743,98 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
             int zlo, zhi;
             reach(w0, frz, cap, zlo, zhi);
             const int zmax = max(-zlo, zhi);
-            for (int i = 0; i <= 2 * zmax; ++i) {
-                const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
-                const float w = hp.worst_d2();
-                { const float nearer = (float)max(adz - 1, 0) * hf; if (nearer * nearer * 0.99999f > w) break; }   // both layers at this |dz| and beyond are out
-                const int z = cz + dz;
-                if (z < 0 || z >= nz) continue;
-                const float gz = slab(z, cz, frz);
-                const float rem = w - gz * gz * 0.99999f;
-                if (rem < 0.f) continue;
-                int ylo, yhi, xlo, xhi;
-                reach(rem, fry, cap, ylo, yhi);
-                reach(rem, frx, cap, xlo, xhi);
-                const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
-                const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
-                if (y1 < y0 || b1 < b0) continue;
-                for (int yw = y0 >> 5; yw <= (y1 >> 5); ++yw) {
-                    uint32_t m = 0;
-                    const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw + yw;
-                    for (int b = b0; b <= b1; ++b, mw += nyw) { m |= *mw; DCREG_STAT(table_loads); }
-                    const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
-                    m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
-                    while (m) {
-                        const int bit = __builtin_ctz(m);
-                        m &= m - 1;
-                        sweep_row((yw << 5) + bit, z, gz);
+            // Layers are taken kSweepBatch at a time: first the row occupancy words of all layers of the batch are requested (ranges from
+            // the ball as it stands at the start of the batch - a superset of what each layer would ask for when its turn comes), then
+            // the layers are swept in order, centre-out.  One exposed memory round trip per batch instead of one per layer: a query
+            // 0.87 m from its surface has 17 layers, and their dependent mask loads were a third of its wave's life (round 4's stamps).
+            // Rows the shrinking ball no longer reaches are turned away by sweep_row itself, so the scans are the same.
+            // A layer whose y range spans more than two words, or whose ball spans more than two 16-cell x blocks (cells far smaller
+            // than the radius), reads its words when its turn comes, as before.
+            bool over = false;
+            for (int i0 = 0; i0 <= 2 * zmax && !over; i0 += kSweepBatch) {
+                // (what pass 1 learns about a layer waits in the wave's run list - the cell-table phase is over, its slots are free: words
+                //  yw0 and yw0 + 1, OR-ed over the x blocks, in s / e; the y range in two gap2h slots, 0xFFFF = nothing to do, 0xFFFE = wide.
+                //  In registers the twelve values of a batch cost the kernel its scratch-free allocation.)
+                static_assert(2 * kSweepBatch <= 9, "the batch's y ranges live in the nine gap2h slots of the run list");
+                const int tid = threadIdx.x & (kWave - 1);
+                {
+                    const float w = hp.worst_d2();
+#pragma unroll
+                    for (int u = 0; u < kSweepBatch; ++u) {
+                        const int i = i0 + u;
+                        const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
+                        const int z = cz + dz;
+                        const float nearer = (float)max(adz - 1, 0) * hf;
+                        bool live = i <= 2 * zmax && !(nearer * nearer * 0.99999f > w) && z >= 0 && z < nz;
+                        const float gz = slab(clampi(z, 0, nz - 1), cz, frz);
+                        const float rem = w - gz * gz * 0.99999f;
+                        live = live && !(rem < 0.f);
+                        int ylo, yhi, xlo, xhi;
+                        reach(rem, fry, cap, ylo, yhi);
+                        reach(rem, frx, cap, xlo, xhi);
+                        const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
+                        const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
+                        live = live && y1 >= y0 && b1 >= b0;
+                        const bool wide = live && (((y1 >> 5) - (y0 >> 5)) > 1 || b1 - b0 > 1 || y1 >= 0xFFFE);
+                        rl.gap2h[u][tid] = live ? (wide ? (uint16_t)0xFFFEu : (uint16_t)y0) : (uint16_t)0xFFFFu;
+                        rl.gap2h[kSweepBatch + u][tid] = (uint16_t)y1;
+                        if (live && !wide) {
+                            const int yw0 = y0 >> 5, yw1 = y1 >> 5, bb = min(b0 + 1, b1);
+                            const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw, *mv = g.ymask + ((int64_t)z * nxb + bb) * nyw;
+                            const uint32_t a0_ = mw[yw0], a1_ = mv[yw0], c0_ = mw[yw1], c1_ = mv[yw1];
+                            DCREG_STAT(table_loads); DCREG_STAT(table_loads);
+                            rl.s[u][tid] = a0_ | a1_;
+                            rl.e[u][tid] = yw1 > yw0 ? (c0_ | c1_) : 0u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kSweepBatch; ++u) {
+                    const uint32_t y0s = rl.gap2h[u][tid];
+                    if (over || y0s == 0xFFFFu) continue;
+                    const int i = i0 + u;
+                    const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
+                    const float w = hp.worst_d2();
+                    { const float nearer = (float)max(adz - 1, 0) * hf; if (nearer * nearer * 0.99999f > w) { over = true; continue; } }   // this |dz| and beyond are out
+                    const int z = cz + dz;
+                    const float gz = slab(z, cz, frz);
+                    if (y0s != 0xFFFEu) {
+                        const int y0 = (int)y0s, y1 = (int)rl.gap2h[kSweepBatch + u][tid];
+                        const int yw0 = y0 >> 5;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int yw = yw0 + k;
+                            if (yw > (y1 >> 5)) break;
+                            uint32_t m = k ? rl.e[u][tid] : rl.s[u][tid];
+                            const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
+                            m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
+                            while (m) {
+                                const int bit = __builtin_ctz(m);
+                                m &= m - 1;
+                                sweep_row((yw << 5) + bit, z, gz);
+                            }
+                        }
+                    } else {                    // a wide layer: ranges and words when its turn comes
+                        const float rem = w - gz * gz * 0.99999f;
+                        if (rem < 0.f) continue;
+                        int ylo, yhi, xlo, xhi;
+                        reach(rem, fry, cap, ylo, yhi);
+                        reach(rem, frx, cap, xlo, xhi);
+                        const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
+                        const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
+                        if (y1 < y0 || b1 < b0) continue;
+                        for (int yw = y0 >> 5; yw <= (y1 >> 5); ++yw) {
+                            uint32_t m = 0;
+                            const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw + yw;
+                            for (int b = b0; b <= b1; ++b, mw += nyw) { m |= *mw; DCREG_STAT(table_loads); }
+                            const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
+                            m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
+                            while (m) {
+                                const int bit = __builtin_ctz(m);
+                                m &= m - 1;
+                                sweep_row((yw << 5) + bit, z, gz);
+                            }
+                        }
                     }
                 }
             }
