@@ -532,12 +532,19 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     a.state = nullptr; a.state_stride = 0;
     a.xcd_chunk = (uint32_t)std::max(c->opt_xcd_chunk, 0);
     if (n_poses == 1 && !state_ids && !gated) {
-        if (c->hint_unknown && c->last_pose_valid) {
+        // how far this pose may carry a point from where the last linearised pose had it
+        double jump = 1e300;
+        if (c->last_pose_valid) {
             double dr = 0.0, dt = 0.0;
             for (int k = 0; k < 9; ++k) dr += (R9[k] - c->last_R[k]) * (R9[k] - c->last_R[k]);
             for (int k = 0; k < 3; ++k) dt += (t3[k] - c->last_t[k]) * (t3[k] - c->last_t[k]);
-            if (std::sqrt(dr) * c->src_radius + std::sqrt(dt) <= 0.5 * c->grid.h) c->hint_misalign = c->hint_last;      // the same trajectory, continued
+            jump = std::sqrt(dr) * c->src_radius + std::sqrt(dt);
         }
+        if (c->hint_unknown && jump <= 0.5 * c->grid.h) c->hint_misalign = c->hint_last;      // the same trajectory, continued
+        // ... and what the last completed launch searched says nothing about a launch half a cell or more away from it (the first
+        // launch of a new run): expect a search of everything - for this launch and for the one that may be queued behind it before
+        // its counts are known (scheduling only: which kernels carry the launch out)
+        if (jump > 0.5 * c->grid.h) { c->last_searched = n_poses * c->n_src; c->last_points = c->last_searched; }
         c->hint_unknown = false;
         std::memcpy(c->last_R, R9, sizeof(c->last_R)); std::memcpy(c->last_t, t3, sizeof(c->last_t));
         c->last_pose_valid = true;
@@ -643,7 +650,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         // event behind the copy - no copyBuffer between two consecutive kernels on the compute stream (it was 4.6 us in front of every
         // 66 us batch: profiles/r04_c5_montecarlo_5000.md).  The slot's previous launch has completed (S.pending was false), so
         // nothing reads d_poses any more.
-        if (c->copy_stream && S.ev_poses) {
+        if (c->opt_pose_copy_stream && c->copy_stream && S.ev_poses) {
             HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(S.ev_poses, c->copy_stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, S.ev_poses, 0));
@@ -669,10 +676,22 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             adv = f >= c->opt_advance_lo && f <= c->opt_advance_hi;
         }
     }
-    const uint32_t n_tiles = blocks_for(n, kAdvTile);
-    if (adv) {
+    if (n_poses == 1 && !state_ids && uses_state && one.fresh != 0u) { c->last_searched = n; c->last_points = n; }     // (a fresh state: every point is searched)
+    // ... or its small-frame form (k_advance_team: sixteen lanes per query, one wave per kTeamTile points): a frame of a few thousand
+    // points, whose query blocks leave most of the device idle, in a launch expected to search something but not more than the teams
+    // can take without becoming the bottleneck themselves
+    bool team = false;
+    if (n_poses == 1 && !state_ids && uses_state && one.fresh == 0u && a.use_cert && !dbg_host && a.count_scale != 0.0 && a.warm && c->opt_team_pass != 0) {
+        if (c->opt_team_pass >= 2) team = true;
+        else if (n <= (int64_t)c->opt_team_pass_max_points && c->last_points == n)
+            team = c->last_searched >= (int64_t)c->opt_team_pass_min_searched && c->last_searched <= (int64_t)c->opt_team_pass_max_searched;
+    }
+    if (team) adv = false;
+    const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
+    if (adv || team) {
         if (ensure(c, c->d_adv_counts, c->adv_counts_cap, (size_t)2 * n_tiles)) return DCREG_E_NOMEM;
         a.adv_counts = c->d_adv_counts;
+        a.adv_n = n_tiles;
     }
     DebugDev dd{};
     free_tmp(S);
@@ -727,6 +746,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (le != hipSuccess) return bail("advance pass launch", le);
         c->n_advance_launches += 1;
     }
+    if (team) {
+        if (fast) hipLaunchKernelGGL((k_advance_team<true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag);
+        else hipLaunchKernelGGL((k_advance_team<false>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return bail("team advance pass launch", le);
+        c->n_advance_launches += 1;
+    }
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
@@ -772,7 +798,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
     S.stamps_only = stamps_only;
-    S.advanced = adv;
+    S.advanced = adv ? 1 : (team ? 2 : 0);
     S.coded = a.count_scale != 0.0;        // how THIS launch's count slots are to be read (the source may be replaced while it is pending)
     if (gated) {
         c->gate_slot = slot;
@@ -904,7 +930,7 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
     }
     c->last_searched = searched; c->last_refitted = refitted; c->last_points = (int64_t)S.n_poses * c->n_src;
     if (c->opt_record_launches && c->launch_series.size() < ((size_t)1 << 20))
-        c->launch_series.push_back(dcreg_ctx::LaunchRec{(double)launch_ms, searched, refitted, c->last_points, S.advanced ? 1 : 0});
+        c->launch_series.push_back(dcreg_ctx::LaunchRec{(double)launch_ms, searched, refitted, c->last_points, S.advanced});
     return DCREG_OK;
 }
 
@@ -1089,9 +1115,14 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
+    else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible
+    else if (k == "team_pass_max_points") c->opt_team_pass_max_points = v;
+    else if (k == "team_pass_min_searched") c->opt_team_pass_min_searched = v;
+    else if (k == "team_pass_max_searched") c->opt_team_pass_max_searched = v;
     else if (k == "advance_lo") c->opt_advance_lo = v;           // ... rule: the last launch searched between these fractions of its points
     else if (k == "advance_hi") c->opt_advance_hi = v;
     else if (k == "advance_min_blocks") c->opt_advance_min_blocks = (int)v;   // ... and the cloud has at least this many query blocks
+    else if (k == "pose_copy_stream") c->opt_pose_copy_stream = v != 0.0;   // batched launches: poses uploaded on the copy stream (0: on the compute stream)
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host

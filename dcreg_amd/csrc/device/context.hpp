@@ -36,7 +36,7 @@ struct LinSlot {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
     hipEvent_t ev_poses = nullptr;  // batched launches: "this slot's poses are on the device" (recorded on the ctx's copy stream)
     bool stamps_only = false;
-    bool advanced = false;         // the advance pass ran in front of the launch in flight (kernels.hpp k_advance)
+    int advanced = 0;              // an advance pass ran in front of the launch in flight: 1 = k_advance, 2 = k_advance_team (kernels.hpp)
     bool coded = false;            // the launch in flight reports searched / refitted counts above its count slots (LinArgs::count_scale)
 };
 
@@ -44,6 +44,7 @@ struct dcreg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;     // pose uploads of batched launches (linearize_begin)
+    bool opt_pose_copy_stream = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     char err[512] = {0};
 
@@ -174,6 +175,10 @@ struct dcreg_ctx {
     int opt_advance = 1;
     double opt_advance_lo = 0.01, opt_advance_hi = 0.45;      // ... the last completed launch searched between these fractions of its points
     int opt_advance_min_blocks = 2048;                        // ... and the cloud has at least this many query blocks (twice what the device holds)
+    // its small-frame form (k_advance_team): same switch values; rule: at most max_points source points, the last completed launch
+    // searched between min_searched and max_searched points
+    int opt_team_pass = 1;
+    double opt_team_pass_max_points = 131072.0, opt_team_pass_min_searched = 32.0, opt_team_pass_max_searched = 16384.0;
     uint32_t *d_adv_counts = nullptr; size_t adv_counts_cap = 0;
     int64_t n_advance_launches = 0;
     int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively

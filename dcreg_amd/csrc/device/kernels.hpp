@@ -415,10 +415,13 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
-    uint32_t adv_s = 0, adv_r = 0;                  // ... and what the advance pass in front of this launch did for this block's tile
-    if (a.adv_counts && wave == 0 && (vb % (uint32_t)(kAdvTile / kLinBlock)) == 0u) {
-        adv_s = a.adv_counts[2 * (vb / (uint32_t)(kAdvTile / kLinBlock))];
-        adv_r = a.adv_counts[2 * (vb / (uint32_t)(kAdvTile / kLinBlock)) + 1];
+    uint32_t adv_s = 0, adv_r = 0;                  // ... and this block's share of what the advance pass in front of this launch did
+    if (a.adv_counts && wave == 0) {                // (entries vb, vb + n_blocks, ...: at most a few per lane; the sum lands in every lane)
+        for (uint32_t e = vb + (uint32_t)threadIdx.x * n_blocks_x; e < a.adv_n; e += 64u * n_blocks_x) {
+            adv_s += a.adv_counts[2 * (size_t)e]; adv_r += a.adv_counts[2 * (size_t)e + 1];
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { adv_s += (uint32_t)__shfl_xor((int)adv_s, m); adv_r += (uint32_t)__shfl_xor((int)adv_r, m); }
     }
     KnnResult<5> nn;
     Fit fit;
@@ -702,6 +705,241 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_advance(con
         const uint32_t e = k * 64u + (uint32_t)lane;
         chunk(std::false_type{}, e, e < n_r);
     }
+}
+
+// ---------------------------------------------------------------- the advance pass for small frames: sixteen lanes per query
+// One registration of a 1-10 k-point frame against a large map (the reference's own workload, icp_test_runner.cpp:442-461) is a few
+// dozen query blocks on a 256-CU device: every wave alone on its SIMD, each running the lock-step search - a chain of a dozen dependent
+// accesses - for its 64 queries.  k_advance_team turns the roles round, like team_search6 but for EVERY query of the launch that needs
+// it, warm or loose: blocks of ONE wave take kTeamTile consecutive points, test their certificates, and serve the points that fail four
+// at a time, SIXTEEN lanes per query -
+//   * the six old neighbours gathered by six lanes (the warm bound: the largest of their distances, inflated like lin_search6's),
+//   * the (y,z) rows of the query's ball - whatever its radius, up to kTeamRows of them - cut to the ball by one lane each
+//     (ball_row: two table loads per row, all in flight together),
+//   * the candidates of all rows dealt to the sixteen lanes (at most kTeamCand each, requested together: ONE round trip for all of
+//     them), the ones inside the bound compacted into the group's list,
+//   * the list ranked by the exact key (distance bits, original index): the first six ranks are the neighbours in canonical order,
+//     the seventh distance the exact lower bound SET6 certificates want,
+//   * certificate, plane fit and state written by the group's first lane, exactly as k_lin's levels 1 and 2 write them -
+// so that a frame of 8 k points is ~1500 waves spread over the device, each a chain of five accesses.  k_lin then finds the
+// certificates fresh and runs the stored-plane path.  A query the team cannot serve (more rows, candidates or points inside its bound
+// than the lists hold) is left alone: k_lin searches it itself.  Results never depend on who searched (history independence).
+#if !defined(DCREG_TEAM_TILE)
+#define DCREG_TEAM_TILE 8
+#endif
+constexpr int kTeamTile = DCREG_TEAM_TILE;        // points per block (one wave)
+constexpr int kTeamG = 16;                        // lanes per query
+constexpr int kTeamRows = 64;                     // rows of a ball the group handles (four per lane)
+constexpr int kTeamCand = 8;                      // candidates per lane
+constexpr int kTeamList = 64;                     // points inside the bound the ranking handles
+static_assert(kTeamTile >= 4 && kTeamTile <= 64, "one wave tests the tile; k_lin reads at most 64 count entries per lane pass");
+struct TeamPassLds {
+    uint32_t q_i[kTeamTile]; float q_x[kTeamTile], q_y[kTeamTile], q_z[kTeamTile]; uint32_t q_kind[kTeamTile];
+    uint32_t run_s[4][kTeamRows], run_len[4][kTeamRows];
+    uint32_t lane_pos[kTeamCand][kWave];
+    uint32_t c_d2[4][kTeamList], c_idx[4][kTeamList], c_pos[4][kTeamList];
+    uint32_t o_d2[4][8], o_pos[4][8];
+};
+template <bool FAST>
+static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
+                                                             const PoseArg *__restrict__ poses, LinArgs a, uint32_t *__restrict__ counts,
+                                                             const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;
+    __shared__ TeamPassLds L;
+    const int lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
+    PoseArg P;
+    if (poses) P = poses[0]; else P = pose1;
+    const size_t ss = a.state_stride;
+    uint32_t *const sbase = a.state + (size_t)P.state * kStateRows * ss;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    uint4 *const SV0 = reinterpret_cast<uint4 *>(sbase + kStV0 * ss), *const SX = reinterpret_cast<uint4 *>(sbase + kStX * ss);
+    dbl2 *const SV1 = reinterpret_cast<dbl2 *>(sbase + kStV1 * ss), *const SV2 = reinterpret_cast<dbl2 *>(sbase + kStV2 * ss);
+    uint32_t *const SW3 = sbase + kStW3 * ss;
+    uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
+    const uint32_t *const SXw = sbase + kStX * ss, *const SYw = sbase + kStY * ss;
+    // ---- the tests: one point per lane
+    uint32_t n_q;
+    {
+        const uint32_t i = blockIdx.x * (uint32_t)kTeamTile + (uint32_t)lane;
+        const bool have = lane < kTeamTile && i < n_src;
+        uint32_t kind = 0;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (have) {
+            const float4 s4 = src[i];
+            const uint4 v0 = SV0[i];
+            const uint32_t w3 = SW3[i];
+            body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
+            const float q0x = __uint_as_float(v0.z), q0y = __uint_as_float(v0.w), q0z = __uint_as_float(w3);
+            const bool need = !cert_holds(v0.x, q0x, q0y, q0z, qx, qy, qz);
+            const bool refit = !need && !cert_is_out(v0.x) && !fit_holds(v0.y, q0x, q0y, q0z, qx, qy, qz);
+            kind = need ? 1u : (refit ? 2u : 0u);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(kind != 0u);
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (kind != 0u) { L.q_i[slot] = i; L.q_x[slot] = qx; L.q_y[slot] = qy; L.q_z[slot] = qz; L.q_kind[slot] = kind; }
+        n_q = (uint32_t)__builtin_popcountll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t served_s = 0, served_r = 0;                     // (in the first lane of every group: what it served)
+    const unsigned long long gmask = 0xFFFFull << (16 * grp);
+    auto gballot = [&](bool x) -> uint32_t { return (uint32_t)((__builtin_amdgcn_ballot_w64(x) & gmask) >> (16 * grp)); };
+    for (uint32_t r0 = 0; r0 < n_q; r0 += 4u) {
+        const uint32_t e = r0 + (uint32_t)grp;
+        const bool act = e < n_q;
+        const uint32_t i = act ? L.q_i[e] : 0u;
+        const float qx = act ? L.q_x[e] : 0.f, qy = act ? L.q_y[e] : 0.f, qz = act ? L.q_z[e] : 0.f;
+        const uint32_t kind = act ? L.q_kind[e] : 0u;
+        bool srch = kind == 1u;                               // uniform over the group
+        uint32_t n_in = 0;                                    // points inside the bound (uniform over the group)
+        float bound = a.radius_sq_f;
+        if (srch) {
+            // ---- the bound: the six old neighbours, one per lane
+            float d2 = 0.f;
+            bool okp = gl >= 6;
+            if (gl < 6 && a.warm) {
+                const uint32_t p = gl < 4 ? SXw[(size_t)i * 4 + gl] : SYw[(size_t)i * 2 + (gl - 4)];
+                if (p != kNoIdx) { const float4 c = g.pts[p]; d2 = dist2_nofma(qx, qy, qz, c); okp = true; }
+            }
+            const bool have6 = gballot(okp) == 0xFFFFu;
+#pragma unroll
+            for (int m = 1; m < kTeamG; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m, kTeamG));
+            if (have6) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(d2) + 1u), 1.17549435e-38f));      // inclusive, as warm_bound6
+            const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
+            bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
+        }
+        // ---- the rows of the ball
+        uint32_t n_runs = 0, n_cand = 0;                      // (uniform over the group)
+        if (srch) {
+            const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+            const double lim = (double)a.max_ring + 1.0;
+            const bool reach = !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
+            const BallCells bc = ball_cells(g, reach ? qx : (float)g.ox, reach ? qy : (float)g.oy, reach ? qz : (float)g.oz, bound);
+            const int ny_r = bc.yhi - bc.ylo + 1, nz_r = bc.zhi - bc.zlo + 1;
+            const int n_rows = reach ? ny_r * nz_r : 0;
+            if (n_rows > kTeamRows) srch = false;            // a ball of more rows than the group handles: left to k_lin
+            uint32_t rs[kTeamRows / kTeamG], re[kTeamRows / kTeamG];
+#pragma unroll
+            for (int t = 0; t < kTeamRows / kTeamG; ++t) {
+                const int k = gl + kTeamG * t;
+                rs[t] = 0u; re[t] = 0u;
+                if (srch && k < n_rows) ball_row(g, bc, bound, bc.ylo + k % ny_r, bc.zlo + k / ny_r, rs[t], re[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kTeamRows / kTeamG; ++t) {
+                const bool ne = re[t] > rs[t];
+                const uint32_t bits = gballot(ne);
+                const uint32_t slot = n_runs + (uint32_t)__builtin_popcount(bits & ((1u << gl) - 1u));
+                if (ne) { L.run_s[grp][slot] = rs[t]; L.run_len[grp][slot] = re[t] - rs[t]; }
+                n_runs += (uint32_t)__builtin_popcount(bits);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- the candidates of all runs, dealt to the sixteen lanes: flat index f = gl + 16 j
+        uint32_t nc = 0;                                      // this lane's candidates
+        if (srch) {
+            uint32_t off = 0;
+            for (uint32_t k = 0; k < n_runs; ++k) {
+                const uint32_t s_ = L.run_s[grp][k], len = L.run_len[grp][k];
+                for (uint32_t f = off + (((uint32_t)gl - off) & (uint32_t)(kTeamG - 1)); f < off + len; f += (uint32_t)kTeamG) {
+                    if (nc < (uint32_t)kTeamCand) L.lane_pos[nc][lane] = s_ + (f - off);
+                    ++nc;
+                }
+                off += len;
+            }
+            n_cand = off;
+            if (n_cand > (uint32_t)(kTeamCand * kTeamG)) srch = false;      // more candidates than the lanes take: left to k_lin
+        }
+        if (srch) {
+            float4 c[kTeamCand];
+            uint32_t cp[kTeamCand];
+#pragma unroll
+            for (int j = 0; j < kTeamCand; ++j) {
+                cp[j] = (uint32_t)j < nc ? L.lane_pos[j][lane] : 0u;
+                c[j] = g.pts[cp[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < kTeamCand; ++j) {
+                const float d2 = dist2_nofma(qx, qy, qz, c[j]);
+                const bool pass = (uint32_t)j < nc && d2 < bound;
+                const uint32_t bits = gballot(pass);
+                const uint32_t slot = n_in + (uint32_t)__builtin_popcount(bits & ((1u << gl) - 1u));
+                if (pass && slot < (uint32_t)kTeamList) { L.c_d2[grp][slot] = __float_as_uint(d2); L.c_idx[grp][slot] = __float_as_uint(c[j].w); L.c_pos[grp][slot] = cp[j]; }
+                n_in += (uint32_t)__builtin_popcount(bits);
+            }
+            if (n_in > (uint32_t)kTeamList) srch = false;    // more points inside the bound than the ranking handles: left to k_lin
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- rank by (distance bits, original index): a total order; the first seven ranks go to the out list
+        if (srch) {
+#pragma unroll
+            for (int m = 0; m < kTeamList / kTeamG; ++m) {
+                const uint32_t me = (uint32_t)(gl + kTeamG * m);
+                if (me < n_in) {
+                    const unsigned long long key = ((unsigned long long)L.c_d2[grp][me] << 32) | L.c_idx[grp][me];
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < n_in; ++j) {
+                        const unsigned long long kj = ((unsigned long long)L.c_d2[grp][j] << 32) | L.c_idx[grp][j];
+                        rank += kj < key ? 1u : 0u;
+                    }
+                    if (rank < 7u) { L.o_d2[grp][rank] = L.c_d2[grp][me]; L.o_pos[grp][rank] = L.c_pos[grp][me]; }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- certificate, fit, state: the group's first lane
+        const bool lead = gl == 0 && ((kind == 1u && srch) || kind == 2u);
+        uint32_t pos6[6], cert = kCertSearch;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
+        if (lead && kind == 1u) {
+            Set6 out;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const bool got = (uint32_t)j < n_in;
+                out.pos[j] = got ? L.o_pos[grp][j] : kNoIdx;
+                out.d2[j] = got ? __uint_as_float(L.o_d2[grp][j]) : bound;
+            }
+            out.lb7 = n_in > 6u ? fminf(__uint_as_float(L.o_d2[grp][6]), bound) : bound;
+            out.n_eval = 0; out.n_shell = 1;
+            cert = make_cert(out, a);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) pos6[j] = out.pos[j];
+            SX[i] = make_uint4(pos6[0], pos6[1], pos6[2], pos6[3]);
+            SY[i] = make_uint2(pos6[4], pos6[5]);
+        } else if (lead) {
+            const uint4 x = SX[i];
+            const uint2 y = SY[i];
+            pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
+            const uint4 o0 = SV0[i];
+            const uint32_t o1 = SW3[i];
+            cert = cert_rebased(o0.x, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz);
+        }
+        const bool set = lead && !cert_is_out(cert);
+        if (wave_any(set)) {
+            const bool use6 = set && cert_is_set6(cert);
+            const bool six = wave_any(use6);
+            if (!use6) pos6[5] = kNoIdx;
+            if (set) {
+                KnnResult<5> nn;
+                Fit fit;
+                (void)fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, false);
+                SV0[i] = make_uint4(cert, fit.word, __float_as_uint(qx), __float_as_uint(qy));
+                SV1[i] = dbl2{fit.plane[0], fit.plane[1]};
+                SV2[i] = dbl2{fit.plane[2], fit.plane[3]};
+                SW3[i] = __float_as_uint(qz);
+            }
+        }
+        if (lead && !set) {                         // searched and found OUT: certificate and reference position, no fit
+            SV0[i] = make_uint4(cert, kFitNone, __float_as_uint(qx), __float_as_uint(qy));
+            SW3[i] = __float_as_uint(qz);
+        }
+        if (lead) { served_s += kind == 1u ? 1u : 0u; served_r += kind == 2u ? 1u : 0u; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // what the block served (the points it left to k_lin are counted there)
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) { served_s += (uint32_t)__shfl_xor((int)served_s, m); served_r += (uint32_t)__shfl_xor((int)served_r, m); }
+    if (lane == 0 && counts) { counts[2 * blockIdx.x] = served_s; counts[2 * blockIdx.x + 1] = served_r; }
 }
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused

@@ -142,9 +142,9 @@ struct LinArgs {
                                   // and the host splits them again (context.hip linearize_end).  What the host does with them:
                                   // scheduling only (which instantiation the next launch uses) and the launch statistics.  0 for
                                   // clouds of more than 2^26 points.
-    const uint32_t *adv_counts;   // a launch that runs behind the advance pass (kernels.hpp k_advance): per tile of kAdvTile points the
-                                  // points that pass searched and refitted, [tile][2]; the first query block of a tile adds them to the
-                                  // counts it reports (count_scale).  null: no pass in front
+    const uint32_t *adv_counts;   // a launch that runs behind an advance pass (kernels.hpp k_advance / k_advance_team): per block of that pass
+    uint32_t adv_n;               // the points it searched and refitted, [adv_n][2]; query block b of this launch adds the entries b, b + n_blocks,
+                                  // ... to the counts it reports (count_scale): every entry is reported once.  null: no pass in front
     float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
                                   // reaches this many cells beyond the distance to that cell (lin_search6)
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
@@ -377,10 +377,6 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
 constexpr int kPend = DCREG_PEND;
 static_assert(kPend >= 4, "a trip parks up to four candidates: the pending list must hold them");
 constexpr int kWave = 64;
-#if !defined(DCREG_SWEEP_BATCH)
-#define DCREG_SWEEP_BATCH 4
-#endif
-constexpr int kSweepBatch = DCREG_SWEEP_BATCH;   // z layers of the row sweep whose occupancy words are requested together (knn_shells)
 struct PendEntry { uint32_t d2_bits, pos; };
 // One RunList per WAVE ([slot][lane]); a wave's list is private to it, so once its search is over the same LDS serves as
 // that wave's staging area for the MFMA reduction of the rows (kernels.hpp) without a block barrier in between.
@@ -743,98 +739,31 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
             int zlo, zhi;
             reach(w0, frz, cap, zlo, zhi);
             const int zmax = max(-zlo, zhi);
-            // Layers are taken kSweepBatch at a time: first the row occupancy words of all layers of the batch are requested (ranges from
-            // the ball as it stands at the start of the batch - a superset of what each layer would ask for when its turn comes), then
-            // the layers are swept in order, centre-out.  One exposed memory round trip per batch instead of one per layer: a query
-            // 0.87 m from its surface has 17 layers, and their dependent mask loads were a third of its wave's life (round 4's stamps).
-            // Rows the shrinking ball no longer reaches are turned away by sweep_row itself, so the scans are the same.
-            // A layer whose y range spans more than two words, or whose ball spans more than two 16-cell x blocks (cells far smaller
-            // than the radius), reads its words when its turn comes, as before.
-            bool over = false;
-            for (int i0 = 0; i0 <= 2 * zmax && !over; i0 += kSweepBatch) {
-                // (what pass 1 learns about a layer waits in the wave's run list - the cell-table phase is over, its slots are free: words
-                //  yw0 and yw0 + 1, OR-ed over the x blocks, in s / e; the y range in two gap2h slots, 0xFFFF = nothing to do, 0xFFFE = wide.
-                //  In registers the twelve values of a batch cost the kernel its scratch-free allocation.)
-                static_assert(2 * kSweepBatch <= 9, "the batch's y ranges live in the nine gap2h slots of the run list");
-                const int tid = threadIdx.x & (kWave - 1);
-                {
-                    const float w = hp.worst_d2();
-#pragma unroll
-                    for (int u = 0; u < kSweepBatch; ++u) {
-                        const int i = i0 + u;
-                        const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
-                        const int z = cz + dz;
-                        const float nearer = (float)max(adz - 1, 0) * hf;
-                        bool live = i <= 2 * zmax && !(nearer * nearer * 0.99999f > w) && z >= 0 && z < nz;
-                        const float gz = slab(clampi(z, 0, nz - 1), cz, frz);
-                        const float rem = w - gz * gz * 0.99999f;
-                        live = live && !(rem < 0.f);
-                        int ylo, yhi, xlo, xhi;
-                        reach(rem, fry, cap, ylo, yhi);
-                        reach(rem, frx, cap, xlo, xhi);
-                        const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
-                        const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
-                        live = live && y1 >= y0 && b1 >= b0;
-                        const bool wide = live && (((y1 >> 5) - (y0 >> 5)) > 1 || b1 - b0 > 1 || y1 >= 0xFFFE);
-                        rl.gap2h[u][tid] = live ? (wide ? (uint16_t)0xFFFEu : (uint16_t)y0) : (uint16_t)0xFFFFu;
-                        rl.gap2h[kSweepBatch + u][tid] = (uint16_t)y1;
-                        if (live && !wide) {
-                            const int yw0 = y0 >> 5, yw1 = y1 >> 5, bb = min(b0 + 1, b1);
-                            const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw, *mv = g.ymask + ((int64_t)z * nxb + bb) * nyw;
-                            const uint32_t a0_ = mw[yw0], a1_ = mv[yw0], c0_ = mw[yw1], c1_ = mv[yw1];
-                            DCREG_STAT(table_loads); DCREG_STAT(table_loads);
-                            rl.s[u][tid] = a0_ | a1_;
-                            rl.e[u][tid] = yw1 > yw0 ? (c0_ | c1_) : 0u;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kSweepBatch; ++u) {
-                    const uint32_t y0s = rl.gap2h[u][tid];
-                    if (over || y0s == 0xFFFFu) continue;
-                    const int i = i0 + u;
-                    const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
-                    const float w = hp.worst_d2();
-                    { const float nearer = (float)max(adz - 1, 0) * hf; if (nearer * nearer * 0.99999f > w) { over = true; continue; } }   // this |dz| and beyond are out
-                    const int z = cz + dz;
-                    const float gz = slab(z, cz, frz);
-                    if (y0s != 0xFFFEu) {
-                        const int y0 = (int)y0s, y1 = (int)rl.gap2h[kSweepBatch + u][tid];
-                        const int yw0 = y0 >> 5;
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int yw = yw0 + k;
-                            if (yw > (y1 >> 5)) break;
-                            uint32_t m = k ? rl.e[u][tid] : rl.s[u][tid];
-                            const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
-                            m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
-                            while (m) {
-                                const int bit = __builtin_ctz(m);
-                                m &= m - 1;
-                                sweep_row((yw << 5) + bit, z, gz);
-                            }
-                        }
-                    } else {                    // a wide layer: ranges and words when its turn comes
-                        const float rem = w - gz * gz * 0.99999f;
-                        if (rem < 0.f) continue;
-                        int ylo, yhi, xlo, xhi;
-                        reach(rem, fry, cap, ylo, yhi);
-                        reach(rem, frx, cap, xlo, xhi);
-                        const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
-                        const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
-                        if (y1 < y0 || b1 < b0) continue;
-                        for (int yw = y0 >> 5; yw <= (y1 >> 5); ++yw) {
-                            uint32_t m = 0;
-                            const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw + yw;
-                            for (int b = b0; b <= b1; ++b, mw += nyw) { m |= *mw; DCREG_STAT(table_loads); }
-                            const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
-                            m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
-                            while (m) {
-                                const int bit = __builtin_ctz(m);
-                                m &= m - 1;
-                                sweep_row((yw << 5) + bit, z, gz);
-                            }
-                        }
+            for (int i = 0; i <= 2 * zmax; ++i) {
+                const int adz = (i + 1) >> 1, dz = (i & 1) ? -adz : adz;
+                const float w = hp.worst_d2();
+                { const float nearer = (float)max(adz - 1, 0) * hf; if (nearer * nearer * 0.99999f > w) break; }   // both layers at this |dz| and beyond are out
+                const int z = cz + dz;
+                if (z < 0 || z >= nz) continue;
+                const float gz = slab(z, cz, frz);
+                const float rem = w - gz * gz * 0.99999f;
+                if (rem < 0.f) continue;
+                int ylo, yhi, xlo, xhi;
+                reach(rem, fry, cap, ylo, yhi);
+                reach(rem, frx, cap, xlo, xhi);
+                const int y0 = max(cy + ylo, 0), y1 = min(cy + yhi, ny - 1);
+                const int b0 = max(cx + xlo, 0) >> 4, b1 = min(cx + xhi, nx - 1) >> 4;
+                if (y1 < y0 || b1 < b0) continue;
+                for (int yw = y0 >> 5; yw <= (y1 >> 5); ++yw) {
+                    uint32_t m = 0;
+                    const uint32_t *mw = g.ymask + ((int64_t)z * nxb + b0) * nyw + yw;
+                    for (int b = b0; b <= b1; ++b, mw += nyw) { m |= *mw; DCREG_STAT(table_loads); }
+                    const int lo = max(y0 - (yw << 5), 0), hi = min(y1 - (yw << 5), 31);
+                    m &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo);
+                    while (m) {
+                        const int bit = __builtin_ctz(m);
+                        m &= m - 1;
+                        sweep_row((yw << 5) + bit, z, gz);
                     }
                 }
             }
@@ -1473,6 +1402,44 @@ DCREG_DEVFN void team_row(const GridDev &g, float qx, float qy, float qz, float 
     const bool ok = yok && zok && (x1 > x0) && !(g2 > bound_f);
     const uint32_t row = ((uint32_t)(cz + dz) * uny + (uint32_t)(cy + dy)) * unx;     // (garbage when outside: not used then)
     (void)sxy;
+    s_out = g.cell_start[ok ? row + (uint32_t)x0 : 0u];
+    e_out = g.cell_start[ok ? row + (uint32_t)x1 : 0u];
+}
+
+// The rows of a query's BALL, any radius (the small-frame advance pass, kernels.hpp k_advance_team): cell of the query and, per axis,
+// the offsets of the cell layers the ball of squared radius bound_f reaches - the arithmetic of knn_shells' reach(), conservative alike
+// (1e-5 relative + 1e-4 of a cell)
+struct BallCells { int cx, cy, cz; float frx, fry, frz; int ylo, yhi, zlo, zhi; };
+DCREG_DEVFN BallCells ball_cells(const GridDev &g, float qx, float qy, float qz, float bound_f) {
+    const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
+    const double big = 6.0e7;
+    const double flx = floor(fmin(fmax(fx, -big), big)), fly = floor(fmin(fmax(fy, -big), big)), flz = floor(fmin(fmax(fz, -big), big));
+    BallCells b;
+    b.cx = (int)flx; b.cy = (int)fly; b.cz = (int)flz;
+    b.frx = (float)(fx - flx); b.fry = (float)(fy - fly); b.frz = (float)(fz - flz);
+    // (a query beyond +-6e7 cells: fr is huge, every slab distance comes out beyond any bound - no row is reached, as it must be)
+    const float rc = fminf(sqrt_approx(fmaxf(bound_f, 0.f)) * 1.00001f * (float)g.inv_h + 1e-4f, 1.0e6f);
+    const int cap = 1 << 24;
+    b.ylo = -min(cap, (int)floorf(rc + 1.f - b.fry)); b.yhi = min(cap, (int)floorf(rc + b.fry));
+    b.zlo = -min(cap, (int)floorf(rc + 1.f - b.frz)); b.zhi = min(cap, (int)floorf(rc + b.frz));
+    return b;
+}
+// [s, e) of the row (cy + dy, cz + dz) cut to the sub-cells the ball reaches (sweep_row's arithmetic); empty where the row lies
+// outside the grid or beyond the ball
+DCREG_DEVFN void ball_row(const GridDev &g, const BallCells &b, float bound_f, int dy, int dz, uint32_t &s_out, uint32_t &e_out) {
+    const float hf = (float)g.h;
+    const float gy = dy < 0 ? ((float)(-dy - 1) + b.fry) * hf : (dy > 0 ? ((float)dy - b.fry) * hf : 0.f);
+    const float gz = dz < 0 ? ((float)(-dz - 1) + b.frz) * hf : (dz > 0 ? ((float)dz - b.frz) * hf : 0.f);
+    const float dyz = (gy * gy + gz * gz) * 0.99999f;
+    const int sx = g.sx, nxf = g.nx * sx;
+    const int cxs = b.cx * sx;
+    const float uf = b.frx * (float)sx, inv_hfs = (float)g.inv_h * (float)sx;
+    const float xr_c = fminf((sqrt_approx(fmaxf(bound_f - dyz, 0.f)) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
+    const int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);
+    const int x0 = max(cxs + dlo, 0), x1 = min(cxs + dhi, nxf - 1) + 1;
+    const int y = b.cy + dy, z = b.cz + dz;
+    const bool ok = !(dyz > bound_f) && y >= 0 && y < g.ny && z >= 0 && z < g.nz && x1 > x0;
+    const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)nxf;     // (garbage when outside: not used then)
     s_out = g.cell_start[ok ? row + (uint32_t)x0 : 0u];
     e_out = g.cell_start[ok ? row + (uint32_t)x1 : 0u];
 }

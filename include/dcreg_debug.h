@@ -57,8 +57,9 @@ int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
  * exceed cap), < 0 on invalid arguments.  bench.py's per-regime roofline is built from this. */
 int dcreg_launch_series(dcreg_ctx *, double *ms, int64_t *searched, int64_t *refitted, int64_t *points, int64_t cap, int reset);
 /* ... and, for the same log (call it BEFORE the resetting dcreg_launch_series): 1 where the advance pass (kernels.hpp k_advance: the
- * searches and refits of a launch in dense waves, in front of the linearisation kernel) ran, 0 where it did not; the duration and the
- * counts of such a launch cover both kernels.  Returns the number of entries logged. */
+ * searches and refits of a launch in dense waves, in front of the linearisation kernel) ran, 2 where its small-frame form did
+ * (k_advance_team: sixteen lanes per query), 0 where neither did; the duration and the counts of such a launch cover both kernels.
+ * Returns the number of entries logged. */
 int dcreg_launch_series_passes(dcreg_ctx *, uint8_t *advanced, int64_t cap);
 
 /* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 1 = the full
@@ -88,6 +89,9 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "advance"            the advance pass in front of single-pose launches: 0 = never, 1 (default) = when the last completed launch searched
  *                        between "advance_lo" (0.01) and "advance_hi" (0.45) of its points and the cloud has at least "advance_min_blocks"
  *                        (2048) query blocks, 2 = whenever the launch can take it (warm state, certificates in use): tests;
+ *   "team_pass"          the small-frame advance pass (sixteen lanes per query) in front of single-pose launches: 0 = never, 1 (default) =
+ *                        for clouds of at most "team_pass_max_points" (131072) points when the last completed launch searched between
+ *                        "team_pass_min_searched" (32) and "team_pass_max_searched" (16384) points, 2 = whenever the launch can take it;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
  *   "fused_batches"      1 (default) = a batched launch whose poses have at most 64 query blocks each finishes inside the kernel (the last block
  *                        of a pose sums and publishes the pose's row); 0 = a k_finalize launch behind it, as for larger poses;

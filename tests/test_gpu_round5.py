@@ -47,7 +47,8 @@ def test_advance_pass_is_invisible(scene, fast):
     tgt, src, radius = _scene(scene, rng)
     prm = api.default_lin_params(radius, 1)
     ctxs = {}
-    for name, opts in (("adv", {"advance": 2}), ("plain", {"advance": 0}), ("all", {"use_certificates": 0, "advance": 0})):
+    for name, opts in (("adv", {"advance": 2, "team_pass": 0}), ("team", {"advance": 0, "team_pass": 2}), ("plain", {"advance": 0, "team_pass": 0}),
+                       ("all", {"use_certificates": 0, "advance": 0, "team_pass": 0})):
         c = api.Context(0)
         c.set_option("fast_plane_fit", fast)
         for k, v in opts.items():
@@ -57,20 +58,21 @@ def test_advance_pass_is_invisible(scene, fast):
         ctxs[name] = c
     T = np.eye(4)
     steps = [0.0, 1e-6, 1e-4, 3e-4, 1e-3, -1e-3, 2e-3, 1e-5, 4e-3, 6e-3, -6e-3, 1e-2, 1e-4, 3e-2, 0.2, 1e-3, 5e-4, 0.0]
-    ran, searched_adv, searched_plain = 0, 0, 0
+    ran, searched_adv, searched_team, searched_plain = 0, 0, 0, 0
     for k, sz in enumerate(steps):
         T = h.pose6d_matrix(sz * 0.6, -sz * 0.3, sz * 0.2, sz * 0.002, -sz * 0.001, sz * 0.004) @ T
         outs = {name: c.linearize(T[:3, :3], T[:3, 3], prm) for name, c in ctxs.items()}
         assert _same_sums(outs["adv"], outs["plain"]) and _same_sums(outs["adv"], outs["all"]), (scene, fast, k)
-        sa, sp = ctxs["adv"].launch_series(reset=True), ctxs["plain"].launch_series(reset=True)
+        assert _same_sums(outs["team"], outs["plain"]), (scene, fast, k)
+        sa, st, sp = ctxs["adv"].launch_series(reset=True), ctxs["team"].launch_series(reset=True), ctxs["plain"].launch_series(reset=True)
         ctxs["all"].launch_series(reset=True)
-        assert len(sa["ms"]) == 1 and sa["advanced"][0] == (1 if k > 0 else 0) and sp["advanced"][0] == 0
+        assert len(sa["ms"]) == 1 and sa["advanced"][0] == (1 if k > 0 else 0) and sp["advanced"][0] == 0 and st["advanced"][0] == (2 if k > 0 else 0)
         ran += int(sa["advanced"][0])
         if k > 0:
-            # (the two contexts need not search the same points: the certificates a search leaves depend on HOW it was carried out - the
-            #  team search of sparse waves knows the seventh distance exactly, the lock-step search of the pass a lower bound of it)
-            searched_adv += int(sa["searched"][0]); searched_plain += int(sp["searched"][0])
-    assert ran == len(steps) - 1 and searched_adv > 0 and searched_plain > 0
+            # (the contexts need not search the same points: the certificates a search leaves depend on HOW it was carried out - the
+            #  team searches know the seventh distance exactly, the lock-step search a lower bound of it)
+            searched_adv += int(sa["searched"][0]); searched_plain += int(sp["searched"][0]); searched_team += int(st["searched"][0])
+    assert ran == len(steps) - 1 and searched_adv > 0 and searched_plain > 0 and searched_team > 0
     for c in ctxs.values():
         c.close()
 
@@ -85,7 +87,7 @@ def test_advance_pass_in_whole_runs_and_behind_the_gate():
     cfg = api.default_config(search_radius=1.0, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=0.0,
                              CONVERGENCE_THRESH_TRANS=0.0, use_weight_derivative=1, always_compute_schur=1)
     logs, picked = {}, {}
-    for name, opts in (("rule", {"advance": 1, "advance_min_blocks": 1}), ("forced", {"advance": 2}), ("off", {"advance": 0})):
+    for name, opts in (("rule", {"advance": 1, "advance_min_blocks": 1, "team_pass": 0}), ("forced", {"advance": 2, "team_pass": 0}), ("off", {"advance": 0, "team_pass": 0})):
         c = api.Context(0)
         for k, v in opts.items():
             c.set_option(k, v)
@@ -105,6 +107,40 @@ def test_advance_pass_in_whole_runs_and_behind_the_gate():
                 assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]), (name, rep, it)
     assert picked["off"].sum() == 0 and picked["forced"].sum() >= 58
     assert 0 < picked["rule"].sum() < 50, picked["rule"]
+
+
+def test_small_frame_registration_with_the_team_pass():
+    """The reference's own workload (icp_test_runner.cpp:442-461): an 8 k-point frame registered against a 200 k-point map, from host
+    buffers, to convergence.  With the small-frame pass by the host's rule (the default), forced and off: iteration for iteration the
+    same H, g, counts and pose, bit for bit; the rule picks the pass for the launches behind the first."""
+    tgt, src = h.scene_parkinglot()
+    gt, T0 = h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
+    cfg = api.default_config(search_radius=0.5, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=1e-5,
+                             CONVERGENCE_THRESH_TRANS=1e-3, use_weight_derivative=0, always_compute_schur=1, gt_matrix=gt.reshape(16))
+    logs, picked = {}, {}
+    for name, opts in (("rule", {}), ("forced", {"team_pass": 2}), ("off", {"team_pass": 0})):
+        c = api.Context(0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_option("record_launches", 1)
+        c.set_target(tgt, 0.5)
+        runs = []
+        for rep in range(2):
+            c.set_source(src)
+            res, lg = c.icp_run(T0, "Ours", cfg)
+            assert res.converged == 1
+            runs.append([(np.array(L.H_upper[:]), np.array(L.gradient[:]), L.effective_points, L.corr_pt_count, np.array(L.transform_matrix[:])) for L in lg[:res.iterations]])
+        logs[name] = runs
+        picked[name] = c.launch_series(reset=True)["advanced"]
+        c.close()
+    for name in ("rule", "forced"):
+        for rep in range(2):
+            assert len(logs[name][rep]) == len(logs["off"][rep])
+            for it, (x, y) in enumerate(zip(logs[name][rep], logs["off"][rep])):
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]), (name, rep, it)
+    assert picked["off"].sum() == 0
+    n_it = len(logs["off"][0])
+    assert (picked["rule"] == 2).sum() >= 2 * (n_it - 3), picked["rule"]
 
 
 def test_parity_fit_takes_its_rows_in_distance_order():
