@@ -122,7 +122,7 @@ EXPORTS = [
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
     "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn", "dcreg_kdtree_build", "dcreg_kdtree_info", "dcreg_knn_timed",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
-    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_launch_series", "dcreg_launch_series_passes", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
+    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_launch_series", "dcreg_launch_series_passes", "dcreg_team_pass_stamps", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_icp_run_montecarlo", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
     "dcreg_set_host_threads", "dcreg_get_host_threads", "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
@@ -180,6 +180,7 @@ def load():
     L.dcreg_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     L.dcreg_launch_series.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.c_int]
     L.dcreg_launch_series_passes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64]
+    L.dcreg_team_pass_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.dcreg_default_config.restype = None
     L.dcreg_default_config.argtypes = [C.POINTER(Config)]
     L.dcreg_analyze_degeneracy.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis)]
@@ -547,6 +548,15 @@ class Context:
         self._L.dcreg_launch_series_passes(self._h, adv.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         self._L.dcreg_launch_series(self._h, _dp(ms), se.ctypes.data_as(lp), rf.ctypes.data_as(lp), pt.ctypes.data_as(lp), n, int(reset))
         return {"ms": ms, "searched": se, "refitted": rf, "points": pt, "advanced": adv}
+
+    def team_pass_stamps(self):
+        """dcreg_team_pass_stamps (option "team_stamps"): [n_blocks, 8] shader-clock words of the last launch that ran the small-frame pass"""
+        n = self._L.dcreg_team_pass_stamps(self._h, None, 0)
+        if n <= 0:
+            return np.zeros((0, 8), np.uint64)
+        st = np.zeros((n + 1, 8), np.uint64)          # the last row: outcome counts (served with slack, layers, wide, rows, list, OUT, no slack, refit)
+        self._L.dcreg_team_pass_stamps(self._h, st.ctypes.data_as(C.POINTER(C.c_uint64)), n + 1)
+        return st
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()

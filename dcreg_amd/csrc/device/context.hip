@@ -747,8 +747,14 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         c->n_advance_launches += 1;
     }
     if (team) {
-        if (fast) hipLaunchKernelGGL((k_advance_team<true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag);
-        else hipLaunchKernelGGL((k_advance_team<false>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag);
+        unsigned long long *stamps = nullptr;
+        if (c->opt_team_stamps) {          // timing probe (dcreg_debug.h dcreg_team_pass_stamps): eight clock words per block of the pass
+            if (ensure(c, c->d_team_stamps, c->team_stamps_cap, (size_t)8 * (n_tiles + 1))) return DCREG_E_NOMEM;
+            (void)hipMemsetAsync(c->d_team_stamps, 0, sizeof(unsigned long long) * 8 * (n_tiles + 1), c->stream);
+            stamps = c->d_team_stamps; c->team_stamps_n = n_tiles;
+        }
+        if (fast) hipLaunchKernelGGL((k_advance_team<true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag, stamps);
+        else hipLaunchKernelGGL((k_advance_team<false>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag, stamps);
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) return bail("team advance pass launch", le);
         c->n_advance_launches += 1;
@@ -1058,7 +1064,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
                     c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner,
-                    c->d_adv_counts};
+                    c->d_adv_counts, c->d_team_stamps};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -1115,6 +1121,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
+    else if (k == "team_stamps") c->opt_team_stamps = v != 0.0;   // timing probe of the small-frame pass (dcreg_team_pass_stamps)
     else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "team_pass_max_points") c->opt_team_pass_max_points = v;
     else if (k == "team_pass_min_searched") c->opt_team_pass_min_searched = v;
@@ -1282,6 +1289,17 @@ int dcreg_launch_series_passes(dcreg_ctx *c, uint8_t *advanced, int64_t cap) {
     const int64_t n = std::min<int64_t>(cap, (int64_t)c->launch_series.size());
     for (int64_t i = 0; i < n; ++i) if (advanced) advanced[i] = (uint8_t)c->launch_series[(size_t)i].advanced;
     return (int)std::min<int64_t>((int64_t)c->launch_series.size(), 0x7FFFFFFF);
+}
+
+int dcreg_team_pass_stamps(dcreg_ctx *c, uint64_t *out, int64_t cap_blocks) {
+    if (!c || cap_blocks < 0) return -1;
+    if (!c->d_team_stamps || c->team_stamps_n == 0) return 0;
+    const int64_t n = std::min<int64_t>(cap_blocks, (int64_t)c->team_stamps_n + 1);      // (+ 1: the outcome histogram behind the blocks)
+    if (out && n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_team_stamps, sizeof(unsigned long long) * 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return (int)std::min<int64_t>((int64_t)c->team_stamps_n, 0x7FFFFFFF);
 }
 
 int dcreg_kernel_time(dcreg_ctx *c, double *ms_total, int64_t *launches, int reset) {

@@ -179,6 +179,8 @@ struct dcreg_ctx {
     // searched between min_searched and max_searched points
     int opt_team_pass = 1;
     double opt_team_pass_max_points = 131072.0, opt_team_pass_min_searched = 32.0, opt_team_pass_max_searched = 16384.0;
+    bool opt_team_stamps = false;
+    unsigned long long *d_team_stamps = nullptr; size_t team_stamps_cap = 0; uint32_t team_stamps_n = 0;
     uint32_t *d_adv_counts = nullptr; size_t adv_counts_cap = 0;
     int64_t n_advance_launches = 0;
     int opt_team_max = 7;          // search.hpp team_search6: waves with at most this many lanes to search serve them cooperatively

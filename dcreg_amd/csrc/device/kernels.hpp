@@ -709,23 +709,27 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_advance(con
 
 // ---------------------------------------------------------------- the advance pass for small frames: sixteen lanes per query
 // One registration of a 1-10 k-point frame against a large map (the reference's own workload, icp_test_runner.cpp:442-461) is a few
-// dozen query blocks on a 256-CU device: every wave alone on its SIMD, each running the lock-step search - a chain of a dozen dependent
-// accesses - for its 64 queries.  k_advance_team turns the roles round, like team_search6 but for EVERY query of the launch that needs
-// it, warm or loose: blocks of ONE wave take kTeamTile consecutive points, test their certificates, and serve the points that fail four
-// at a time, SIXTEEN lanes per query -
-//   * the six old neighbours gathered by six lanes (the warm bound: the largest of their distances, inflated like lin_search6's),
-//   * the (y,z) rows of the query's ball - whatever its radius, up to kTeamRows of them - cut to the ball by one lane each
-//     (ball_row: two table loads per row, all in flight together),
-//   * the candidates of all rows dealt to the sixteen lanes (at most kTeamCand each, requested together: ONE round trip for all of
-//     them), the ones inside the bound compacted into the group's list,
-//   * the list ranked by the exact key (distance bits, original index): the first six ranks are the neighbours in canonical order,
-//     the seventh distance the exact lower bound SET6 certificates want,
-//   * certificate, plane fit and state written by the group's first lane, exactly as k_lin's levels 1 and 2 write them -
-// so that a frame of 8 k points is ~1500 waves spread over the device, each a chain of five accesses.  k_lin then finds the
-// certificates fresh and runs the stored-plane path.  A query the team cannot serve (more rows, candidates or points inside its bound
-// than the lists hold) is left alone: k_lin searches it itself.  Results never depend on who searched (history independence).
+// dozen query blocks on a 256-CU device: every wave alone on its SIMD, each running the lock-step search for its 64 queries - a chain
+// of a dozen and more DEPENDENT memory round trips (0.5-0.8 us each: old neighbours, start-bound probe trip by trip, cell table,
+// candidate trips, sweep layers, fit gather), which is what such a launch lasts.  k_advance_team turns the roles round, like
+// team_search6 but for EVERY query of the launch that needs it, warm or loose: blocks of ONE wave take kTeamTile consecutive points,
+// test their certificates (the point, the tested state groups and the six stored positions in one batch of loads), and serve the
+// points that fail four at a time, SIXTEEN lanes per query, five round trips per query whatever its ball:
+//   1 the six old neighbours gathered by six lanes (the warm bound: the largest of their distances, inflated like lin_search6's);
+//   2 the occupied (y,z) rows of the query's ball: a ball of at most sixteen rows lists them all, a larger one reads the row
+//     occupancy words of its z layers (one layer per lane) and lists the rows whose bit is set;
+//   3 the rows cut to the ball by one lane each (ball_row: two table loads per row, all in flight together);
+//   4 the candidates of all rows dealt to the sixteen lanes (at most kTeamCand each, requested together), the ones inside the bound
+//     compacted into the group's list with their coordinates;
+//   the list ranked by the exact key (distance bits, original index): the first six ranks are the neighbours in canonical order, the
+//     seventh distance the exact lower bound SET6 certificates want; certificate and plane fit (on the coordinates the list holds: no
+//     second gather) by the group's first lane;
+//   5 the state written exactly as k_lin's levels 1 and 2 write it.
+// A frame of 8 k points is ~2000 waves spread over the device.  k_lin then finds the certificates fresh and runs the stored-plane
+// path.  A query the team cannot serve (more layers, rows, candidates or points inside its bound than the lists hold) is left alone:
+// k_lin searches it itself.  Results never depend on who searched (history independence).
 #if !defined(DCREG_TEAM_TILE)
-#define DCREG_TEAM_TILE 8
+#define DCREG_TEAM_TILE 4
 #endif
 constexpr int kTeamTile = DCREG_TEAM_TILE;        // points per block (one wave)
 constexpr int kTeamG = 16;                        // lanes per query
@@ -734,18 +738,29 @@ constexpr int kTeamCand = 8;                      // candidates per lane
 constexpr int kTeamList = 64;                     // points inside the bound the ranking handles
 static_assert(kTeamTile >= 4 && kTeamTile <= 64, "one wave tests the tile; k_lin reads at most 64 count entries per lane pass");
 struct TeamPassLds {
-    uint32_t q_i[kTeamTile]; float q_x[kTeamTile], q_y[kTeamTile], q_z[kTeamTile]; uint32_t q_kind[kTeamTile];
-    uint32_t run_s[4][kTeamRows], run_len[4][kTeamRows];
-    uint32_t lane_pos[kTeamCand][kWave];
+    uint32_t q_i[kTeamTile], q_kind[kTeamTile], q_cert[kTeamTile], q_pos[kTeamTile][6];
+    float q_x[kTeamTile], q_y[kTeamTile], q_z[kTeamTile], q_q0[kTeamTile][3];
+    int16_t row_y[4][kTeamRows], row_z[4][kTeamRows];            // offsets from the query's cell
+    uint32_t run_s[4][kTeamRows], run_len[4][kTeamRows];         // (run_len: lengths, then their exclusive prefix sums)
     uint32_t c_d2[4][kTeamList], c_idx[4][kTeamList], c_pos[4][kTeamList];
-    uint32_t o_d2[4][8], o_pos[4][8];
+    float c_x[4][kTeamList], c_y[4][kTeamList], c_z[4][kTeamList];
+    uint32_t o_d2[4][8], o_pos[4][8], o_idx[4][8];
+    float o_x[4][8], o_y[4][8], o_z[4][8];
 };
 template <bool FAST>
 static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
                                                              const PoseArg *__restrict__ poses, LinArgs a, uint32_t *__restrict__ counts,
-                                                             const uint32_t *__restrict__ abort_flag) {
+                                                             const uint32_t *__restrict__ abort_flag, unsigned long long *__restrict__ stamps) {
     if (abort_flag && *abort_flag != 0u) return;
     __shared__ TeamPassLds L;
+    // (timing probe, option "team_stamps": lane 0 stores the shader clock at the phase boundaries of the block's first round - eight words per block)
+    auto stamp = [&](int k) {
+        if (stamps) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + k] = __builtin_readcyclecounter();
+        }
+    };
+    stamp(0);
     const int lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
     PoseArg P;
     if (poses) P = poses[0]; else P = pose1;
@@ -756,18 +771,19 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
     dbl2 *const SV1 = reinterpret_cast<dbl2 *>(sbase + kStV1 * ss), *const SV2 = reinterpret_cast<dbl2 *>(sbase + kStV2 * ss);
     uint32_t *const SW3 = sbase + kStW3 * ss;
     uint2 *const SY = reinterpret_cast<uint2 *>(sbase + kStY * ss);
-    const uint32_t *const SXw = sbase + kStX * ss, *const SYw = sbase + kStY * ss;
-    // ---- the tests: one point per lane
+    // ---- the tests: one point per lane; the stored positions come with the same batch of loads (they are what a failing point needs next)
     uint32_t n_q;
     {
         const uint32_t i = blockIdx.x * (uint32_t)kTeamTile + (uint32_t)lane;
         const bool have = lane < kTeamTile && i < n_src;
         uint32_t kind = 0;
         float qx = 0.f, qy = 0.f, qz = 0.f;
+        uint4 v0 = make_uint4(0u, 0u, 0u, 0u), x = make_uint4(kNoIdx, kNoIdx, kNoIdx, kNoIdx);
+        uint2 y = make_uint2(kNoIdx, kNoIdx);
+        uint32_t w3 = 0u;
         if (have) {
             const float4 s4 = src[i];
-            const uint4 v0 = SV0[i];
-            const uint32_t w3 = SW3[i];
+            v0 = SV0[i]; w3 = SW3[i]; x = SX[i]; y = SY[i];
             body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
             const float q0x = __uint_as_float(v0.z), q0y = __uint_as_float(v0.w), q0z = __uint_as_float(w3);
             const bool need = !cert_holds(v0.x, q0x, q0y, q0z, qx, qy, qz);
@@ -776,13 +792,25 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(kind != 0u);
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (kind != 0u) { L.q_i[slot] = i; L.q_x[slot] = qx; L.q_y[slot] = qy; L.q_z[slot] = qz; L.q_kind[slot] = kind; }
+        if (kind != 0u) {
+            L.q_i[slot] = i; L.q_x[slot] = qx; L.q_y[slot] = qy; L.q_z[slot] = qz; L.q_kind[slot] = kind; L.q_cert[slot] = v0.x;
+            L.q_q0[slot][0] = __uint_as_float(v0.z); L.q_q0[slot][1] = __uint_as_float(v0.w); L.q_q0[slot][2] = __uint_as_float(w3);
+            L.q_pos[slot][0] = x.x; L.q_pos[slot][1] = x.y; L.q_pos[slot][2] = x.z; L.q_pos[slot][3] = x.w; L.q_pos[slot][4] = y.x; L.q_pos[slot][5] = y.y;
+        }
         n_q = (uint32_t)__builtin_popcountll(m);
     }
     __builtin_amdgcn_wave_barrier();
+    stamp(1);
     uint32_t served_s = 0, served_r = 0;                     // (in the first lane of every group: what it served)
     const unsigned long long gmask = 0xFFFFull << (16 * grp);
-    auto gballot = [&](bool x) -> uint32_t { return (uint32_t)((__builtin_amdgcn_ballot_w64(x) & gmask) >> (16 * grp)); };
+    auto gballot = [&](bool b) -> uint32_t { return (uint32_t)((__builtin_amdgcn_ballot_w64(b) & gmask) >> (16 * grp)); };
+    auto gscan_excl = [&](uint32_t v, uint32_t &total) -> uint32_t {        // exclusive prefix sum over the sixteen lanes of the group
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < kTeamG; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, kTeamG); if (gl >= d) inc += o; }
+        total = (uint32_t)__shfl((int)inc, kTeamG - 1, kTeamG);
+        return inc - v;
+    };
     for (uint32_t r0 = 0; r0 < n_q; r0 += 4u) {
         const uint32_t e = r0 + (uint32_t)grp;
         const bool act = e < n_q;
@@ -790,39 +818,103 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
         const float qx = act ? L.q_x[e] : 0.f, qy = act ? L.q_y[e] : 0.f, qz = act ? L.q_z[e] : 0.f;
         const uint32_t kind = act ? L.q_kind[e] : 0u;
         bool srch = kind == 1u;                               // uniform over the group
+        uint32_t why = 0;                                     // (probe: why a search was left to k_lin)
         uint32_t n_in = 0;                                    // points inside the bound (uniform over the group)
         float bound = a.radius_sq_f;
-        if (srch) {
-            // ---- the bound: the six old neighbours, one per lane
+        // ---- 1: the six stored neighbours, one per lane: the warm bound of a search, the points of a refit
+        {
             float d2 = 0.f;
             bool okp = gl >= 6;
-            if (gl < 6 && a.warm) {
-                const uint32_t p = gl < 4 ? SXw[(size_t)i * 4 + gl] : SYw[(size_t)i * 2 + (gl - 4)];
-                if (p != kNoIdx) { const float4 c = g.pts[p]; d2 = dist2_nofma(qx, qy, qz, c); okp = true; }
+            if (gl < 6 && kind != 0u && (a.warm || kind == 2u)) {
+                const uint32_t p = L.q_pos[e][gl];
+                if (p != kNoIdx) {
+                    const float4 c = g.pts[p];
+                    d2 = dist2_nofma(qx, qy, qz, c); okp = true;
+                    if (kind == 2u) { L.o_pos[grp][gl] = p; L.o_idx[grp][gl] = __float_as_uint(c.w); L.o_x[grp][gl] = c.x; L.o_y[grp][gl] = c.y; L.o_z[grp][gl] = c.z; }
+                }
             }
             const bool have6 = gballot(okp) == 0xFFFFu;
 #pragma unroll
             for (int m = 1; m < kTeamG; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m, kTeamG));
-            if (have6) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(d2) + 1u), 1.17549435e-38f));      // inclusive, as warm_bound6
-            const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
-            bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
+            if (srch) {
+                if (have6) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(d2) + 1u), 1.17549435e-38f));      // inclusive, as warm_bound6
+                const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;
+                bound = fminf(fmaxf(bound, fminf(bound * infl, cap)), a.radius_sq_f);
+            }
         }
-        // ---- the rows of the ball
-        uint32_t n_runs = 0, n_cand = 0;                      // (uniform over the group)
+        if (r0 == 0u) stamp(2);
+        // ---- 2: the rows of the ball
+        uint32_t n_rows = 0;                                  // (uniform over the group)
+        BallCells bc{};
         if (srch) {
             const double fx = ((double)qx - g.ox) * g.inv_h, fy = ((double)qy - g.oy) * g.inv_h, fz = ((double)qz - g.oz) * g.inv_h;
             const double lim = (double)a.max_ring + 1.0;
             const bool reach = !(fx < -lim || fy < -lim || fz < -lim || fx > g.nx + lim || fy > g.ny + lim || fz > g.nz + lim);
-            const BallCells bc = ball_cells(g, reach ? qx : (float)g.ox, reach ? qy : (float)g.oy, reach ? qz : (float)g.oz, bound);
+            bc = ball_cells(g, reach ? qx : (float)g.ox, reach ? qy : (float)g.oy, reach ? qz : (float)g.oz, bound);
             const int ny_r = bc.yhi - bc.ylo + 1, nz_r = bc.zhi - bc.zlo + 1;
-            const int n_rows = reach ? ny_r * nz_r : 0;
-            if (n_rows > kTeamRows) srch = false;            // a ball of more rows than the group handles: left to k_lin
+            if (!reach) {
+                n_rows = 0;                                   // beyond the grid: nothing inside the bound
+            } else if (ny_r * nz_r <= kTeamG) {               // a small ball: every row of its bounding square
+                n_rows = (uint32_t)(ny_r * nz_r);
+                if (gl < (int)n_rows) { L.row_y[grp][gl] = (int16_t)(bc.ylo + gl % ny_r); L.row_z[grp][gl] = (int16_t)(bc.zlo + gl / ny_r); }
+            } else if (nz_r > kTeamG || !g.ymask) {
+                srch = false; why = 1;                        // more layers than lanes: left to k_lin
+            } else {                                          // the occupied rows of every z layer of the ball, one layer per lane
+                uint32_t m0 = 0u, m1 = 0u;
+                int y0 = 0, y1 = -1;
+                bool wide = false;
+                const int z = bc.cz + bc.zlo + gl;
+                if (gl < nz_r && z >= 0 && z < g.nz) {
+                    const float hf = (float)g.h;
+                    const int dz = bc.zlo + gl;
+                    const float gz = dz < 0 ? ((float)(-dz - 1) + bc.frz) * hf : (dz > 0 ? ((float)dz - bc.frz) * hf : 0.f);
+                    const float rem = bound - gz * gz * 0.99999f;
+                    if (!(rem < 0.f)) {
+                        const float rc = fminf(sqrt_approx(rem) * 1.00001f * (float)g.inv_h + 1e-4f, 1.0e6f);
+                        const int cap = 1 << 24;
+                        const int ylo = -min(cap, (int)floorf(rc + 1.f - bc.fry)), yhi = min(cap, (int)floorf(rc + bc.fry));
+                        const int xlo = -min(cap, (int)floorf(rc + 1.f - bc.frx)), xhi = min(cap, (int)floorf(rc + bc.frx));
+                        y0 = max(bc.cy + ylo, 0); y1 = min(bc.cy + yhi, g.ny - 1);
+                        const int b0 = max(bc.cx + xlo, 0) >> 4, b1 = min(bc.cx + xhi, g.nx - 1) >> 4;
+                        if (y1 >= y0 && b1 >= b0) {
+                            wide = ((y1 >> 5) - (y0 >> 5)) > 1 || b1 - b0 > 1;
+                            if (!wide) {
+                                const int yw0 = y0 >> 5, yw1 = y1 >> 5, bb = min(b0 + 1, b1);
+                                const uint32_t *mw = g.ymask + ((int64_t)z * g.nxb + b0) * g.nyw, *mv = g.ymask + ((int64_t)z * g.nxb + bb) * g.nyw;
+                                const uint32_t a0_ = mw[yw0], a1_ = mv[yw0], c0_ = mw[yw1], c1_ = mv[yw1];
+                                m0 = a0_ | a1_; m1 = yw1 > yw0 ? (c0_ | c1_) : 0u;
+                                const int base0 = yw0 << 5;
+                                {   const int lo = max(y0 - base0, 0), hi = min(y1 - base0, 31);
+                                    m0 &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo); }
+                                if (yw1 > yw0) { const int lo = 0, hi = min(y1 - (base0 + 32), 31); m1 &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo); }
+                            }
+                        } else { y1 = y0 - 1; }
+                    }
+                }
+                if (gballot(wide) != 0u) { srch = false; why = 2; }       // a layer spanning more words or x blocks than one lane reads: left to k_lin
+                uint32_t total = 0;
+                const uint32_t mine = (uint32_t)__builtin_popcount(m0) + (uint32_t)__builtin_popcount(m1);
+                uint32_t slot = gscan_excl(srch ? mine : 0u, total);
+                if (total > (uint32_t)kTeamRows) { srch = false; why = 3; }           // more occupied rows than the group handles: left to k_lin
+                if (srch) {
+                    const int base0 = (y0 >> 5) << 5, dzl = bc.zlo + gl;
+                    while (m0) { const int bit = __builtin_ctz(m0); m0 &= m0 - 1u; L.row_y[grp][slot] = (int16_t)(base0 + bit - bc.cy); L.row_z[grp][slot] = (int16_t)dzl; ++slot; }
+                    while (m1) { const int bit = __builtin_ctz(m1); m1 &= m1 - 1u; L.row_y[grp][slot] = (int16_t)(base0 + 32 + bit - bc.cy); L.row_z[grp][slot] = (int16_t)dzl; ++slot; }
+                    n_rows = total;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (r0 == 0u) stamp(3);
+        // ---- 3: the rows cut to the ball, up to four per lane, their table loads in flight together
+        uint32_t n_runs = 0, n_cand = 0;                      // (uniform over the group)
+        if (srch) {
             uint32_t rs[kTeamRows / kTeamG], re[kTeamRows / kTeamG];
 #pragma unroll
             for (int t = 0; t < kTeamRows / kTeamG; ++t) {
-                const int k = gl + kTeamG * t;
+                const uint32_t k = (uint32_t)(gl + kTeamG * t);
                 rs[t] = 0u; re[t] = 0u;
-                if (srch && k < n_rows) ball_row(g, bc, bound, bc.ylo + k % ny_r, bc.zlo + k / ny_r, rs[t], re[t]);
+                if (k < n_rows) ball_row(g, bc, bound, (int)L.row_y[grp][k], (int)L.row_z[grp][k], rs[t], re[t]);
             }
 #pragma unroll
             for (int t = 0; t < kTeamRows / kTeamG; ++t) {
@@ -834,63 +926,85 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- the candidates of all runs, dealt to the sixteen lanes: flat index f = gl + 16 j
-        uint32_t nc = 0;                                      // this lane's candidates
+        if (r0 == 0u) stamp(4);
+        // ---- 4: the candidates of all runs, dealt to the sixteen lanes kTeamCand at a time (flat index f = base + gl + 16 j): a chunk's
+        // loads are requested together, the points inside the bound are compacted into the group's list with their coordinates
         if (srch) {
             uint32_t off = 0;
-            for (uint32_t k = 0; k < n_runs; ++k) {
-                const uint32_t s_ = L.run_s[grp][k], len = L.run_len[grp][k];
-                for (uint32_t f = off + (((uint32_t)gl - off) & (uint32_t)(kTeamG - 1)); f < off + len; f += (uint32_t)kTeamG) {
-                    if (nc < (uint32_t)kTeamCand) L.lane_pos[nc][lane] = s_ + (f - off);
-                    ++nc;
-                }
-                off += len;
-            }
+            for (uint32_t k = 0; k < n_runs; ++k) { const uint32_t len = L.run_len[grp][k]; L.run_len[grp][k] = off; off += len; }     // lengths -> exclusive offsets
             n_cand = off;
-            if (n_cand > (uint32_t)(kTeamCand * kTeamG)) srch = false;      // more candidates than the lanes take: left to k_lin
         }
-        if (srch) {
-            float4 c[kTeamCand];
-            uint32_t cp[kTeamCand];
+        // (a list that overflows - a loose bound in a dense part of the map - is ranked as it stands: the seventh smallest distance of
+        //  ANY 64 real points bounds the sixth neighbour's from above, so the candidates are taken once more against that bound)
+        bool again = srch;                                    // this group (re)takes its candidates in the coming attempt
+        for (int attempt = 0; attempt < 2 && wave_any(again); ++attempt) {
+            if (again) n_in = 0;
+            uint32_t k = 0;                                   // the run this lane's next flat index lies in (it only moves forward)
+            for (uint32_t base = 0; wave_any(again && base < n_cand); base += (uint32_t)(kTeamCand * kTeamG)) {
+                const bool on = again && base < n_cand;
+                float4 c[kTeamCand];
+                uint32_t cp[kTeamCand];
 #pragma unroll
-            for (int j = 0; j < kTeamCand; ++j) {
-                cp[j] = (uint32_t)j < nc ? L.lane_pos[j][lane] : 0u;
-                c[j] = g.pts[cp[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < kTeamCand; ++j) {
-                const float d2 = dist2_nofma(qx, qy, qz, c[j]);
-                const bool pass = (uint32_t)j < nc && d2 < bound;
-                const uint32_t bits = gballot(pass);
-                const uint32_t slot = n_in + (uint32_t)__builtin_popcount(bits & ((1u << gl) - 1u));
-                if (pass && slot < (uint32_t)kTeamList) { L.c_d2[grp][slot] = __float_as_uint(d2); L.c_idx[grp][slot] = __float_as_uint(c[j].w); L.c_pos[grp][slot] = cp[j]; }
-                n_in += (uint32_t)__builtin_popcount(bits);
-            }
-            if (n_in > (uint32_t)kTeamList) srch = false;    // more points inside the bound than the ranking handles: left to k_lin
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- rank by (distance bits, original index): a total order; the first seven ranks go to the out list
-        if (srch) {
-#pragma unroll
-            for (int m = 0; m < kTeamList / kTeamG; ++m) {
-                const uint32_t me = (uint32_t)(gl + kTeamG * m);
-                if (me < n_in) {
-                    const unsigned long long key = ((unsigned long long)L.c_d2[grp][me] << 32) | L.c_idx[grp][me];
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < n_in; ++j) {
-                        const unsigned long long kj = ((unsigned long long)L.c_d2[grp][j] << 32) | L.c_idx[grp][j];
-                        rank += kj < key ? 1u : 0u;
+                for (int j = 0; j < kTeamCand; ++j) {
+                    const uint32_t f = base + (uint32_t)(gl + kTeamG * j);
+                    cp[j] = kNoIdx;
+                    if (on && f < n_cand) {
+                        while (k + 1u < n_runs && f >= L.run_len[grp][k + 1u]) ++k;
+                        cp[j] = L.run_s[grp][k] + (f - L.run_len[grp][k]);
                     }
-                    if (rank < 7u) { L.o_d2[grp][rank] = L.c_d2[grp][me]; L.o_pos[grp][rank] = L.c_pos[grp][me]; }
+                    c[j] = g.pts[cp[j] != kNoIdx ? cp[j] : 0u];
+                }
+#pragma unroll
+                for (int j = 0; j < kTeamCand; ++j) {
+                    const float d2 = dist2_nofma(qx, qy, qz, c[j]);
+                    const bool pass = cp[j] != kNoIdx && d2 < bound;
+                    const uint32_t bits = gballot(pass);
+                    const uint32_t slot = n_in + (uint32_t)__builtin_popcount(bits & ((1u << gl) - 1u));
+                    if (pass && slot < (uint32_t)kTeamList) {
+                        L.c_d2[grp][slot] = __float_as_uint(d2); L.c_idx[grp][slot] = __float_as_uint(c[j].w); L.c_pos[grp][slot] = cp[j];
+                        L.c_x[grp][slot] = c[j].x; L.c_y[grp][slot] = c[j].y; L.c_z[grp][slot] = c[j].z;
+                    }
+                    if (on) n_in += (uint32_t)__builtin_popcount(bits);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            if (r0 == 0u && attempt == 0) stamp(5);
+            // ---- rank by (distance bits, original index): a total order; the first seven ranks go to the out list
+            if (again) {
+                const uint32_t n_l = min(n_in, (uint32_t)kTeamList);
+#pragma unroll
+                for (int m = 0; m < kTeamList / kTeamG; ++m) {
+                    const uint32_t me = (uint32_t)(gl + kTeamG * m);
+                    if (me < n_l) {
+                        const unsigned long long key = ((unsigned long long)L.c_d2[grp][me] << 32) | L.c_idx[grp][me];
+                        uint32_t rank = 0;
+                        for (uint32_t j = 0; j < n_l; ++j) {
+                            const unsigned long long kj = ((unsigned long long)L.c_d2[grp][j] << 32) | L.c_idx[grp][j];
+                            rank += kj < key ? 1u : 0u;
+                        }
+                        if (rank < 7u) {
+                            L.o_d2[grp][rank] = L.c_d2[grp][me]; L.o_pos[grp][rank] = L.c_pos[grp][me]; L.o_idx[grp][rank] = L.c_idx[grp][me];
+                            L.o_x[grp][rank] = L.c_x[grp][me]; L.o_y[grp][rank] = L.c_y[grp][me]; L.o_z[grp][rank] = L.c_z[grp][me];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const bool over = again && n_in > (uint32_t)kTeamList;
+            if (over && attempt == 1) { srch = false; why = 4; }          // still more than a list's worth (ties): left to k_lin
+            if (over && attempt == 0) bound = fmaxf(__uint_as_float(L.o_d2[grp][6] + 1u), 1.17549435e-38f);     // inclusive: the next float up
+            again = over && attempt == 0;
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
+        if (r0 == 0u) stamp(6);
         // ---- certificate, fit, state: the group's first lane
         const bool lead = gl == 0 && ((kind == 1u && srch) || kind == 2u);
-        uint32_t pos6[6], cert = kCertSearch;
+        uint32_t cert = kCertSearch;
+        float4 pt[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) pos6[j] = kNoIdx;
+        for (int j = 0; j < 6; ++j) pt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool six_known = false;                               // the sixth point exists
         if (lead && kind == 1u) {
             Set6 out;
 #pragma unroll
@@ -898,31 +1012,29 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
                 const bool got = (uint32_t)j < n_in;
                 out.pos[j] = got ? L.o_pos[grp][j] : kNoIdx;
                 out.d2[j] = got ? __uint_as_float(L.o_d2[grp][j]) : bound;
+                if (got) pt[j] = make_float4(L.o_x[grp][j], L.o_y[grp][j], L.o_z[grp][j], __uint_as_float(L.o_idx[grp][j]));
             }
             out.lb7 = n_in > 6u ? fminf(__uint_as_float(L.o_d2[grp][6]), bound) : bound;
             out.n_eval = 0; out.n_shell = 1;
             cert = make_cert(out, a);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) pos6[j] = out.pos[j];
-            SX[i] = make_uint4(pos6[0], pos6[1], pos6[2], pos6[3]);
-            SY[i] = make_uint2(pos6[4], pos6[5]);
+            six_known = out.pos[5] != kNoIdx;
+            SX[i] = make_uint4(out.pos[0], out.pos[1], out.pos[2], out.pos[3]);
+            SY[i] = make_uint2(out.pos[4], out.pos[5]);
         } else if (lead) {
-            const uint4 x = SX[i];
-            const uint2 y = SY[i];
-            pos6[0] = x.x; pos6[1] = x.y; pos6[2] = x.z; pos6[3] = x.w; pos6[4] = y.x; pos6[5] = y.y;
-            const uint4 o0 = SV0[i];
-            const uint32_t o1 = SW3[i];
-            cert = cert_rebased(o0.x, __uint_as_float(o0.z), __uint_as_float(o0.w), __uint_as_float(o1), qx, qy, qz);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (L.q_pos[e][j] != kNoIdx) pt[j] = make_float4(L.o_x[grp][j], L.o_y[grp][j], L.o_z[grp][j], __uint_as_float(L.o_idx[grp][j]));
+            six_known = L.q_pos[e][5] != kNoIdx;
+            cert = cert_rebased(L.q_cert[e], L.q_q0[e][0], L.q_q0[e][1], L.q_q0[e][2], qx, qy, qz);
         }
         const bool set = lead && !cert_is_out(cert);
         if (wave_any(set)) {
-            const bool use6 = set && cert_is_set6(cert);
+            const bool use6 = set && cert_is_set6(cert) && six_known;
             const bool six = wave_any(use6);
-            if (!use6) pos6[5] = kNoIdx;
             if (set) {
                 KnnResult<5> nn;
                 Fit fit;
-                (void)fit_from_set<FAST>(g, a, qx, qy, qz, pos6, six, nn, fit, false);
+                (void)fit_from_points<FAST>(a, qx, qy, qz, pt, use6, six, nn, fit, false);
                 SV0[i] = make_uint4(cert, fit.word, __float_as_uint(qx), __float_as_uint(qy));
                 SV1[i] = dbl2{fit.plane[0], fit.plane[1]};
                 SV2[i] = dbl2{fit.plane[2], fit.plane[3]};
@@ -934,7 +1046,14 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
             SW3[i] = __float_as_uint(qz);
         }
         if (lead) { served_s += kind == 1u ? 1u : 0u; served_r += kind == 2u ? 1u : 0u; }
+        if (stamps && gl == 0 && kind != 0u) {      // probe: the outcomes, counted behind the blocks' stamp words
+            unsigned long long *hist = stamps + (size_t)gridDim.x * 8;
+            const uint32_t slack = __float_as_uint(__uint_as_float(cert & 0x7FFFFFFEu));
+            const int code = kind == 2u ? 7 : (!srch ? (int)why : (cert_is_out(cert) ? 5 : (slack == 0u ? 6 : 0)));
+            atomicAdd(hist + code, 1ull);
+        }
         __builtin_amdgcn_wave_barrier();
+        if (r0 == 0u) stamp(7);
     }
     // what the block served (the points it left to k_lin are counted there)
 #pragma unroll

@@ -1683,15 +1683,24 @@ struct Fit { double plane[4]; uint32_t word; };
 // search at this pose -, radius gate, plane fit, neighbour-only gates, and the fit word that says how far this all stays valid.
 // `six` is uniform over the wave; `nn` receives the ordered five (debug dumps).  Returns 0 (radius gate failed: no plane), else 1 with
 // fit.word's gate bits set.
+// (fit_from_points: the same for a caller that holds the points themselves - pt[0..4], and pt[5] where use6 -: kernels.hpp k_advance_team)
+template <bool FASTMATH>
+DCREG_DEVFN uint8_t fit_from_points(const LinArgs &a, float qx, float qy, float qz, float4 (&pt)[6], bool use6, bool six, KnnResult<5> &nn, Fit &fit,
+                                    bool presorted);
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t fit_from_set(const GridDev &g, const LinArgs &a, float qx, float qy, float qz, const uint32_t (&pos)[6], bool six,
                                  KnnResult<5> &nn, Fit &fit, bool presorted = false) {
-    float d2[6];
     float4 pt[6];
     const bool use6 = six && pos[5] != kNoIdx;
 #pragma unroll
     for (int j = 0; j < 5; ++j) pt[j] = g.pts[pos[j]];
     pt[5] = use6 ? g.pts[pos[5]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return fit_from_points<FASTMATH>(a, qx, qy, qz, pt, use6, six, nn, fit, presorted);
+}
+template <bool FASTMATH>
+DCREG_DEVFN uint8_t fit_from_points(const LinArgs &a, float qx, float qy, float qz, float4 (&pt)[6], bool use6, bool six, KnnResult<5> &nn, Fit &fit,
+                                    bool presorted) {
+    float d2[6];
 #pragma unroll
     for (int j = 0; j < 5; ++j) d2[j] = dist2_nofma(qx, qy, qz, pt[j]);
     d2[5] = use6 ? dist2_nofma(qx, qy, qz, pt[5]) : __builtin_inff();            // a lane with five sorts its padding last

@@ -62,6 +62,13 @@ int dcreg_launch_series(dcreg_ctx *, double *ms, int64_t *searched, int64_t *ref
  * Returns the number of entries logged. */
 int dcreg_launch_series_passes(dcreg_ctx *, uint8_t *advanced, int64_t cap);
 
+/* Timing probe of the small-frame advance pass (option "team_stamps" = 1): of the LAST launch that ran the pass, per block (one wave,
+ * kTeamTile points) eight shader-clock words - start, tests done, old neighbours gathered, rows listed, rows cut (table loads), candidates
+ * taken, ranked, state written (first round of the block; 0 where a block had nothing to do); one more row of eight outcome counts
+ * follows the blocks.  Copies at most cap_blocks x 8 words;
+ * returns the number of blocks of that launch.  Waits for the stream. */
+int dcreg_team_pass_stamps(dcreg_ctx *, uint64_t *out, int64_t cap_blocks);
+
 /* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 1 = the full
  * eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis); the record must equal dcreg_analyze_degeneracy's */
 int dcreg_analyze_degeneracy_two_part(const double H[36], int detection, int handling, const dcreg_config *, dcreg_analysis *, int *owed);
