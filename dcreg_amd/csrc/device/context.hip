@@ -667,24 +667,17 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     // device holds at once (below that a launch lasts as long as one search whether its searches are dense or not) in a launch expected
     // to search a few per cent of its points - expected = what the last completed launch reported (with the engines' pipeline that is
     // the launch two back).  Scheduling only: the sums are the same with and without the pass.
-    bool adv = false;
+    bool adv = false, team = false;
     a.adv_counts = nullptr;
-    if (n_poses == 1 && !state_ids && uses_state && one.fresh == 0u && a.use_cert && !dbg_host && a.count_scale != 0.0 && c->opt_advance != 0) {
-        if (c->opt_advance >= 2) adv = true;
-        else if (nbx >= (uint32_t)c->opt_advance_min_blocks && c->last_searched >= 0 && c->last_points == n) {
-            const double f = (double)c->last_searched / (double)n;
-            adv = f >= c->opt_advance_lo && f <= c->opt_advance_hi;
-        }
-    }
-    if (n_poses == 1 && !state_ids && uses_state && one.fresh != 0u) { c->last_searched = n; c->last_points = n; }     // (a fresh state: every point is searched)
-    // ... or its small-frame form (k_advance_team: sixteen lanes per query, one wave per kTeamTile points): a frame of a few thousand
-    // points, whose query blocks leave most of the device idle, in a launch expected to search something but not more than the teams
-    // can take without becoming the bottleneck themselves
-    bool team = false;
-    if (n_poses == 1 && !state_ids && uses_state && one.fresh == 0u && a.use_cert && !dbg_host && a.count_scale != 0.0 && a.warm && c->opt_team_pass != 0) {
-        if (c->opt_team_pass >= 2) team = true;
-        else if (n <= (int64_t)c->opt_team_pass_max_points && c->last_points == n)
-            team = c->last_searched >= (int64_t)c->opt_team_pass_min_searched && c->last_searched <= (int64_t)c->opt_team_pass_max_searched;
+    if (n_poses == 1 && !state_ids && uses_state && one.fresh == 0u && a.use_cert && !dbg_host && a.count_scale != 0.0 && a.warm) {
+        // what the launch is expected to search: what the last completed launch reported (with the engines' pipeline: the launch two back)
+        const bool known = c->last_searched >= 0 && c->last_points == n;
+        const double f = known ? (double)c->last_searched / (double)n : -1.0;
+        adv = c->opt_advance >= 2 || (c->opt_advance == 1 && nbx >= (uint32_t)c->opt_advance_min_blocks && known && f >= c->opt_advance_lo && f <= c->opt_advance_hi);
+        // ... its small-frame form (k_advance_team: sixteen lanes per query, one wave per kTeamTile points): a frame of a few thousand
+        // points, whose query blocks leave most of the device idle, in a launch expected to search most of its points (the pass costs
+        // ~12 us whatever it finds to do; k_lin alone gets cheaper as its searching waves thin out, so below half it wins again)
+        team = c->opt_team_pass >= 2 || (c->opt_team_pass == 1 && n <= (int64_t)c->opt_team_pass_max_points && known && f >= c->opt_team_pass_min_frac);
     }
     if (team) adv = false;
     const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
@@ -1124,8 +1117,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "team_stamps") c->opt_team_stamps = v != 0.0;   // timing probe of the small-frame pass (dcreg_team_pass_stamps)
     else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "team_pass_max_points") c->opt_team_pass_max_points = v;
-    else if (k == "team_pass_min_searched") c->opt_team_pass_min_searched = v;
-    else if (k == "team_pass_max_searched") c->opt_team_pass_max_searched = v;
+    else if (k == "team_pass_min_frac") c->opt_team_pass_min_frac = v;
     else if (k == "advance_lo") c->opt_advance_lo = v;           // ... rule: the last launch searched between these fractions of its points
     else if (k == "advance_hi") c->opt_advance_hi = v;
     else if (k == "advance_min_blocks") c->opt_advance_min_blocks = (int)v;   // ... and the cloud has at least this many query blocks

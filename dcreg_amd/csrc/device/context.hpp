@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <vector>
 
@@ -44,7 +45,7 @@ struct dcreg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;     // pose uploads of batched launches (linearize_begin)
-    bool opt_pose_copy_stream = true;
+    bool opt_pose_copy_stream = false;     // (measured: C5 1.64 M it/s on the compute stream, 1.56 M on the copy stream - profiles/r05_ablation.md)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     char err[512] = {0};
 
@@ -173,12 +174,12 @@ struct dcreg_ctx {
     double opt_far_loose = 1.5;    // search.hpp lin_search6: when a start bound is loose enough to be worth a probe (cells)
     // the advance pass (kernels.hpp k_advance): 0 never, 1 by the rule below, 2 whenever a launch can take it (tests)
     int opt_advance = 1;
-    double opt_advance_lo = 0.01, opt_advance_hi = 0.45;      // ... the last completed launch searched between these fractions of its points
+    double opt_advance_lo = 0.003, opt_advance_hi = 0.30;     // ... the last completed launch searched between these fractions of its points
     int opt_advance_min_blocks = 2048;                        // ... and the cloud has at least this many query blocks (twice what the device holds)
     // its small-frame form (k_advance_team): same switch values; rule: at most max_points source points, the last completed launch
-    // searched between min_searched and max_searched points
+    // searched at least min_frac of them
     int opt_team_pass = 1;
-    double opt_team_pass_max_points = 131072.0, opt_team_pass_min_searched = 32.0, opt_team_pass_max_searched = 16384.0;
+    double opt_team_pass_max_points = 16384.0, opt_team_pass_min_frac = 0.5;
     bool opt_team_stamps = false;
     unsigned long long *d_team_stamps = nullptr; size_t team_stamps_cap = 0; uint32_t team_stamps_n = 0;
     uint32_t *d_adv_counts = nullptr; size_t adv_counts_cap = 0;

@@ -641,6 +641,8 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_advance(con
     __syncthreads();
     const uint32_t n_s = n_list[0], n_r = n_list[1];
     if (threadIdx.x == 0 && counts) { counts[2 * blockIdx.x] = n_s; counts[2 * blockIdx.x + 1] = n_r; }
+    if (threadIdx.x == 0 && a.search_count && n_s)            // (option "count_searches": the pass's searches count like k_lin's)
+        atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)n_s);
     // ---- the list, 64 entries per wave at a time: the searches (waves in turn), then the refit-only points
     const uint32_t c_s = (n_s + 63u) >> 6, c_r = (n_r + 63u) >> 6;
     auto chunk = [&](auto searching_c, uint32_t e, bool act) {
@@ -1059,6 +1061,8 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
 #pragma unroll
     for (int m = 16; m < 64; m <<= 1) { served_s += (uint32_t)__shfl_xor((int)served_s, m); served_r += (uint32_t)__shfl_xor((int)served_r, m); }
     if (lane == 0 && counts) { counts[2 * blockIdx.x] = served_s; counts[2 * blockIdx.x + 1] = served_r; }
+    if (lane == 0 && a.search_count && served_s)              // (option "count_searches": the pass's searches count like k_lin's)
+        atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)served_s);
 }
 
 // Batched launches: one block per pose sums that pose's block partials with the SAME association order as the fused

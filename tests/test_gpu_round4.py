@@ -91,6 +91,7 @@ def test_team_search_of_sparse_waves_is_invisible(scene):
         for k, v in opts.items():
             c.set_option(k, v)
         c.set_option("count_searches", 1); c.set_option("record_launches", 1)
+        c.set_option("team_pass", 0); c.set_option("advance", 0)        # (this test is about the searches INSIDE the linearisation kernel)
         c.set_target(tgt, radius); c.set_source(src)
         ctxs[name] = c
     T = np.eye(4)

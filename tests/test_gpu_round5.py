@@ -111,8 +111,8 @@ def test_advance_pass_in_whole_runs_and_behind_the_gate():
 
 def test_small_frame_registration_with_the_team_pass():
     """The reference's own workload (icp_test_runner.cpp:442-461): an 8 k-point frame registered against a 200 k-point map, from host
-    buffers, to convergence.  With the small-frame pass by the host's rule (the default), forced and off: iteration for iteration the
-    same H, g, counts and pose, bit for bit; the rule picks the pass for the launches behind the first."""
+    buffers, to convergence.  With the small-frame pass by the host's rule (the default), forced and off: iteration for
+    iteration the same H, g, counts and pose, bit for bit."""
     tgt, src = h.scene_parkinglot()
     gt, T0 = h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
     cfg = api.default_config(search_radius=0.5, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=1e-5,
@@ -140,7 +140,8 @@ def test_small_frame_registration_with_the_team_pass():
                 assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]), (name, rep, it)
     assert picked["off"].sum() == 0
     n_it = len(logs["off"][0])
-    assert (picked["rule"] == 2).sum() >= 2 * (n_it - 3), picked["rule"]
+    assert (picked["forced"] == 2).sum() >= 2 * (n_it - 1) - 1, picked["forced"]
+    assert (picked["rule"] == 2).sum() >= 2 * (n_it - 8), picked["rule"]      # (every launch expected to search most of the frame)
 
 
 def test_parity_fit_takes_its_rows_in_distance_order():
