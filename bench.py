@@ -342,7 +342,9 @@ def roofline_blocks(name, n_queries_per_launch, kern_us):
     prof = profile_record(name)
     hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("source"),
-           "kernel": "k_lin (certificate test, exact 6-NN search where needed, plane fit, point-to-plane row, J^T J / J^T r reduction)",
+           "kernel": "k_lin (certificate test, exact 6-NN search where needed, plane fit, point-to-plane row, J^T J / J^T r reduction) + the advance pass "
+                     "the host puts in front of it in some launches (k_advance / k_advance_team: the searches and refits in dense waves / by teams of 16 lanes); "
+                     "kernel_us_avg brackets all kernels of a linearisation",
            "kernel_us_avg": kern_us, "points_per_launch": n_queries_per_launch, "algorithmic_bytes_per_launch": algo}
     out = {"roofline": hbm}
     mix = valu_mix()
@@ -453,6 +455,7 @@ def regime_probe(P, runs=6):
         algo = BYTES_PER_QUERY * float(pts[sel].mean())
         out[name] = {"launches": int(sel.sum()), "mean_us": mean_us, "min_us": float(us.min()), "max_us": float(us.max()),
                      "share_of_kernel_time": float(us.sum() / (1e3 * ms.sum())),
+                     "launches_with_advance_pass": int((ser["advanced"][ok][sel] == 1).sum()), "launches_with_team_pass": int((ser["advanced"][ok][sel] == 2).sum()),
                      "mean_searched_frac": float(frac_s[sel].mean()), "mean_refitted_frac": float(refit[sel].mean()),
                      "achieved_GBps": algo / (mean_us * 1e-6) / 1e9, "frac": algo / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     # the first four launches of a run, by position (the launches 0.87 m off the surface)
@@ -517,6 +520,13 @@ def c3_registration(D, args, repeats=20):
         tc = time.perf_counter()
         if rep >= 3:
             t_src.append(tb - ta); t_tot.append(tc - ta); its.append(res.iterations)
+    # one more registration, logged (untimed): which launches ran the small-frame pass, and what they searched
+    ctx.set_option("record_launches", 1)
+    ctx.launch_series(reset=True)
+    ctx.set_source(src)
+    ctx.icp_run(T0, args.method, cfg, log_capacity=0)
+    ser = ctx.launch_series(reset=True)
+    ctx.set_option("record_launches", 0)
     T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
     te, re_ = api.pose_error(gt, T)
     ctx.close()
@@ -525,6 +535,8 @@ def c3_registration(D, args, repeats=20):
            "trans_error_vs_gt_m": float(te), "rot_error_vs_gt_deg": float(re_), "repeats": repeats,
            "workload": "PK01 stand-in: %d-pt frame vs %d-pt map, radius 0.5, method %s, thresholds 1e-5 rad / 1e-3 m, init / gt poses of config/icp_pk01.yaml; "
                        "frame from a host buffer every time (dcreg_set_source), map resident" % (len(src), len(tgt), args.method),
+           "launch_structure": {"k_lin_alone": int((ser["advanced"] == 0).sum()), "k_advance_team_then_k_lin": int((ser["advanced"] == 2).sum()),
+                                "k_advance_then_k_lin": int((ser["advanced"] == 1).sum()), "searched_per_launch": [int(x) for x in ser["searched"]]},
            "reference_published_ms": 2.11, "reference_source": "paper table 6 / results/long_duration experiments/table3_4/*/dcreg/data_time.txt (Parking Lot, the authors' CPU; real data)"}
     if not args.no_cpu_baseline:
         from oracle import pyoracle as po
@@ -695,6 +707,8 @@ def main(argv=None):
             mq = measure(Q, D, steps=k, warmup=1 if mc else w["run_len"], repeats=5)
             sub[name] = summarize(name, Q, D, mq, k, n_gpus)
             sub[name]["host_threads_per_rank"] = host_threads
+            if n_gpus == 1 and not mc and not args.no_regimes:
+                sub[name]["roofline_by_regime"] = regime_probe(Q, runs=4)
             Q.close()
         if n_gpus == 1:
             sub["c3_pk01_8k_registration"] = c3_registration(D, args)

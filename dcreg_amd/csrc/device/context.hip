@@ -112,7 +112,7 @@ static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double 
     g.n_pts = (uint32_t)n;
     if (ensure(c, c->d_keys, c->keys_cap, (size_t)n) || ensure(c, c->d_keys2, c->keys2_cap, (size_t)n) ||
         ensure(c, c->d_vals, c->vals_cap, (size_t)n) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n) ||
-        ensure(c, *d.cell_start, *d.cell_cap, (size_t)n_cells + 1) || ensure(c, *d.sorted, *d.sorted_cap, (size_t)n + 8))
+        ensure(c, *d.cell_start, *d.cell_cap, (size_t)n_cells + 1) || ensure(c, *d.sorted, *d.sorted_cap, (size_t)n + kPtsPad))
         return DCREG_E_NOMEM;
     hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, d.raw, n, g, c->d_keys, c->d_vals);
     int bits = 1;
@@ -120,7 +120,7 @@ static int build_grid_at(dcreg_ctx *c, const GridDst &d, double h, const double 
     int rc = sort_pairs_u32(c, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2, (size_t)n, bits);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, d.raw, c->d_vals2, n, *d.sorted);
-    HIP_TRY(c, hipMemsetAsync(*d.sorted + n, 0, 8 * sizeof(float4), c->stream));   // tail padding
+    HIP_TRY(c, hipMemsetAsync(*d.sorted + n, 0, kPtsPad * sizeof(float4), c->stream));   // tail padding
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_cell_start, dim3(blocks_for(n_cells + 1, 256)), dim3(256), 0, c->stream, c->d_keys2, n, n_cells, *d.cell_start, c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(occupied, c->d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -59,7 +59,7 @@ struct GridDev {
                                   // (y,z) row is still ONE contiguous run per x-interval, but the interval is cut sx times finer
     uint32_t n_pts;
     const uint32_t *cell_start;   // [nx*sx*ny*nz + 1], entry ((z*ny + y)*nx + x)*sx + sub
-    const float4 *pts;            // sorted target; at least 3 readable entries follow the last point (candidate loads come in fours)
+    const float4 *pts;            // sorted target; kPtsPad readable entries follow the last point (candidate loads come in batches)
     const uint8_t *gap;           // [nx*ny*nz] Chebyshev distance (cells) to the nearest occupied cell, 255 = more than
     int gap_cap;                  //   gap_cap; null = not built.  Lets a query in empty space skip the rings it knows are empty
     const uint32_t *owner;        // [nx*ny*nz] with the field: an occupied cell at that distance (kNoIdx beyond gap_cap); null = not built.
@@ -320,6 +320,23 @@ struct HeapFast {
     DCREG_DEVFN bool boundary_tie() const { return full() && outside_min == d[K - 1]; }
 };
 
+// The six smallest of the squared distances pushed, ascending - distances only (lin_search6's start-bound probe): entry i becomes the
+// median of (d[i-1], d[i], x), all read before any is written, as in HeapFast::push.  Padding slots push +inf.
+struct Top6 {
+    static constexpr int K = 6;
+    float d[6];
+    uint32_t n_eval, n_shell;      // (interface of the heaps; unused)
+    DCREG_DEVFN void init(float bound_f) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = bound_f;
+        n_eval = 0; n_shell = 1;
+    }
+    DCREG_DEVFN void push(float x, uint32_t /*idx*/, uint32_t /*p*/, bool /*valid*/ = true) {
+        d[5] = med3f(d[4], d[5], x); d[4] = med3f(d[3], d[4], x); d[3] = med3f(d[2], d[3], x);
+        d[2] = med3f(d[1], d[2], x); d[1] = med3f(d[0], d[1], x); d[0] = fminf(d[0], x);
+    }
+};
+
 // float32, NOT contracted to FMA: must round exactly like the oracle's / FLANN's plain mul+add chain
 DCREG_DEVFN float dist2_nofma(float qx, float qy, float qz, const float4 &c) {
 #pragma clang fp contract(off)
@@ -342,7 +359,7 @@ DCREG_DEVFN void body_to_global(const PoseArg &P, double px, double py, double p
 
 // one run of the ring walk: four candidates per trip, their loads issued together (slots past the end read on in the
 // sorted array and push +inf)
-template <class H>
+template <class H, int NB = 1>
 DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp);
 
 DCREG_DEVFN int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // lo <= hi at every call site
@@ -411,17 +428,27 @@ DCREG_DEVFN void push_point(H &hp, float qx, float qy, float qz, const float4 &c
     hp.push(valid ? d2 : __builtin_inff(), __float_as_uint(c.w), p, valid);     // padding slots can never enter
 }
 
-template <class H>
+// (NB: trips whose loads are requested together - a scan that nothing else overlaps, like the start-bound probe of a far query, pays one
+//  memory round trip per NB trips instead of one per trip; the sorted array is padded for the widest batch, kPtsPad)
+constexpr int kPtsPad = 16;
+#if !defined(DCREG_PROBE_BATCH)
+#define DCREG_PROBE_BATCH 2
+#endif
+constexpr int kProbeBatch = DCREG_PROBE_BATCH;   // lin_search6's start-bound probe (at most 48 points)
+template <class H, int NB>
 DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
+    static_assert(4 * NB <= kPtsPad, "slots past the end of the array read its padding");
     DCREG_STAT(runs);
-    for (uint32_t p = s; p < e; p += 4) {
-        DCREG_STAT(trips);
-        float4 c[4];
+    for (uint32_t p = s; p < e; p += 4 * NB) {
+        float4 c[4 * NB];
         const float4 *cp4 = g.pts + p;          // slots past the end read the array's padding / the next cell: masked below
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = cp4[u];
+        for (int u = 0; u < 4 * NB; ++u) c[u] = cp4[u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) push_point<H>(hp, qx, qy, qz, c[u], p + u, p + u < e);
+        for (int u = 0; u < 4 * NB; ++u) {
+            if (u % 4 == 0 && p + u < e) DCREG_STAT(trips);
+            push_point<H>(hp, qx, qy, qz, c[u], p + u, p + u < e);
+        }
     }
 }
 
@@ -1337,7 +1364,13 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
             all_in_space = !wave_any(reach && !in_space);
         }
         if (wave_any(far)) {
-            HeapFast<6> hb;
+            // (only the sixth smallest DISTANCE of the probed points is wanted - no positions, no tie bookkeeping: a sorted six of floats
+            //  kept by the median trick of HeapFast::push, six instructions per point instead of the 25 of the full insertion network)
+#if defined(DCREG_PROBE_FULLHEAP)
+            HeapFast<6> hb;            // (the A/B of profiles/r05_ablation.md)
+#else
+            Top6 hb;
+#endif
             hb.init(bound);
             uint32_t s_ = 0, e_ = 0;
             if (far) {
@@ -1347,8 +1380,9 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
                 e_ = g.cell_start[row + min(ox + 2u, (uint32_t)g.nx) * (uint32_t)g.sx];
                 e_ = min(e_, s_ + 48u);
             }
-            scan_run<HeapFast<6>>(g, s_, e_, qx, qy, qz, hb);
-            if (far && hb.full()) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(hb.d[5]) + 1u), 1.17549435e-38f));   // inclusive, as warm_bound6
+            scan_run<decltype(hb), kProbeBatch>(g, s_, e_, qx, qy, qz, hb);
+            // (six points closer than the bound: d[5] < bound, and only then does the new bound differ from the old one)
+            if (far) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(hb.d[5]) + 1u), 1.17549435e-38f));   // inclusive, as warm_bound6
         }
     }
     const float infl = a.prune_infl, cap = a.infl_max_d2 * a.prune_infl;

@@ -12,6 +12,10 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()[:60]
 
 ALL_LIN = "dcreg::k_lin (all instantiations)"
+# one linearisation = one k_lin dispatch + the advance pass that may run in front of it (k_advance / k_advance_team): per-linearisation
+# figures are the totals over all of those kernels divided by the number of k_lin dispatches
+LIN = "one linearisation (k_lin + advance passes)"
+def is_lin(name): return "k_lin" in name or "k_advance" in name
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
@@ -40,6 +44,13 @@ if kt:
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         md.append("| %s | %d | %.0f | %d | %d | %d |" % (k, len(v), sum(v) / len(v), min(v), max(v), sum(v)))
         ks[k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)}
+    n_lin = len(agg.get(ALL_LIN, []))
+    if n_lin:
+        tot = sum(sum(v) for k, v in agg.items() if is_lin(k) and k != ALL_LIN)
+        n_pass = sum(len(v) for k, v in agg.items() if "k_advance" in k)
+        md.append("| %s | %d | %.0f | | | %d |" % (LIN, n_lin, tot / n_lin, tot))
+        ks[LIN] = {"calls": n_lin, "avg_ns": tot / n_lin, "passes": n_pass}
+        md += ["", "(%d of the %d linearisations ran an advance pass in front of k_lin; the last row charges the passes to them)" % (n_pass, n_lin)]
     out["kernel_trace"] = ks
     md.append("")
 # rocprofv3's own --stats table of the same process
@@ -61,10 +72,23 @@ def counters(sub):
     return res
 pm = {}
 for sub in ("fetch", "write", "sq1", "sq2", "tcc"):
-    for k, v in counters(sub).items():
-        if "k_lin" in k or "k_finalize" in k:
+    cs = counters(sub)
+    n_lin_c = 0
+    for k, v in cs.items():
+        if k == ALL_LIN and v:
+            n_lin_c = max(len(vals) for vals in v.values())
+    for k, v in cs.items():
+        if is_lin(k) or "k_finalize" in k:
             for cn, vals in v.items():
                 pm.setdefault(k, {})[cn] = sum(vals) / len(vals)
+    if n_lin_c:        # per linearisation: the passes' counters charged to the k_lin dispatches
+        tot = collections.defaultdict(float)
+        for k, v in cs.items():
+            if is_lin(k) and k != ALL_LIN:
+                for cn, vals in v.items():
+                    tot[cn] += sum(vals)
+        for cn, t in tot.items():
+            pm.setdefault(LIN, {})[cn] = t / n_lin_c
 out["pmc_per_dispatch"] = pm
 if pm:
     md += ["## PMC counters, mean per dispatch", ""]
@@ -72,7 +96,7 @@ if pm:
         md.append("**%s**" % k)
         md.append("")
         md += ["| counter | value |", "|---|---|"] + ["| %s | %.4g |" % (a, b) for a, b in sorted(v.items())] + [""]
-    lin = pm.get(ALL_LIN) or next((v for k, v in pm.items() if "k_lin" in k), None)     # mean over ALL launches of the run
+    lin = pm.get(LIN) or pm.get(ALL_LIN) or next((v for k, v in pm.items() if "k_lin" in k), None)     # mean over ALL linearisations of the run
     if lin and "FETCH_SIZE" in lin:
         fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
         raw = (fetch_kb + write_kb) * 1024.0
@@ -92,12 +116,12 @@ if pm:
                           "calibration": cal_src,
                           "note": "FETCH_SIZE/WRITE_SIZE are KB at the L2<->fabric boundary (Infinity-Cache hits included).  On gfx950 FETCH_SIZE "
                                   "reports half the bytes read - measured on this kernel's own patterns, see `calibration`; WRITE_SIZE is exact."}
-        md += ["## HBM-side traffic of k_lin per launch", "",
+        md += ["## HBM-side traffic per linearisation (k_lin + advance passes)", "",
                "FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB -> %.2f MB raw, %.2f MB with the calibrated factors (read x%.3f, write x%.3f: %s)." % (
                    fetch_kb, write_kb, raw / 1e6, corr / 1e6, f_read, f_write, cal_src), ""]
     if lin and "SQ_WAVES" in lin:
         w = lin["SQ_WAVES"]
-        md += ["## Per-wave instruction mix of k_lin", "",
+        md += ["## Per-wave instruction mix, all kernels of a linearisation", "",
                "waves %.0f; per wave: VALU %.0f, SALU %.0f, LDS %.0f, VMEM_RD %.0f; SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (
                    w, lin.get("SQ_INSTS_VALU", 0) / w, lin.get("SQ_INSTS_SALU", 0) / w, lin.get("SQ_INSTS_LDS", 0) / w,
                    lin.get("SQ_INSTS_VMEM_RD", 0) / w, lin.get("SQ_WAIT_ANY", 0) / max(lin.get("SQ_WAVE_CYCLES", 1), 1)), ""]

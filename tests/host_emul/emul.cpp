@@ -61,7 +61,7 @@ static uint32_t build_at(EmuIndex &E, const float *xyz, int64_t n, double h, con
     }
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });   // radix sort is stable too
-    E.pts.assign((size_t)n + 8, float4{0.f, 0.f, 0.f, 0.f});
+    E.pts.assign((size_t)n + dcreg::kPtsPad, float4{0.f, 0.f, 0.f, 0.f});
     E.cell_start.assign((size_t)n_cells + 1, 0u);
     uint32_t occ = 0;
     std::vector<uint32_t> cnt((size_t)n_cells, 0u);

@@ -176,3 +176,17 @@ def test_parity_fit_takes_its_rows_in_distance_order():
         T = h.pose6d_matrix(sz, -sz * 0.5, sz * 0.2, sz * 0.01, 0.0, -sz * 0.01) @ T
         assert _same_sums(c.linearize(T[:3, :3], T[:3, 3], prm), f.linearize(T[:3, :3], T[:3, 3], prm)), sz
     c.close(); f.close()
+
+
+def test_two_rccl_ranks_on_one_device_are_refused_by_rccl_itself():
+    """The one-GPU box cannot exercise RCCL with more than one rank: RCCL (like NCCL) refuses a communicator whose ranks share a device
+    ("invalid usage": duplicate GPU).  This test pins that reason down - two processes, backend nccl, both on cuda:0, 127.0.0.1
+    rendezvous (scripts/rccl_two_ranks_probe.py) - so that DESIGN.md's "RCCL with N > 1 ranks has never run" stays a statement about
+    the hardware available, not about the code: the two-rank paths of the library run over gloo on this box (test_bench_launcher,
+    test_two_ranks_...), the RCCL path with a communicator of one rank (test_native_rccl_exchange_world_of_one).  Should RCCL ever
+    accept the shared device, both ranks must then complete their all_gather."""
+    import os, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(h.REPO, "scripts", "rccl_two_ranks_probe.py")], capture_output=True, text=True, timeout=300).stdout
+    ok = out.count("torch nccl all_gather ok")
+    refused = out.count("invalid usage") + out.count("Duplicate GPU")
+    assert ok == 2 or (ok == 0 and refused >= 2), out[-2000:]
