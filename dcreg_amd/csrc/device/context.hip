@@ -645,18 +645,10 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             hp[i].fresh = (has && c->batch_state_valid[(size_t)state_ids[i]] != 0) ? 0u : 1u;
             if (has) c->batch_state_valid[(size_t)state_ids[i]] = 1;
         }
-        // The poses travel on a stream of their own: while the device still works on the other slot's launch (the Monte-Carlo engine
-        // keeps two groups of trials alternating) the copy engine brings this launch's poses over, and the launch only waits for the
-        // event behind the copy - no copyBuffer between two consecutive kernels on the compute stream (it was 4.6 us in front of every
-        // 66 us batch: profiles/r04_c5_montecarlo_5000.md).  The slot's previous launch has completed (S.pending was false), so
-        // nothing reads d_poses any more.
-        if (c->opt_pose_copy_stream && c->copy_stream && S.ev_poses) {
-            HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(c, hipEventRecord(S.ev_poses, c->copy_stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, S.ev_poses, 0));
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->stream));
-        }
+        // (measured and dropped, profiles/r05_ablation.md: the upload on a copy stream behind an event - the cross-stream dependency costs
+        //  more than the 4.6 us copy it hides, C5 1.56 M against 1.64 M it/s - and no upload at all, the kernel reading the pinned block:
+        //  +2.7 us per kernel, nothing gained - the experiment is bound by its kernels, two groups of trials alternating on the device)
+        HIP_TRY(c, hipMemcpyAsync(S.d_poses, S.h_poses, bytes, hipMemcpyHostToDevice, c->stream));
         d_poses = (const PoseArg *)S.d_poses;
         if (use_states) { a.state = c->d_state_batch; a.state_stride = (uint32_t)c->state_batch_stride; }
     }
@@ -1033,10 +1025,6 @@ int dcreg_backend_create(dcreg_ctx **out, int device) {
     c->stream = c->own_stream;
     for (LinSlot &S : c->slots)       // "time_kernels": the events of each slot's launch (created here, not in a timed region)
         if (hipEventCreate(&S.ev0) != hipSuccess || hipEventCreate(&S.ev1) != hipSuccess) { S.ev0 = S.ev1 = nullptr; }
-    // pose uploads of batched launches: a copy stream + one event per slot (without them the copy goes through the compute stream)
-    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) c->copy_stream = nullptr;
-    for (LinSlot &S : c->slots)
-        if (hipEventCreateWithFlags(&S.ev_poses, hipEventDisableTiming) != hipSuccess) S.ev_poses = nullptr;
     *out = c;
     return DCREG_OK;
 }
@@ -1064,12 +1052,10 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
         for (void *b : S.tmp_dev) (void)hipFree(b);
         if (S.ev0) (void)hipEventDestroy(S.ev0);
         if (S.ev1) (void)hipEventDestroy(S.ev1);
-        if (S.ev_poses) (void)hipEventDestroy(S.ev_poses);
         if (S.h_out) (void)hipHostFree(S.h_out);
         if (S.h_poses) (void)hipHostFree(S.h_poses);
     }
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
-    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1121,7 +1107,6 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "advance_lo") c->opt_advance_lo = v;           // ... rule: the last launch searched between these fractions of its points
     else if (k == "advance_hi") c->opt_advance_hi = v;
     else if (k == "advance_min_blocks") c->opt_advance_min_blocks = (int)v;   // ... and the cloud has at least this many query blocks
-    else if (k == "pose_copy_stream") c->opt_pose_copy_stream = v != 0.0;   // batched launches: poses uploaded on the copy stream (0: on the compute stream)
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
     else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host

@@ -35,7 +35,6 @@ struct LinSlot {
     size_t n_rows = 0;
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
-    hipEvent_t ev_poses = nullptr;  // batched launches: "this slot's poses are on the device" (recorded on the ctx's copy stream)
     bool stamps_only = false;
     int advanced = 0;              // an advance pass ran in front of the launch in flight: 1 = k_advance, 2 = k_advance_team (kernels.hpp)
     bool coded = false;            // the launch in flight reports searched / refitted counts above its count slots (LinArgs::count_scale)
@@ -44,8 +43,6 @@ struct LinSlot {
 struct dcreg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t copy_stream = nullptr;     // pose uploads of batched launches (linearize_begin)
-    bool opt_pose_copy_stream = false;     // (measured: C5 1.64 M it/s on the compute stream, 1.56 M on the copy stream - profiles/r05_ablation.md)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     char err[512] = {0};
 
