@@ -669,7 +669,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         // ... its small-frame form (k_advance_team: sixteen lanes per query, one wave per kTeamTile points): a frame of a few thousand
         // points, whose query blocks leave most of the device idle, in a launch expected to search most of its points (the pass costs
         // ~12 us whatever it finds to do; k_lin alone gets cheaper as its searching waves thin out, so below half it wins again)
-        team = c->opt_team_pass >= 2 || (c->opt_team_pass == 1 && n <= (int64_t)c->opt_team_pass_max_points && known && f >= c->opt_team_pass_min_frac);
+        // ... and only against a map whose occupied cells hold several points each: there a query with a loose bound (an OUT point, a
+        // jump) has a hundred and more candidates in its 27-cell block and the lock-step search, two trips in flight, is at its slowest;
+        // against a sparse map (the 7.5 k-point fixture: 1.6 points per occupied cell) it is as fast as the teams
+        const double per_cell = (double)c->n_tgt / (double)std::max<uint32_t>(c->occupied_cells, 1u);
+        team = c->opt_team_pass >= 2 || (c->opt_team_pass == 1 && n <= (int64_t)c->opt_team_pass_max_points && known && f >= c->opt_team_pass_min_frac &&
+                                         per_cell >= c->opt_team_pass_min_cell_pts);
     }
     if (team) adv = false;
     const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
@@ -1104,6 +1109,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "team_pass_max_points") c->opt_team_pass_max_points = v;
     else if (k == "team_pass_min_frac") c->opt_team_pass_min_frac = v;
+    else if (k == "team_pass_min_cell_pts") c->opt_team_pass_min_cell_pts = v;
     else if (k == "advance_lo") c->opt_advance_lo = v;           // ... rule: the last launch searched between these fractions of its points
     else if (k == "advance_hi") c->opt_advance_hi = v;
     else if (k == "advance_min_blocks") c->opt_advance_min_blocks = (int)v;   // ... and the cloud has at least this many query blocks

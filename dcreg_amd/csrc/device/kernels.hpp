@@ -580,8 +580,13 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
 // changes a result (history independence), so the sums are bitwise those of a launch without the pass.  The host decides per launch
 // (context.hip: the fraction of points the last completed launch searched; clouds whose query blocks exceed what the device holds).
 // A point whose new certificate has no slack at all (exact distance ties) is searched again by k_lin - correct, merely slower.
+#if !defined(DCREG_ADV_DEPTH)
+#define DCREG_ADV_DEPTH 4
+#endif
+constexpr int kAdvDepth = DCREG_ADV_DEPTH;        // trips in flight in the pass's searches (search.hpp knn_search DEPTH); > 2: the kernel takes
+                                                  // the registers of two waves per SIMD - its dense waves are few and each a chain of round trips
 template <bool FAST>
-static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_advance(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
+static __global__ __launch_bounds__(kLinBlock, (DCREG_ADV_DEPTH > 2 ? 2 : DCREG_LIN_OCC)) void k_advance(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
                                                                               const PoseArg *__restrict__ poses, LinArgs a,
                                                                               uint32_t *__restrict__ counts, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off
@@ -664,7 +669,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_advance(con
         uint32_t iw = i;
         if constexpr (searching) {
             Set6 s6;
-            lin_search6<kLinSweep>(g, runs[wave], a, act, a.warm != 0, pos6, qx, qy, qz, s6, cert);
+            lin_search6<kLinSweep, kAdvDepth>(g, runs[wave], a, act, a.warm != 0, pos6, qx, qy, qz, s6, cert);
             asm volatile("" : "+v"(iw));
 #pragma unroll
             for (int j = 0; j < 6; ++j) pos6[j] = s6.pos[j];

@@ -501,7 +501,10 @@ DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, ui
 // the pruning distance of its moment, hence of the end: the 7th-neighbour bound min(outside_min, final pruning distance, bound) does
 // not need them.  The boundary-tie test of knn_exact does (a filtered candidate may equal the K-th best where the pruning distance is
 // not inflated), so only search6 - which decides ties on the 5th / 6th entries alone - turns it off.
-template <class H, bool SWEEP = false, bool NOTE = true>
+// DEPTH: register sets of the candidate loop's software pipeline, i.e. trips whose loads are in flight while one is consumed (2: what a
+// kernel at four waves per SIMD can afford; 4: the instantiations whose launches leave the SIMDs nearly empty and last as long as one
+// wave's chain of round trips - the advance pass).  The scan order - and with it every result - does not depend on it.
+template <class H, bool SWEEP = false, bool NOTE = true, int DEPTH = 2>
 DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f,
                                            int max_ring, H &hp, float infl = 1.f, float cap = __builtin_inff(), bool empty_block = false) {   // max_ring < 0: unbounded
     hp.init(bound_f, infl, cap);
@@ -641,14 +644,17 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
                 for (int u = 0; u < W; ++u) push_point<H>(hp, qx, qy, qz, sl.c[u], sl.cp + u, sl.cp + u < sl.ce);
             }
         };
-        Slot A, B;
-        fetch(A);
-        while (A.live) {
-            if (H::kDeferred && wave_any(cnt > kPend - W)) flush();      // room for the next W candidates in every lane
-            fetch(B); consume(A);
-            if (!B.live) break;
-            if (H::kDeferred && wave_any(cnt > kPend - W)) flush();
-            fetch(A); consume(B);
+        Slot S[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH - 1; ++k) fetch(S[k]);
+        bool go = S[0].live;
+        while (go) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                if (H::kDeferred && wave_any(cnt > kPend - W)) flush();      // room for the next W candidates in every lane
+                fetch(S[(k + DEPTH - 1) % DEPTH]); consume(S[k]);
+                if (!S[(k + 1) % DEPTH].live) { go = false; break; }
+            }
         }
         if constexpr (H::kDeferred) {
             flush();
@@ -1259,11 +1265,11 @@ struct Set6 {
 // 5th and 6th best distances are equal floats; then - lattices, duplicated points - the 64-bit-key search (distance, original index)
 // is run for this lane and its first five entries are the canonical set.  (A tie between the 6th best and a point outside does not
 // matter: neither belongs to the five, and both are at the distance the certificate uses.)
-template <bool SWEEP>
+template <bool SWEEP, int DEPTH = 2>
 DCREG_DEVFN void search6(const GridDev &g, RunList &rl, float qx, float qy, float qz, float bound_f, int max_ring, float infl, float cap, Set6 &out,
                          bool empty_block = false) {
     HeapFast<6> hf;
-    knn_search<HeapFast<6>, SWEEP, false>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap, empty_block);
+    knn_search<HeapFast<6>, SWEEP, false, DEPTH>(g, rl, qx, qy, qz, bound_f, max_ring, hf, infl, cap, empty_block);
     out.n_eval = hf.n_eval; out.n_shell = hf.n_shell;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { out.pos[j] = hf.pos[j]; out.d2[j] = hf.d[j]; }
@@ -1326,7 +1332,7 @@ DCREG_DEVFN float warm_bound6(const GridDev &g, const uint32_t (&oldpos)[6], flo
 }
 
 // search of one query inside a linearisation: bound (warm or cold), reach test, 6-NN, certificate
-template <bool SWEEP>
+template <bool SWEEP, int DEPTH = 2>
 DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, bool have_q, bool warm, const uint32_t (&oldpos)[6],
                              float qx, float qy, float qz, Set6 &st, uint32_t &cert) {
     float bound = a.radius_sq_f;
@@ -1390,7 +1396,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
     st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;
-    if (reach) search6<SWEEP>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st, SWEEP && all_in_space);
+    if (reach) search6<SWEEP, DEPTH>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st, SWEEP && all_in_space);
     cert = make_cert(st, a);
 }
 
