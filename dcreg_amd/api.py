@@ -179,8 +179,10 @@ def load():
     L.dcreg_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
     L.dcreg_kernel_time.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     L.dcreg_launch_series.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.c_int]
-    L.dcreg_launch_series_passes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64]
-    L.dcreg_team_pass_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
+    if hasattr(L, "dcreg_launch_series_passes"):        # (absent from an older build loaded through DCREG_LIB for an A/B: scripts/ab_multi.sh)
+        L.dcreg_launch_series_passes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64]
+    if hasattr(L, "dcreg_team_pass_stamps"):
+        L.dcreg_team_pass_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.dcreg_default_config.restype = None
     L.dcreg_default_config.argtypes = [C.POINTER(Config)]
     L.dcreg_analyze_degeneracy.argtypes = [dp, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Analysis)]
@@ -545,7 +547,8 @@ class Context:
         ms = np.empty(n, np.float64)
         se, rf, pt = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
         adv = np.zeros(n, np.uint8)
-        self._L.dcreg_launch_series_passes(self._h, adv.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+        if hasattr(self._L, "dcreg_launch_series_passes"):
+            self._L.dcreg_launch_series_passes(self._h, adv.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         self._L.dcreg_launch_series(self._h, _dp(ms), se.ctypes.data_as(lp), rf.ctypes.data_as(lp), pt.ctypes.data_as(lp), n, int(reset))
         return {"ms": ms, "searched": se, "refitted": rf, "points": pt, "advanced": adv}
 

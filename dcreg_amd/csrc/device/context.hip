@@ -415,6 +415,7 @@ static void free_tmp(LinSlot &S) {
 // after a launch that may not have run: what the states hold is unknown
 static void drop_warm(dcreg_ctx *c) {
     c->state_valid = false;
+    c->adv_counts_dirty = true;        // (a pass may have run without the k_lin that takes its counts)
     std::fill(c->batch_state_valid.begin(), c->batch_state_valid.end(), (uint8_t)0);
 }
 // publish a gate record (kernels.hpp GateHost): pose words and checksum first, the number last.  R == null: an abort, the pose words
@@ -678,10 +679,14 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     }
     if (team) adv = false;
     const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
-    if (adv || team) {
-        if (ensure(c, c->d_adv_counts, c->adv_counts_cap, (size_t)2 * n_tiles)) return DCREG_E_NOMEM;
+    if (adv || team) {      // the passes' counts, per query block of k_lin: zero between launches (k_lin takes them and zeroes them again)
+        const size_t had = c->adv_counts_cap;
+        if (ensure(c, c->d_adv_counts, c->adv_counts_cap, (size_t)kCounterStride * nbx)) return DCREG_E_NOMEM;      // (a 128-byte line per query block)
+        if (c->adv_counts_cap != had || c->adv_counts_dirty) {
+            HIP_TRY(c, hipMemsetAsync(c->d_adv_counts, 0, sizeof(uint32_t) * c->adv_counts_cap, c->stream));
+            c->adv_counts_dirty = false;
+        }
         a.adv_counts = c->d_adv_counts;
-        a.adv_n = n_tiles;
     }
     DebugDev dd{};
     free_tmp(S);

@@ -415,13 +415,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
     bool refit = have_q && !need && !cert_is_out(cert) && !fit_holds(fitw, q0x, q0y, q0z, qx, qy, qz);
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
-    uint32_t adv_s = 0, adv_r = 0;                  // ... and this block's share of what the advance pass in front of this launch did
-    if (a.adv_counts && wave == 0) {                // (entries vb, vb + n_blocks, ...: at most a few per lane; the sum lands in every lane)
-        for (uint32_t e = vb + (uint32_t)threadIdx.x * n_blocks_x; e < a.adv_n; e += 64u * n_blocks_x) {
-            adv_s += a.adv_counts[2 * (size_t)e]; adv_r += a.adv_counts[2 * (size_t)e + 1];
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { adv_s += (uint32_t)__shfl_xor((int)adv_s, m); adv_r += (uint32_t)__shfl_xor((int)adv_r, m); }
+    uint32_t adv_s = 0, adv_r = 0;                  // ... and what the advance pass in front of this launch did for this block's points
+    if (a.adv_counts && wave == 0) {                // (taken and zeroed again: the passes only ever add to zeroes)
+        adv_s = a.adv_counts[(size_t)vb * kCounterStride]; adv_r = a.adv_counts[(size_t)vb * kCounterStride + 1];
+        if (threadIdx.x == 0) { a.adv_counts[(size_t)vb * kCounterStride] = 0u; a.adv_counts[(size_t)vb * kCounterStride + 1] = 0u; }
     }
     KnnResult<5> nn;
     Fit fit;
@@ -645,7 +642,8 @@ static __global__ __launch_bounds__(kLinBlock, (DCREG_ADV_DEPTH > 2 ? 2 : DCREG_
     }
     __syncthreads();
     const uint32_t n_s = n_list[0], n_r = n_list[1];
-    if (threadIdx.x == 0 && counts) { counts[2 * blockIdx.x] = n_s; counts[2 * blockIdx.x + 1] = n_r; }
+    // (reported by the first query block of the tile: LinArgs::adv_counts)
+    if (threadIdx.x == 0 && counts) { counts[(size_t)blockIdx.x * (kAdvTile / kLinBlock) * kCounterStride] = n_s; counts[(size_t)blockIdx.x * (kAdvTile / kLinBlock) * kCounterStride + 1] = n_r; }
     if (threadIdx.x == 0 && a.search_count && n_s)            // (option "count_searches": the pass's searches count like k_lin's)
         atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)n_s);
     // ---- the list, 64 entries per wave at a time: the searches (waves in turn), then the refit-only points
@@ -743,7 +741,7 @@ constexpr int kTeamG = 16;                        // lanes per query
 constexpr int kTeamRows = 64;                     // rows of a ball the group handles (four per lane)
 constexpr int kTeamCand = 8;                      // candidates per lane
 constexpr int kTeamList = 64;                     // points inside the bound the ranking handles
-static_assert(kTeamTile >= 4 && kTeamTile <= 64, "one wave tests the tile; k_lin reads at most 64 count entries per lane pass");
+static_assert(kTeamTile >= 1 && kTeamTile <= 64 && kLinBlock % kTeamTile == 0, "one wave tests the tile; a tile lies inside one query block");
 struct TeamPassLds {
     uint32_t q_i[kTeamTile], q_kind[kTeamTile], q_cert[kTeamTile], q_pos[kTeamTile][6];
     float q_x[kTeamTile], q_y[kTeamTile], q_z[kTeamTile], q_q0[kTeamTile][3];
@@ -1065,7 +1063,12 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
     // what the block served (the points it left to k_lin are counted there)
 #pragma unroll
     for (int m = 16; m < 64; m <<= 1) { served_s += (uint32_t)__shfl_xor((int)served_s, m); served_r += (uint32_t)__shfl_xor((int)served_r, m); }
-    if (lane == 0 && counts) { counts[2 * blockIdx.x] = served_s; counts[2 * blockIdx.x + 1] = served_r; }
+    // (added to the entry of the query block the tile belongs to: LinArgs::adv_counts - k_lin takes the sums and zeroes them again)
+    if (lane == 0 && counts && (served_s | served_r)) {
+        const size_t kb = ((size_t)blockIdx.x * kTeamTile) / kLinBlock;      // (one 128-byte line per query block: atomics on one line are served one after the other)
+        if (served_s) atomicAdd(&counts[kb * kCounterStride], served_s);
+        if (served_r) atomicAdd(&counts[kb * kCounterStride + 1], served_r);
+    }
     if (lane == 0 && a.search_count && served_s)              // (option "count_searches": the pass's searches count like k_lin's)
         atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * (kCounterStride / 2), (unsigned long long)served_s);
 }

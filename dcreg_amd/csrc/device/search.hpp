@@ -142,9 +142,10 @@ struct LinArgs {
                                   // and the host splits them again (context.hip linearize_end).  What the host does with them:
                                   // scheduling only (which instantiation the next launch uses) and the launch statistics.  0 for
                                   // clouds of more than 2^26 points.
-    const uint32_t *adv_counts;   // a launch that runs behind an advance pass (kernels.hpp k_advance / k_advance_team): per block of that pass
-    uint32_t adv_n;               // the points it searched and refitted, [adv_n][2]; query block b of this launch adds the entries b, b + n_blocks,
-                                  // ... to the counts it reports (count_scale): every entry is reported once.  null: no pass in front
+    uint32_t *adv_counts;         // a launch that runs behind an advance pass (kernels.hpp k_advance / k_advance_team): per QUERY BLOCK of this
+                                  // launch the points the pass searched and refitted among its points, [n_blocks][32] (a line each: words 0, 1); the
+                                  // block adds them to the counts it reports (count_scale) and zeroes them again for the next launch.
+                                  // null: no pass in front
     float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
                                   // reaches this many cells beyond the distance to that cell (lin_search6)
     int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
