@@ -171,7 +171,7 @@ struct dcreg_ctx {
     double opt_far_loose = 1.5;    // search.hpp lin_search6: when a start bound is loose enough to be worth a probe (cells)
     // the advance pass (kernels.hpp k_advance): 0 never, 1 by the rule below, 2 whenever a launch can take it (tests)
     int opt_advance = 1;
-    double opt_advance_lo = 0.01, opt_advance_hi = 0.30;      // ... the last completed launch searched between these fractions of its points
+    double opt_advance_lo = 0.01, opt_advance_hi = 0.45;     // ... the last completed launch searched between these fractions of its points
     int opt_advance_min_blocks = 2048;                        // ... and the cloud has at least this many query blocks (twice what the device holds)
     // its small-frame form (k_advance_team): same switch values; rule: at most max_points source points, the last completed launch
     // searched at least min_frac of them, the map has at least min_cell_pts points per occupied cell

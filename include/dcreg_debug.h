@@ -94,7 +94,7 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "count_searches"     see dcreg_launch_stats;
  *   "record_launches"    see dcreg_launch_series;
  *   "advance"            the advance pass in front of single-pose launches: 0 = never, 1 (default) = when the last completed launch searched
- *                        between "advance_lo" (0.01) and "advance_hi" (0.30) of its points and the cloud has at least "advance_min_blocks"
+ *                        between "advance_lo" (0.01) and "advance_hi" (0.45) of its points and the cloud has at least "advance_min_blocks"
  *                        (2048) query blocks, 2 = whenever the launch can take it (warm state, certificates in use): tests;
  *   "team_pass"          the small-frame advance pass (sixteen lanes per query) in front of single-pose launches: 0 = never, 1 (default) =
  *                        for clouds of at most "team_pass_max_points" (16384) points when the last completed launch searched at least
