@@ -342,6 +342,10 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
     }
 }
 
+#if !defined(DCREG_LIN_DEPTH)
+#define DCREG_LIN_DEPTH 2
+#endif
+constexpr int kLinDepth = DCREG_LIN_DEPTH;        // register sets of k_lin's candidate pipeline (search.hpp knn_search DEPTH)
 // points per block of the advance pass (k_advance below): kAdvTile / kLinBlock query blocks of k_lin
 #if !defined(DCREG_ADV_TILE)
 #define DCREG_ADV_TILE 1024
@@ -475,7 +479,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             if (!by_team) {
                 Set6 s6;
                 uint32_t c2;
-                lin_search6<kLinSweep>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
+                lin_search6<kLinSweep, kLinDepth>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
                 if (need) {
                     cert = c2;
 #pragma unroll

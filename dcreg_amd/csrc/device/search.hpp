@@ -648,7 +648,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
         Slot S[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH - 1; ++k) fetch(S[k]);
-        bool go = S[0].live;
+        bool go = DEPTH > 1 ? S[0].live : have;
         while (go) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {

@@ -1,0 +1,82 @@
+"""Randomised hunt for the advance passes (GPU box): random scenes, sizes, radii, cell sizes (balls of one to a dozen cells: the teams' row
+lists, layer masks and overflow paths all occur), walks that mix tiny steps and jumps.  At every step the 31 sums of a context with the dense
+pass forced, one with the team pass forced and one without passes must agree BIT FOR BIT, and with the oracle to 1e-8.
+usage: fuzz_passes.py [n_cases] [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dcreg_amd import scenes as h
+import dcreg_amd
+from dcreg_amd import api
+from oracle import pyoracle as po
+
+
+def _rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def same(a, b):
+    return (a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
+            and a["sum_r2"] == b["sum_r2"] and a["sum_b2"] == b["sum_b2"])
+
+
+def run(n_cases, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    ctxs = {"dense": dcreg_amd.Context(0), "team": dcreg_amd.Context(0), "plain": dcreg_amd.Context(0)}
+    ctxs["dense"].set_option("advance", 2); ctxs["dense"].set_option("team_pass", 0)
+    ctxs["team"].set_option("advance", 0); ctxs["team"].set_option("team_pass", 2)
+    ctxs["plain"].set_option("advance", 0); ctxs["plain"].set_option("team_pass", 0)
+    bad = 0
+    for case in range(n_cases):
+        kind = rng.integers(0, 5)
+        n = int(rng.choice([800, 3000, 12000, 40000]))
+        if kind == 0: tgt = h.scene_cylinder(n, seed=int(rng.integers(1 << 30)), noise=float(rng.choice([0.0, 0.01, 0.05])))
+        elif kind == 1: tgt = h.scene_corridor(n, seed=int(rng.integers(1 << 30)), length=float(rng.choice([20.0, 60.0])))
+        elif kind == 2: tgt = h.scene_planes(n, seed=int(rng.integers(1 << 30)))
+        elif kind == 3: tgt = (rng.uniform(-3, 3, (n, 3)) * np.array([1.0, 1.0, float(rng.choice([0.02, 1.0]))])).astype(np.float32)
+        else:                                                  # a lattice with duplicates: ties everywhere
+            g = np.arange(0, 12, dtype=np.float32) * np.float32(rng.choice([0.2, 0.35]))
+            tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+            tgt = np.concatenate([tgt, tgt[::5]])
+        m = int(rng.integers(200, 5000))
+        src = tgt[rng.integers(0, len(tgt), m)] + rng.normal(0, float(rng.choice([0.0, 0.01, 0.2])), (m, 3))
+        if rng.random() < 0.3:
+            src = np.concatenate([src, rng.uniform(-60, 60, (50, 3))])          # far outliers
+        src = src.astype(np.float32)
+        radius = float(rng.choice([0.3, 0.5, 1.0, 2.0]))
+        cf, gf = float(rng.choice([0.5, 1.0, 1.5, 2.0, 3.0])), int(rng.integers(0, 2))
+        fast = int(rng.integers(0, 2))
+        for c in ctxs.values():
+            c.set_option("cell_factor", cf); c.set_option("gap_field", gf); c.set_option("fast_plane_fit", fast)
+            c.set_target(tgt, radius); c.set_source(src)
+        tree = po.KdTree(tgt)
+        wd = int(rng.integers(0, 2))
+        T = h.pose6d_matrix(*(rng.normal(0, 0.05, 3)), *(rng.normal(0, 0.003, 3)))
+        for step in range(6):
+            amp = float(rng.choice([1e-5, 0.002, 0.02, 0.3]))
+            T = h.pose6d_matrix(*(rng.normal(0, amp, 3)), *(rng.normal(0, amp * 0.05, 3))) @ T
+            outs = {k: c.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(radius, wd)) for k, c in ctxs.items()}
+            good = same(outs["dense"], outs["plain"]) and same(outs["team"], outs["plain"])
+            if good and step in (0, 5):
+                r = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(radius, wd))
+                good = outs["plain"]["n_eff"] == r["n_eff"] and outs["plain"]["n_pt"] == r["n_pt"]
+                if good and r["n_eff"] > 0:
+                    good = _rel_err(outs["plain"]["H_upper"], r["H_upper"]) < (1e-8 if fast else 1e-6) and _rel_err(outs["plain"]["g"], r["g"]) < 1e-6
+            if not good:
+                bad += 1
+                print("MISMATCH case %d step %d: kind %d n %d m %d radius %.2f cell_factor %.1f n_eff %d / %d / %d" % (
+                    case, step, kind, len(tgt), len(src), radius, cf, outs["dense"]["n_eff"], outs["team"]["n_eff"], outs["plain"]["n_eff"]), flush=True)
+        if verbose:
+            print("case %2d ok: kind %d, %5d x %4d, R %.1f, cell %.3f, fast %d, n_eff %d" % (case, kind, len(tgt), len(src), radius, ctxs["plain"].index_info().cell, fast, outs["plain"]["n_eff"]), flush=True)
+    for c in ctxs.values():
+        c.close()
+    return bad
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("fuzz_passes done: %d mismatches in %d cases" % (bad, n_cases))
+    sys.exit(1 if bad else 0)

@@ -190,3 +190,13 @@ def test_two_rccl_ranks_on_one_device_are_refused_by_rccl_itself():
     ok = out.count("torch nccl all_gather ok")
     refused = out.count("invalid usage") + out.count("Duplicate GPU")
     assert ok == 2 or (ok == 0 and refused >= 2), out[-2000:]
+
+
+def test_bounded_hunt_for_the_advance_passes():
+    """scripts/fuzz_passes.py with a fixed seed inside the suite: 40 random scenes (five kinds incl. a lattice with duplicates; radii 0.3-2 m
+    against cells of half to three neighbour spacings: balls of one to a dozen cells; either plane fit; with / without the empty-space
+    field) x 6 steps from 10 um to decimetres: dense pass forced == team pass forced == no pass, bit for bit, and == oracle."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_passes", os.path.join(h.REPO, "scripts", "fuzz_passes.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.run(40, 20260928, verbose=False) == 0
