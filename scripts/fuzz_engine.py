@@ -13,6 +13,8 @@ from oracle import pyoracle as po
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 ctx = dcreg_amd.Context(0)
+for _kv in os.environ.get("DCREG_FUZZ_OPTS", "").split():      # e.g. DCREG_FUZZ_OPTS="advance=2 team_pass=0": the hunt with a pass forced
+    ctx.set_option(_kv.split("=")[0], float(_kv.split("=")[1]))
 METHODS = ["Ours", "NONE", "ME-SR", "FCN-SR", "ME-TSVD", "ME-TReg"]
 bad = soft = 0
 for case in range(n_cases):

@@ -62,7 +62,9 @@ def run(n_cases, seed, verbose=True):
             if good and step in (0, 5):
                 r = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(radius, wd))
                 good = outs["plain"]["n_eff"] == r["n_eff"] and outs["plain"]["n_pt"] == r["n_pt"]
-                if good and r["n_eff"] > 0:
+                # (a lattice with duplicated points: rank-deficient 5x3 systems, whose truncated solution rounding decides - here as in the
+                #  reference's Eigen build; only the counts are comparable there: DESIGN.md section 2)
+                if good and r["n_eff"] > 0 and kind != 4:
                     good = _rel_err(outs["plain"]["H_upper"], r["H_upper"]) < (1e-8 if fast else 1e-6) and _rel_err(outs["plain"]["g"], r["g"]) < 1e-6
             if not good:
                 bad += 1

@@ -16,6 +16,8 @@ cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 iters = 0
 for c in range(cycles):
     ctx = dcreg_amd.Context(0)
+    for _kv in os.environ.get("DCREG_FUZZ_OPTS", "").split():      # e.g. DCREG_FUZZ_OPTS="advance=2 team_pass=0": the hunt with a pass forced
+        ctx.set_option(_kv.split("=")[0], float(_kv.split("=")[1]))
     for rep in range(int(rng.integers(1, 4))):
         n = int(rng.choice([500, 7000, 60000, 250000]))
         tgt = h.scene_cylinder(n, seed=int(rng.integers(1 << 30)), noise=0.01)
