@@ -47,6 +47,8 @@ def lib():
         L.emu_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(LinParams),
                                     C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p, C.c_int64, C.c_void_p]
         L.emu_plane_fit.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.emu_ball_query.restype = C.c_int64
+        L.emu_ball_query.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.emu_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -114,6 +116,15 @@ def knn(index, q, k=5, max_radius=0.0):
     d2 = np.empty((len(q), k), np.float32)
     lib().emu_knn(index.ptr, _ptr(q), len(q), int(k), float(max_radius), _ptr(idx), _ptr(d2))
     return idx, d2
+
+
+def ball_query(index, q, bound):
+    """The row enumeration of the small-frame advance pass (kernels.hpp k_advance_team) for one query and squared bound, replayed on the
+    host -> (n_inside or a negative code where the device would leave the query to k_lin, idx[7], d2[7]: the seven nearest below the bound)"""
+    q = np.ascontiguousarray(q, np.float32).reshape(3)
+    idx = np.full(7, -1, np.int32); d2 = np.full(7, np.inf, np.float32)
+    n = lib().emu_ball_query(index.ptr, _ptr(q), float(bound), _ptr(idx), _ptr(d2))
+    return int(n), idx, d2
 
 
 class Source:

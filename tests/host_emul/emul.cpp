@@ -438,6 +438,69 @@ void emu_block_rows(void *idx, const float *q_xyz, const float *bounds, int64_t 
             team_row(E->g, q_xyz[3 * i], q_xyz[3 * i + 1], q_xyz[3 * i + 2], bounds[i], r % 3 - 1, r / 3 - 1, out[(i * 9 + r) * 2], out[(i * 9 + r) * 2 + 1]);
 }
 
+// Scalar replay of the row enumeration of kernels.hpp k_advance_team for ONE query and bound: the rows of the ball (every row of its
+// bounding square when that is at most sixteen rows, else the rows whose occupancy bit is set in the words of the ball's z layers - one
+// lane per layer on the device, two words x two 16-cell x blocks each), every row cut to the ball by ball_row; all points of those runs
+// with a float distance below the bound, ranked by (distance bits, original index).  out_idx / out_d2: the first seven (-1 / inf where
+// fewer); returns the number of points inside the bound, or -1 - k where the device would leave the query to k_lin (k = 1: more layers
+// than lanes, 2: a layer wider than one lane reads, 3: more than 64 occupied rows).
+int64_t emu_ball_query(void *idx, const float *q, float bound, int32_t *out_idx, float *out_d2) {
+    EmuIndex *E = (EmuIndex *)idx;
+    const GridDev &g = E->g;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const BallCells bc = ball_cells(g, qx, qy, qz, bound);
+    const int ny_r = bc.yhi - bc.ylo + 1, nz_r = bc.zhi - bc.zlo + 1;
+    std::vector<std::pair<int, int>> rows;
+    if (ny_r * nz_r <= 16) {
+        for (int k = 0; k < ny_r * nz_r; ++k) rows.push_back({bc.ylo + k % ny_r, bc.zlo + k / ny_r});
+    } else {
+        if (nz_r > 16 || !g.ymask) return -2;
+        for (int gl = 0; gl < nz_r; ++gl) {
+            const int dz = bc.zlo + gl, z = bc.cz + dz;
+            if (z < 0 || z >= g.nz) continue;
+            const float hf = (float)g.h;
+            const float gz = dz < 0 ? ((float)(-dz - 1) + bc.frz) * hf : (dz > 0 ? ((float)dz - bc.frz) * hf : 0.f);
+            const float rem = bound - gz * gz * 0.99999f;
+            if (rem < 0.f) continue;
+            const float rc = fminf(sqrt_approx(rem) * 1.00001f * (float)g.inv_h + 1e-4f, 1.0e6f);
+            const int cap = 1 << 24;
+            const int ylo = -std::min(cap, (int)floorf(rc + 1.f - bc.fry)), yhi = std::min(cap, (int)floorf(rc + bc.fry));
+            const int xlo = -std::min(cap, (int)floorf(rc + 1.f - bc.frx)), xhi = std::min(cap, (int)floorf(rc + bc.frx));
+            const int y0 = std::max(bc.cy + ylo, 0), y1 = std::min(bc.cy + yhi, g.ny - 1);
+            const int b0 = std::max(bc.cx + xlo, 0) >> 4, b1 = std::min(bc.cx + xhi, g.nx - 1) >> 4;
+            if (y1 < y0 || b1 < b0) continue;
+            if (((y1 >> 5) - (y0 >> 5)) > 1 || b1 - b0 > 1) return -3;
+            const int yw0 = y0 >> 5, yw1 = y1 >> 5, bb = std::min(b0 + 1, b1);
+            const uint32_t *mw = g.ymask + ((int64_t)z * g.nxb + b0) * g.nyw, *mv = g.ymask + ((int64_t)z * g.nxb + bb) * g.nyw;
+            uint32_t m0 = mw[yw0] | mv[yw0], m1 = yw1 > yw0 ? (mw[yw1] | mv[yw1]) : 0u;
+            const int base0 = yw0 << 5;
+            { const int lo = std::max(y0 - base0, 0), hi = std::min(y1 - base0, 31); m0 &= (0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo); }
+            if (yw1 > yw0) { const int hi = std::min(y1 - (base0 + 32), 31); m1 &= (0xFFFFFFFFu >> (31 - hi)); }
+            for (int b = 0; b < 32; ++b) if (m0 & (1u << b)) rows.push_back({base0 + b - bc.cy, dz});
+            for (int b = 0; b < 32; ++b) if (m1 & (1u << b)) rows.push_back({base0 + 32 + b - bc.cy, dz});
+        }
+        if (rows.size() > 64) return -4;
+    }
+    struct Ent { uint64_t key; float d2; uint32_t idx; };
+    std::vector<Ent> list;
+    for (const auto &r : rows) {
+        uint32_t s_ = 0, e_ = 0;
+        ball_row(g, bc, bound, r.first, r.second, s_, e_);
+        for (uint32_t p = s_; p < e_; ++p) {
+            const float4 c = g.pts[p];
+            const float d2 = dist2_nofma(qx, qy, qz, c);
+            if (d2 < bound) list.push_back(Ent{((uint64_t)__float_as_uint(d2) << 32) | __float_as_uint(c.w), d2, __float_as_uint(c.w)});
+        }
+    }
+    std::sort(list.begin(), list.end(), [](const Ent &x, const Ent &y) { return x.key < y.key; });
+    for (int j = 0; j < 7; ++j) {
+        const bool got = (size_t)j < list.size();
+        out_idx[j] = got ? (int32_t)list[(size_t)j].idx : -1;
+        out_d2[j] = got ? list[(size_t)j].d2 : INFINITY;
+    }
+    return (int64_t)list.size();
+}
+
 // plane fit alone: Q = 5 neighbours (row-major 5x3); fast = 1 -> plane_fit_qr_fast
 void emu_plane_fit(const double *Q, int fast, double x[3]) {
     double qx[5], qy[5], qz[5];

@@ -348,3 +348,38 @@ def test_far_from_the_origin_and_very_dense_cells():
     bi, bd = emul.knn(idx, qd, k=5, max_radius=0.3)
     inside = od < np.float32(0.09)
     assert np.array_equal(bi[inside], oi[inside])
+
+
+def test_the_rows_of_a_ball_hold_every_point_inside_it():
+    """The small-frame advance pass (kernels.hpp k_advance_team) lists the (y,z) rows of a query's ball - all rows of its bounding square,
+    or the rows whose occupancy bit is set in the words of its z layers - and cuts each to the ball (search.hpp ball_cells / ball_row).
+    Replayed on the host for random queries and bounds from a fraction of a cell to a dozen cells, inside, at the border of and far
+    outside the cloud: the points it finds below the bound are EXACTLY the brute-force ones (float distances as the device forms them),
+    ranked by (distance, index)."""
+    rng = np.random.default_rng(17)
+    scenes = [(h.scene_corridor(30_000, seed=2, length=30.0), 1.0, 0.0), (h.scene_planes(20_000, seed=3), 0.5, 0.0),
+              (h.cylinder_cloud(), 1.0, 0.0), (h.scene_cylinder(20_000, seed=4, noise=0.01), 2.0, 0.12)]
+    served = left = 0
+    for tgt, radius, cell in scenes:
+        idx = emul.Index(tgt, radius, cell=cell)
+        t32 = tgt.astype(np.float32)
+        for case in range(300):
+            base = t32[rng.integers(0, len(t32))]
+            q = (base + rng.normal(0, float(rng.choice([0.0, 0.01, 0.3, 3.0])), 3)).astype(np.float32)
+            if case % 50 == 0:
+                q = (t32.max(0) + np.float32(rng.uniform(0.0, 40.0))).astype(np.float32)          # beyond a corner of the grid
+            r = float(rng.choice([0.05, 0.3, 1.0])) * radius * 1.05
+            bound = np.float32(r * r)
+            n, got_idx, got_d2 = emul.ball_query(idx, q, bound)
+            if n < 0:
+                left += 1
+                continue
+            served += 1
+            d = t32 - q                                                   # float32, un-fused, (x^2 + y^2) + z^2: dist2_nofma
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            inside = np.flatnonzero(d2 < bound)
+            assert n == len(inside), (case, n, len(inside), q, r)
+            order = inside[np.lexsort((inside, d2[inside].view(np.uint32)))][:7]
+            assert np.array_equal(got_idx[:len(order)], order.astype(np.int32)) and np.all(got_idx[len(order):] == -1), (case, got_idx, order)
+            assert np.array_equal(got_d2[:len(order)].view(np.uint32), d2[order].view(np.uint32))
+    assert served > 900 and left < 200, (served, left)
