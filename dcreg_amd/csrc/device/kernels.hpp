@@ -348,7 +348,7 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
 constexpr int kLinDepth = DCREG_LIN_DEPTH;        // register sets of k_lin's candidate pipeline (search.hpp knn_search DEPTH)
 // points per block of the advance pass (k_advance below): kAdvTile / kLinBlock query blocks of k_lin
 #if !defined(DCREG_ADV_TILE)
-#define DCREG_ADV_TILE 1024
+#define DCREG_ADV_TILE 1536
 #endif
 constexpr int kAdvTile = DCREG_ADV_TILE;
 static_assert(kAdvTile % kLinBlock == 0 && kAdvTile <= 65536, "a tile is a whole number of query blocks; list entries are 16-bit offsets");
