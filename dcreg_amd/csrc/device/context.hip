@@ -593,21 +593,25 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         }
         if (gated) {
             if (!c->h_gate) {     // all or nothing: a half-built gate would be taken for a whole one by the next call
-                GateHost *hg = nullptr; PoseArg *dp = nullptr; uint32_t *da = nullptr;
+                GateHost *hg = nullptr; PoseArg *dp = nullptr; uint32_t *da = nullptr; GateDev *gd = nullptr;
                 bool ok = hipHostMalloc((void **)&hg, sizeof(GateHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
                 ok = ok && hipMalloc((void **)&dp, sizeof(PoseArg)) == hipSuccess && hipMalloc((void **)&da, sizeof(uint32_t)) == hipSuccess;
+                // (the device copy of the record, for launches gated in their first kernel: cleared IN THE STREAM - the ctx stream does not
+                //  synchronise with the null stream)
+                ok = ok && hipMalloc((void **)&gd, sizeof(GateDev)) == hipSuccess && hipMemsetAsync(gd, 0, sizeof(GateDev), c->stream) == hipSuccess;
                 void *dgh = nullptr;
                 ok = ok && hipHostGetDevicePointer(&dgh, hg, 0) == hipSuccess;
                 if (!ok) {
                     if (hg) (void)hipHostFree(hg);
                     if (dp) (void)hipFree(dp);
                     if (da) (void)hipFree(da);
+                    if (gd) (void)hipFree(gd);
                     c->state_valid = state_was_valid;
                     c->fail("allocating the launch gate failed");
                     return DCREG_E_NOMEM;
                 }
                 std::memset(hg, 0, sizeof(GateHost));
-                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_pose = dp; c->d_gate_abort = da;
+                c->h_gate = hg; c->d_gate_host = (GateHost *)dgh; c->d_gate_pose = dp; c->d_gate_abort = da; c->d_gate_dev = gd;
             }
             d_poses = c->d_gate_pose;
         }
@@ -724,10 +728,22 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         c->fail("%s failed: %s", what, hipGetErrorString(e));
         return DCREG_E_DEVICE;
     };
+    // A gated launch the device holds at once (at most kChunk query blocks) waits for its pose in its FIRST kernel instead of behind a
+    // gate kernel (kernels.hpp gate_wait: one kernel boundary less on a launch that lasts a few microseconds); larger launches keep
+    // k_gate (every wave would pay for the wait: profiles/r04_gate_in_kernel.txt)
+    GateArgs gt{nullptr, nullptr, 0ull, nullptr, nullptr, 0u};
+    const bool gate_inside = gated && c->opt_gate_in_kernel && nbx <= (uint32_t)kChunk && !adv && !dbg_host;
+    const PoseArg *lin_poses = d_poses;            // what k_lin reads its pose from (null: pose1)
     if (gated) {
         const unsigned long long want = ++c->gate_seq;
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, one.fresh, c->d_gate_abort);
-        abort_flag = c->d_gate_abort;
+        if (gate_inside) {
+            gt = GateArgs{c->d_gate_host, c->d_gate_dev, want, team ? c->d_gate_pose : nullptr, team ? c->d_gate_abort : nullptr, one.fresh};
+            if (team) abort_flag = c->d_gate_abort;        // (k_lin behind the teams reads what their polling wave left, as behind k_gate)
+            else lin_poses = nullptr;                      // (k_lin itself is the gated kernel: pose1 carries state / fresh)
+        } else {
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, c->d_gate_host, want, c->d_gate_pose, one.fresh, c->d_gate_abort);
+            abort_flag = c->d_gate_abort;
+        }
     }
     if (timed) {                           // after the gate: the events bracket the linearisation, not the wait for the pose
         const hipError_t ee = hipEventRecord(S.ev0, c->stream);
@@ -748,8 +764,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
             (void)hipMemsetAsync(c->d_team_stamps, 0, sizeof(unsigned long long) * 8 * (n_tiles + 1), c->stream);
             stamps = c->d_team_stamps; c->team_stamps_n = n_tiles;
         }
-        if (fast) hipLaunchKernelGGL((k_advance_team<true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag, stamps);
-        else hipLaunchKernelGGL((k_advance_team<false>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag, stamps);
+        if (gate_inside) {      // the teams are the gated kernel
+            if (fast) hipLaunchKernelGGL((k_advance_team<true, true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, (const PoseArg *)nullptr, a, c->d_adv_counts, (const uint32_t *)nullptr, stamps, gt);
+            else hipLaunchKernelGGL((k_advance_team<false, true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, (const PoseArg *)nullptr, a, c->d_adv_counts, (const uint32_t *)nullptr, stamps, gt);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_advance_team<true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag, stamps, gt);
+            else hipLaunchKernelGGL((k_advance_team<false>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a, c->d_adv_counts, abort_flag, stamps, gt);
+        }
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) return bail("team advance pass launch", le);
         c->n_advance_launches += 1;
@@ -757,8 +778,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     {
         const dim3 grid(nbx, (unsigned)n_poses);
 #define DCREG_LAUNCH_LIN(MODE, FUSED, FAST)                                                                                              \
-    hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, d_poses, a,    \
-                       S.d_partials, nbx, fin, dd, abort_flag)
+    hipLaunchKernelGGL((k_lin<MODE, FUSED, FAST>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a,  \
+                       S.d_partials, nbx, fin, dd, abort_flag, gt)
+        if (gate_inside && !team) {        // k_lin is the gated kernel (fused, MODE 0: a gated launch is never a dump)
+            if (fast) hipLaunchKernelGGL((k_lin<0, true, true, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a, S.d_partials, nbx, fin, dd, abort_flag, gt);
+            else hipLaunchKernelGGL((k_lin<0, true, false, true>), grid, dim3(kLinBlock), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a, S.d_partials, nbx, fin, dd, abort_flag, gt);
+        } else
         if (stamps_only) { if (fast) DCREG_LAUNCH_LIN(2, true, true); else DCREG_LAUNCH_LIN(2, true, false); }     // (the probe writes the shared state: same fit as the plain launches)
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
@@ -1050,6 +1075,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     if (c->d_euler) (void)hipFree(c->d_euler);
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
+    if (c->d_gate_dev) (void)hipFree(c->d_gate_dev);
     if (c->d_group_est) (void)hipFree(c->d_group_est);
     kdtree_free(c->kd); c->kd = nullptr;
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
@@ -1110,6 +1136,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
+    else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)
     else if (k == "team_stamps") c->opt_team_stamps = v != 0.0;   // timing probe of the small-frame pass (dcreg_team_pass_stamps)
     else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "team_pass_max_points") c->opt_team_pass_max_points = v;

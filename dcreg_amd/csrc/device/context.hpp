@@ -109,6 +109,8 @@ struct dcreg_ctx {
     dcreg::GateHost *h_gate = nullptr, *d_gate_host = nullptr;
     dcreg::PoseArg *d_gate_pose = nullptr;
     uint32_t *d_gate_abort = nullptr;
+    dcreg::GateDev *d_gate_dev = nullptr;  // device copy of the gate record: launches gated in their first kernel (kernels.hpp gate_wait)
+    bool opt_gate_in_kernel = true;
     unsigned long long gate_seq = 0;       // number of the gated launch last queued
     int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)
     bool gate_uses_state = false;          // what the queued launch was built with: it reads / writes the ctx's own state,

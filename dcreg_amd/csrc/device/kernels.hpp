@@ -281,6 +281,91 @@ static __global__ __launch_bounds__(64) void k_gate(const GateHost *__restrict__
     if (lane == 0) { dst->state = 0; dst->fresh = fresh; *abort_flag = (uint32_t)(seq & 1ull); }
 }
 
+// ---- the gate INSIDE the first kernel of a small launch (round 5; round 4 measured both forms: profiles/r04_gate_in_kernel.txt).  A
+// launch of a few dozen blocks lasts 4-10 us, and the boundary between the one-wave gate kernel and it is 1.5 us of that; a launch of
+// thousands of blocks pays 2 us for the instructions below in every wave instead.  So: launches the device holds at once (at most
+// kChunk query blocks: the fixture, a LiDAR frame) wait for their pose themselves - every wave requests the DEVICE copy of the gate
+// record together with its first loads (a wave dispatched after the pose has reached the device finds it whole and its own: no extra
+// round trip), the first wave of the launch polls the host record and fills the device copy (and, for the kernels queued behind this
+// one, the device-resident PoseArg and abort word k_gate would have filled) - and large launches keep k_gate.
+struct alignas(128) GateDev { unsigned long long w[16]; };   // w[0] = (launch number << 1) | abort, w[1..12] = R, t, w[13] = checksum (as GateHost)
+struct GateArgs {
+    const GateHost *host; GateDev *dev;
+    unsigned long long want;           // this launch's number
+    PoseArg *pose_out; uint32_t *abort_out;     // what the kernels behind this one read (null: nothing is queued behind the gated kernel)
+    uint32_t fresh;
+};
+// one lane-parallel read of a 14-word gate record (host or device copy): the words (lane l < 14 holds w[l]) and whether they form a
+// whole record (checksum) - uniform results in `seq` (w[0]) and the return value.  All 64 lanes of the wave call.
+template <int SCOPE>
+__device__ __forceinline__ bool gate_read(const unsigned long long *rec, unsigned long long &v, unsigned long long &seq) {
+    const int lane = threadIdx.x & 63;
+    v = lane < kGateWords ? __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, SCOPE) : 0ull;
+    unsigned long long x = v;          // xor of all the record's words (lanes beyond it contribute 0): the salt when the record is whole
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+        x ^= ((unsigned long long)hi << 32) | lo;
+    }
+    const uint32_t slo = __builtin_amdgcn_readfirstlane((uint32_t)v), shi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    seq = ((unsigned long long)shi << 32) | slo;
+    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)x), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return (((unsigned long long)xhi << 32) | xlo) == kGateSalt;
+}
+// Called by every wave of a launch gated in the kernel, convergently, once its pose-independent loads are in flight; v / seq / whole = the
+// wave's read of the DEVICE record (gate_read<agent>, requested with those loads).  Returns false when the launch was called off.
+__device__ __forceinline__ bool gate_wait(const GateArgs &gt, unsigned long long v, unsigned long long seq, bool whole, PoseArg &P) {
+    const int lane = threadIdx.x & 63;
+    GateDev *gd = gt.dev;
+    if (!(whole && (seq >> 1) == gt.want)) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+            // the polling wave: host record -> device record
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long hv = 0, hseq = 0;
+            bool call_off = false;
+            for (;;) {
+                const bool hw = gate_read<__HIP_MEMORY_SCOPE_SYSTEM>(gt.host->w, hv, hseq);
+                if ((hseq >> 1) == gt.want && hw) { call_off = (hseq & 1ull) != 0ull; break; }
+                // a whole record with a LATER number: the host has moved on, i.e. it called this launch off before this wave ever ran
+                if (((hseq >> 1) > gt.want && hw) || wall_clock64() - t0 > kGateTimeoutTicks) { call_off = true; break; }     // (or nobody opens)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (call_off) {             // an abort record of this launch's number (the pose words are whatever they were: nobody reads them)
+                hv = lane == 0 ? ((gt.want << 1) | 1ull) : (lane < kGateWords - 1 ? hv : 0ull);
+                unsigned long long x = lane < kGateWords - 1 ? hv : 0ull;
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), m);
+                    x ^= ((unsigned long long)hi << 32) | lo;
+                }
+                if (lane == kGateWords - 1) hv = x ^ kGateSalt;
+            }
+            if (gt.pose_out) {          // what k_gate would have left for the kernels queued behind this one
+                if (lane >= 1 && lane <= 12) {
+                    const double d = __longlong_as_double((long long)hv);
+                    if (lane <= 9) gt.pose_out->R[lane - 1] = d; else gt.pose_out->t[lane - 10] = d;
+                }
+                if (lane == 0) { gt.pose_out->state = 0; gt.pose_out->fresh = gt.fresh; *gt.abort_out = call_off ? 1u : 0u; }
+            }
+            if (lane < kGateWords) __hip_atomic_store(&gd->w[lane], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // every wave that came too early (the polling one included): until the device record is whole and this launch's
+        for (;;) {
+            whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gd->w, v, seq);
+            if (whole && (seq >> 1) == gt.want) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if ((seq & 1ull) != 0ull) return false;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k + 1), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k + 1);
+        const double d = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        if (k < 9) P.R[k] = d; else P.t[k - 9] = d;
+    }
+    return true;
+}
+
 // ---- the common tail of a block: the wave's rows -> its Gram matrix and counts in LDS (the wave's LDS staging area must be free) ...
 // gm: where this wave's 8x8 Gram matrix goes (64 doubles; may be the head of its own staging area: the operand reads are over by then)
 __device__ __forceinline__ void wave_rows_to_lds(const double (&row)[8], uint8_t flag, double *stage, double *gm, double (*cnt)[2],
@@ -354,11 +439,11 @@ constexpr int kAdvTile = DCREG_ADV_TILE;
 static_assert(kAdvTile % kLinBlock == 0 && kAdvTile <= 65536, "a tile is a whole number of query blocks; list entries are 16-bit offsets");
 
 // ---------------------------------------------------------------- k_lin
-template <int MODE, bool FUSED, bool FAST>
+template <int MODE, bool FUSED, bool FAST, bool GATE = false>
 static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
-                                                          DebugDev dbg, const uint32_t *__restrict__ abort_flag) {
+                                                          DebugDev dbg, const uint32_t *__restrict__ abort_flag, GateArgs gt) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
     __shared__ double red[kLinBlock / 32][kSlots];
     __shared__ double cnt[kLinBlock / 64][2];
@@ -409,6 +494,11 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
         const uint4 v0 = SV0[i];
         p01 = SV1[i]; p23 = SV2[i];
         cert = v0.x; fitw = v0.y; q0[0] = v0.z; q0[1] = v0.w; q0[2] = SW3[i];
+    }
+    if constexpr (GATE) {      // a small launch gated in the kernel: the pose arrives now, the loads above are in flight meanwhile (pose1: state / fresh)
+        unsigned long long gate_v = 0ull, gate_seq = 0ull;
+        const bool gate_whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gt.dev->w, gate_v, gate_seq);
+        if (!gate_wait(gt, gate_v, gate_seq, gate_whole, P)) return;       // called off: every wave returns here, before any barrier
     }
     float qx, qy, qz;
     body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
@@ -756,10 +846,10 @@ struct TeamPassLds {
     uint32_t o_d2[4][8], o_pos[4][8], o_idx[4][8];
     float o_x[4][8], o_y[4][8], o_z[4][8];
 };
-template <bool FAST>
+template <bool FAST, bool GATE = false>
 static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
                                                              const PoseArg *__restrict__ poses, LinArgs a, uint32_t *__restrict__ counts,
-                                                             const uint32_t *__restrict__ abort_flag, unsigned long long *__restrict__ stamps) {
+                                                             const uint32_t *__restrict__ abort_flag, unsigned long long *__restrict__ stamps, GateArgs gt) {
     if (abort_flag && *abort_flag != 0u) return;
     __shared__ TeamPassLds L;
     // (timing probe, option "team_stamps": lane 0 stores the shader clock at the phase boundaries of the block's first round - eight words per block)
@@ -790,9 +880,14 @@ static __global__ __launch_bounds__(kWave) void k_advance_team(const float4 *__r
         uint4 v0 = make_uint4(0u, 0u, 0u, 0u), x = make_uint4(kNoIdx, kNoIdx, kNoIdx, kNoIdx);
         uint2 y = make_uint2(kNoIdx, kNoIdx);
         uint32_t w3 = 0u;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have) { s4 = src[i]; v0 = SV0[i]; w3 = SW3[i]; x = SX[i]; y = SY[i]; }
+        if constexpr (GATE) {  // gated in the kernel: the pose arrives now, the loads above are in flight meanwhile (pose1: state / fresh)
+            unsigned long long gate_v = 0ull, gate_seq = 0ull;
+            const bool gate_whole = gate_read<__HIP_MEMORY_SCOPE_AGENT>(gt.dev->w, gate_v, gate_seq);
+            if (!gate_wait(gt, gate_v, gate_seq, gate_whole, P)) return;
+        }
         if (have) {
-            const float4 s4 = src[i];
-            v0 = SV0[i]; w3 = SW3[i]; x = SX[i]; y = SY[i];
             body_to_global(P, (double)s4.x, (double)s4.y, (double)s4.z, qx, qy, qz);
             const float q0x = __uint_as_float(v0.z), q0y = __uint_as_float(v0.w), q0z = __uint_as_float(w3);
             const bool need = !cert_holds(v0.x, q0x, q0y, q0z, qx, qy, qz);

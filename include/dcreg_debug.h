@@ -100,6 +100,8 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *                        for clouds of at most "team_pass_max_points" (16384) points when the last completed launch searched at least
  *                        "team_pass_min_frac" (0.5) of them and the map holds at least "team_pass_min_cell_pts" (3) points per occupied
  *                        cell, 2 = whenever the launch can take it; "team_stamps": see dcreg_team_pass_stamps;
+ *   "gate_in_kernel"     1 (default) = a pipelined launch of at most 64 query blocks waits for its pose in its first kernel (one kernel boundary
+ *                        less); 0 = behind the one-wave gate kernel, like larger launches;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
  *   "fused_batches"      1 (default) = a batched launch whose poses have at most 64 query blocks each finishes inside the kernel (the last block
  *                        of a pose sums and publishes the pose's row); 0 = a k_finalize launch behind it, as for larger poses;
