@@ -200,3 +200,55 @@ def test_bounded_hunt_for_the_advance_passes():
     spec = importlib.util.spec_from_file_location("fuzz_passes", os.path.join(h.REPO, "scripts", "fuzz_passes.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     assert mod.run(40, 20260928, verbose=False) == 0
+
+
+@pytest.mark.parametrize("team", [0, 2])
+def test_small_launches_gated_in_their_first_kernel(team):
+    """A pipelined launch of at most 64 query blocks waits for its pose inside its first kernel (k_lin, or k_advance_team when the teams
+    run) instead of behind the gate kernel.  The protocol of test_gated_launches_equal_blocking_ones on the fixture, with the gate inside
+    and - option "gate_in_kernel" 0 - behind k_gate: bitwise the blocking results; a launch that is called off leaves results and state
+    untouched; called off and the next one published at once (the polling wave may only start when the record already carries the later
+    number); a context destroyed with a gate still waiting."""
+    tgt = h.cylinder_cloud()
+    src = tgt[::3]
+    prm = api.default_lin_params(1.0, 1)
+    poses = [h.pose6d_matrix(0.05 * k, -0.03 * k, 0.02, h.deg2rad(0.3 * k), 0.0, h.deg2rad(-0.2 * k)) for k in range(6)]
+    ref = api.Context(0)
+    ref.set_option("team_pass", 0)
+    ref.set_target(tgt, 1.0); ref.set_source(src)
+    want = [ref.linearize(T[:3, :3], T[:3, 3], prm) for T in poses]
+    ref.close()
+    for inside in (1, 0):
+        c = api.Context(0)
+        c.set_option("team_pass", team); c.set_option("gate_in_kernel", inside); c.set_option("record_launches", 1)
+        c.set_target(tgt, 1.0); c.set_source(src)
+        slot = 0
+        c.linearize_begin(poses[0][:3, :3], poses[0][:3, 3], prm, slot=slot)
+        got = []
+        for k in range(len(poses)):
+            last = k + 1 == len(poses)
+            if not last:
+                c.linearize_gated_begin(prm, slot=slot ^ 1)
+            got.append(c.linearize_end(slot=slot))
+            if not last:
+                c.gate_open(poses[k + 1][:3, :3], poses[k + 1][:3, 3])
+                slot ^= 1
+        for a, b in zip(got, want):
+            assert _same_sums(a, b), (team, inside)
+        assert (c.launch_series(reset=True)["advanced"][1:] == team).all()
+        c.linearize_gated_begin(prm, slot=1)
+        c.gate_abort()
+        again = c.linearize(poses[-1][:3, :3], poses[-1][:3, 3], prm)
+        assert _same_sums(again, want[-1])
+        for _ in range(20):
+            c.linearize_gated_begin(prm, slot=1)
+            c.gate_abort()
+            c.linearize_gated_begin(prm, slot=1)
+            c.gate_open(poses[-2][:3, :3], poses[-2][:3, 3])
+            out = c.linearize_end(slot=1)
+            assert _same_sums(out, want[-2])
+            c.linearize_gated_begin(prm, slot=0)
+            c.gate_open(poses[-1][:3, :3], poses[-1][:3, 3])
+            assert _same_sums(c.linearize_end(slot=0), want[-1])
+        c.linearize_gated_begin(prm, slot=1)
+        c.close()                                                   # destroys the context with the gate still waiting
