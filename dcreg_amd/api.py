@@ -66,6 +66,7 @@ class Config(C.Structure):
                 ("KAPPA_TARGET", C.c_double), ("PCG_TOLERANCE", C.c_double), ("PCG_MAX_ITER", C.c_int),
                 ("STD_REG_GAMMA", C.c_double), ("ADAPTIVE_REG_ALPHA", C.c_double),
                 ("use_weight_derivative", C.c_int), ("always_compute_schur", C.c_int),
+                ("euler_exact_jacobian", C.c_int), ("reserved_cfg_", C.c_int),
                 ("gt_matrix", C.c_double * 16)]
 
 
@@ -250,14 +251,15 @@ def default_config(**kw):
     return cfg
 
 
-def default_lin_params(search_radius=1.0, use_weight_derivative=0, euler_rpy=None):
-    """euler_rpy = (roll, pitch, yaw): the Euler / LOAM row of the second engine (R, t passed to linearize must be the
-    pose6d_matrix of that pose)."""
+def default_lin_params(search_radius=1.0, use_weight_derivative=0, euler_rpy=None, euler_exact=False):
+    """euler_rpy = (roll, pitch, yaw): the Euler row of the second engine (R, t passed to linearize must be the pose6d_matrix of
+    that pose) - DCREG_PARAM_EULER = as the reference writes it (icp_test_runner.cpp:2299-2346), euler_exact =
+    DCREG_PARAM_EULER_EXACT, the exact roll / pitch / yaw derivative."""
     p = LinParams()
     load().dcreg_default_lin_params(C.byref(p), float(search_radius))
     p.use_weight_derivative = int(use_weight_derivative)
     if euler_rpy is not None:
-        p.parameterization = 1
+        p.parameterization = 2 if euler_exact else 1
         p.euler_rpy[:] = [float(v) for v in euler_rpy]
     return p
 

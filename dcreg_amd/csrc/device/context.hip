@@ -375,28 +375,56 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     a.max_ring = k;
     c->last_max_ring = k;
     a.count_scale = c->n_src < ((int64_t)1 << 26) ? kCountScale : 0.0;      // (strictly below: a count of 2^26 would read as one more of the number riding above it)
-    a.euler = p->parameterization == DCREG_PARAM_EULER ? 1 : 0;
-    if (p->parameterization != DCREG_PARAM_SO3 && p->parameterization != DCREG_PARAM_EULER) { c->fail("unknown parameterization"); return DCREG_E_INVALID; }
+    a.euler = p->parameterization != DCREG_PARAM_SO3 ? 1 : 0;
+    if (p->parameterization != DCREG_PARAM_SO3 && p->parameterization != DCREG_PARAM_EULER && p->parameterization != DCREG_PARAM_EULER_EXACT) { c->fail("unknown parameterization"); return DCREG_E_INVALID; }
     a.dR = nullptr;
-    if (a.euler) {   // derivatives of R = Rz(yaw) Ry(pitch) Rx(roll) (Pose6D2Matrix, utils.hpp:452-460), handed over in device memory
-        const double cr = std::cos(p->euler_rpy[0]), sr = std::sin(p->euler_rpy[0]);
-        const double cp = std::cos(p->euler_rpy[1]), sp = std::sin(p->euler_rpy[1]);
-        const double cy = std::cos(p->euler_rpy[2]), sy = std::sin(p->euler_rpy[2]);
-        const double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, dRx[9] = {0, 0, 0, 0, -sr, -cr, 0, cr, -sr};
-        const double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, dRy[9] = {-sp, 0, cp, 0, 0, 0, -cp, 0, -sp};
-        const double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1}, dRz[9] = {-sy, -cy, 0, cy, -sy, 0, 0, 0, 0};
-        auto mul3 = [](const double *A, const double *B, const double *C3, double *out) {
-            double T[9];
-            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j]; T[i * 3 + j] = s; }
-            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * C3[k * 3 + j]; out[i * 3 + j] = s; }
-        };
+    if (a.euler) {
+        // The kernel's Euler branch (search.hpp row_of_plane) evaluates, for k = 0 (roll column) / 1 (pitch) / 2 (yaw),
+        //     A[k] = c.x (D[9k+0] p.y + D[9k+1] p.z + D[9k+2] p.x) + c.y (D[9k+3] p.y + ...) + c.z (D[9k+6] p.y + ...)
+        // - the shape of icp_test_runner.cpp:2323-2335 with its axis relabelling (pointOri = (p.y, p.z, p.x), coeff = (c.y, c.z, c.x)) undone for c
+        // and kept for p, so that every product and every sum is taken in the order of the source text.  The 27 coefficients come from here.
         if (!c->h_euler) {
             HIP_TRY(c, hipHostMalloc((void **)&c->h_euler, 27 * sizeof(double), hipHostMallocDefault));
             HIP_TRY(c, hipMalloc((void **)&c->d_euler, 27 * sizeof(double)));
         }
         // (the staging block is reused: the launches of the Euler engine are blocking calls, one at a time)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        mul3(Rz, Ry, dRx, c->h_euler); mul3(Rz, dRy, Rx, c->h_euler + 9); mul3(dRz, Ry, Rx, c->h_euler + 18);
+        double *D = c->h_euler;
+        if (p->parameterization == DCREG_PARAM_EULER) {
+            // the reference's row, literally (:2299-2346): srx / crx of PITCH, sry / cry of YAW, srz / crz of ROLL; the brackets of arx times coeff.z,
+            // coeff.x, coeff.y (LOAM: x, y, z), of ary times coeff.z, coeff.y, of arz times coeff.z, coeff.x, coeff.y; matA row = [arz, arx, ary, ...]
+            const double srx = std::sin(p->euler_rpy[1]), crx = std::cos(p->euler_rpy[1]);
+            const double sry = std::sin(p->euler_rpy[2]), cry = std::cos(p->euler_rpy[2]);
+            const double srz = std::sin(p->euler_rpy[0]), crz = std::cos(p->euler_rpy[0]);
+            const double crx_sry = crx * sry, crz_sry = crz * sry, srx_sry = srx * sry, srx_srz = srx * srz;   // :2319-2322
+            // arz (:2331-2335) -> column 0
+            D[0] = crz * srx_sry - cry * srz;   D[1] = -cry * crz - srx_sry * srz;   D[2] = 0.0;      // x coeff.z (= c.x)
+            D[3] = crx * crz;                   D[4] = -(crx * srz);                 D[5] = 0.0;      // x coeff.x (= c.y)
+            D[6] = sry * srz + cry * crz * srx; D[7] = crz_sry - cry * srx_srz;      D[8] = 0.0;      // x coeff.y (= c.z)
+            // arx (:2323-2326) -> column 1
+            D[9] = crx_sry * srz;               D[10] = crx * crz_sry;               D[11] = -srx_sry;        // x coeff.z
+            D[12] = -srx_srz;                   D[13] = -(crz * srx);                D[14] = -crx;            // x coeff.x
+            D[15] = crx * cry * srz;            D[16] = crx * cry * crz;             D[17] = -(cry * srx);    // x coeff.y
+            // ary (:2327-2330) -> column 2 (no coeff.x bracket)
+            D[18] = cry * srx_srz - crz_sry;    D[19] = sry * srz + cry * crz * srx; D[20] = crx * cry;       // x coeff.z
+            D[21] = 0.0;                        D[22] = 0.0;                         D[23] = 0.0;
+            D[24] = -cry * crz - srx_sry * srz; D[25] = cry * srz - crz * srx_sry;   D[26] = -crx_sry;        // x coeff.y
+        } else {
+            // exact derivatives of R = Rz(yaw) Ry(pitch) Rx(roll) (Pose6D2Matrix, utils.hpp:452-460), columns in the kernel's (p.y, p.z, p.x) order
+            const double cr = std::cos(p->euler_rpy[0]), sr = std::sin(p->euler_rpy[0]);
+            const double cp = std::cos(p->euler_rpy[1]), sp = std::sin(p->euler_rpy[1]);
+            const double cy = std::cos(p->euler_rpy[2]), sy = std::sin(p->euler_rpy[2]);
+            const double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, dRx[9] = {0, 0, 0, 0, -sr, -cr, 0, cr, -sr};
+            const double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, dRy[9] = {-sp, 0, cp, 0, 0, 0, -cp, 0, -sp};
+            const double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1}, dRz[9] = {-sy, -cy, 0, cy, -sy, 0, 0, 0, 0};
+            auto mul3 = [](const double *A, const double *B, const double *C3, double *out) {
+                double T[9], O[9];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j]; T[i * 3 + j] = s; }
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * C3[k * 3 + j]; O[i * 3 + j] = s; }
+                for (int i = 0; i < 3; ++i) { out[i * 3 + 0] = O[i * 3 + 1]; out[i * 3 + 1] = O[i * 3 + 2]; out[i * 3 + 2] = O[i * 3 + 0]; }
+            };
+            mul3(Rz, Ry, dRx, D); mul3(Rz, dRy, Rx, D + 9); mul3(dRz, Ry, Rx, D + 18);
+        }
         HIP_TRY(c, hipMemcpyAsync(c->d_euler, c->h_euler, 27 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         a.dR = c->d_euler;
     }

@@ -148,8 +148,8 @@ struct LinArgs {
                                   // null: no pass in front
     float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
                                   // reaches this many cells beyond the distance to that cell (lin_search6)
-    int euler;                    // 1: LOAM roll/pitch/yaw row (second engine, :2296-2347) instead of the SO(3) row
-    const double *dR;             // euler: 27 doubles in device memory - dR/droll, dR/dpitch, dR/dyaw of R = Rz(yaw) Ry(pitch) Rx(roll),
+    int euler;                    // 1: roll/pitch/yaw row of the second engine (:2299-2346) instead of the SO(3) row
+    const double *dR;             // euler: 27 doubles in device memory - the bracket coefficients of that row (context.hip make_lin_args),
                                   // row-major (behind a pointer: as a member the 54 words would be hoisted into registers for every launch)
 };
 
@@ -1656,6 +1656,15 @@ DCREG_DEVFN uint8_t plane_of_set(const LinArgs &a, const KnnResult<5> &nn, doubl
 // itself, added over the points (row_products below; on the device the MFMA reduction of kernels.hpp), plus two counts: effective
 // points (flag 1) and points that passed the radius gate (flag != 0, :1731).  Returns flag 1 or 4; nrm / r_out / s_out receive the
 // plane normal, residual and weight.
+// one rotation entry of the Euler row (see row_of_plane): plain multiplies and adds in the order icp_test_runner.cpp:2323-2335 writes them
+DCREG_DEVFN double euler_entry(const double *D, double c0, double c1, double c2, double px, double py, double pz) {
+#pragma clang fp contract(off)
+    const double b0 = D[0] * py + D[1] * pz + D[2] * px;
+    const double b1 = D[3] * py + D[4] * pz + D[5] * px;
+    const double b2 = D[6] * py + D[7] * pz + D[8] * px;
+    return b0 * c0 + b1 * c1 + b2 * c2;
+}
+
 template <bool FASTMATH>
 DCREG_DEVFN uint8_t row_of_plane(const PoseArg &P, const LinArgs &a, const float4 &s4, float qxf, float qyf, float qzf, const double (&plane)[4],
                                  double (&row)[8], double (&nrm)[3], double &r_out, double &s_out) {
@@ -1687,14 +1696,15 @@ DCREG_DEVFN uint8_t row_of_plane(const PoseArg &P, const LinArgs &a, const float
         A[0] = w * (py * m2 - pz * m1); A[1] = w * (pz * m0 - px * m2); A[2] = w * (px * m1 - py * m0);
         A[3] = w * m0; A[4] = w * m1; A[5] = w * m2;
     } else {
-        // second engine (:2296-2347): row = [ c^T dR/droll p, c^T dR/dpitch p, c^T dR/dyaw p, c^T ] with
-        // c = the float-stored weighted normal s*n; no weight derivative, no division by s
+        // second engine (:2299-2346): row = [ arz, arx, ary, c^T ], c = the float-stored weighted normal s*n; no weight derivative, no
+        // division by s.  Every rotation entry is three brackets (linear in the point, in the reference's relabelled order y, z, x) times
+        // the three components of c: the 27 coefficients are the host's (context.hip make_lin_args) - the reference's literal trigonometric
+        // products, or with DCREG_PARAM_EULER_EXACT the derivatives of R -; sums in the order of the source text, no FMA contraction.
         const double c0 = (double)cxf, c1 = (double)cyf, c2 = (double)czf;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double *D = a.dR + 9 * k;
-            A[k] = c0 * (D[0] * px + D[1] * py + D[2] * pz) + c1 * (D[3] * px + D[4] * py + D[5] * pz) +
-                   c2 * (D[6] * px + D[7] * py + D[8] * pz);
+            A[k] = euler_entry(D, c0, c1, c2, px, py, pz);
         }
         A[3] = c0; A[4] = c1; A[5] = c2;
     }

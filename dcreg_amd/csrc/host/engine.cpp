@@ -381,7 +381,8 @@ int dcreg_icp_run_montecarlo(dcreg_ctx *ctx, const double base_xyzrpy[6], uint64
     return run_trials_core(ctx, n_trials, R0.data(), t0.data(), detection, handling, cfg, results, slots);
 }
 
-// Second engine: TestRunner::Point2PlaneICP (icp_test_runner.cpp:2064-2830), Pose6D state, LOAM Jacobian.
+// Second engine: TestRunner::Point2PlaneICP (icp_test_runner.cpp:2064-2830), Pose6D state, the Jacobian of :2299-2346 (LOAM's brackets,
+// the reference's coefficient order; include/dcreg.h enum dcreg_parameterization).
 int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, int handling, const dcreg_config *cfg,
                         dcreg_iter_log *log, int log_capacity, dcreg_icp_result *res, double final_pose6d[6]) {
     if (!ctx || !pose6d || !cfg || !res) return DCREG_E_INVALID;
@@ -392,7 +393,7 @@ int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, i
     double Hlast[36];
     for (int i = 0; i < 36; ++i) Hlast[i] = (i % 7 == 0) ? 1.0 : 0.0;
     dcreg_lin_params prm = lin_params_of(*cfg);
-    prm.parameterization = DCREG_PARAM_EULER;
+    prm.parameterization = cfg->euler_exact_jacobian ? DCREG_PARAM_EULER_EXACT : DCREG_PARAM_EULER;   // default: the row of :2299-2346 as written
     prm.use_weight_derivative = 0;                     // this engine has no weight-derivative term (:2296-2347)
     dcreg_index_info info;
     dcreg_index_info_get(ctx, &info);

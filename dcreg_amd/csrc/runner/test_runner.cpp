@@ -4,7 +4,8 @@
 // YAML keys, method-name dispatch, std::map method order, enum strings and the on-disk formats are kept, so
 // DCReg/config/icp.yaml, icp_iter.yaml and icp_pk01.yaml run unmodified apart from paths.
 // Additive keys (all optional): icp.use_weight_derivative, icp.always_compute_schur, icp.use_so3_parameterization (the
-// reference's Config field, utils.hpp:170, which its loader never reads; false selects the Euler / LOAM engine), device, test.seed,
+// reference's Config field, utils.hpp:170, which its loader never reads; false selects the Euler / LOAM engine),
+// icp.euler_exact_jacobian (default false = that engine's row as the reference writes it, :2299-2346; true = the exact derivative), device, test.seed,
 // test.perturb_trans_m, test.perturb_rot_deg (seeded per-run perturbation of initial_noise; the reference has no RNG), icp.fast_plane_fit
 // (default false HERE: the driver reproduces the reference's reports, so its plane fit is the Eigen-shaped factorisation step for step;
 // the library's own default is the reduced-instruction fit, which agrees to a few ulp - DESIGN.md).
@@ -120,6 +121,7 @@ bool loadConfig(const std::string &filename, RunnerConfig &c) {     // :20-153
             c.core.CONVERGENCE_THRESH_ROT = i["CONVERGENCE_THRESH_ROT"].as_double();
             if (i.has("use_weight_derivative")) c.core.use_weight_derivative = i["use_weight_derivative"].as_bool();
             if (i.has("always_compute_schur")) c.core.always_compute_schur = i["always_compute_schur"].as_bool();
+            if (i.has("euler_exact_jacobian")) c.core.euler_exact_jacobian = i["euler_exact_jacobian"].as_bool();
             if (i.has("use_so3_parameterization")) c.use_so3_parameterization = i["use_so3_parameterization"].as_bool();
             std::cout << "CONVERGENCE_THRESH_TRANS: " << c.core.CONVERGENCE_THRESH_TRANS << std::endl;
             std::cout << "CONVERGENCE_THRESH_ROT: " << c.core.CONVERGENCE_THRESH_ROT << std::endl;

@@ -69,14 +69,20 @@ typedef struct dcreg_lin_params {
     double weight_min;             /* 0.1,     :1785 */
     int use_weight_derivative;     /* USE_WEIGHT_DERIVATIVE, :1691 (0 = released source, 1 = paper) */
     int k;                         /* 5 (only value supported) */
-    int parameterization;          /* DCREG_PARAM_SO3 (right perturbation, math_utils.hpp:102-121) or DCREG_PARAM_EULER
-                                      (LOAM roll/pitch/yaw Jacobian of the second engine, icp_test_runner.cpp:2296-2347) */
+    int parameterization;          /* enum dcreg_parameterization below */
     int reserved_;
-    double euler_rpy[3];           /* DCREG_PARAM_EULER: roll, pitch, yaw of the pose the R passed alongside was built from
-                                      (Pose6D2Matrix: R = Rz(yaw) Ry(pitch) Rx(roll), utils.hpp:452-460) */
+    double euler_rpy[3];           /* DCREG_PARAM_EULER / _EULER_EXACT: roll, pitch, yaw of the pose the R passed alongside was built
+                                      from (Pose6D2Matrix: R = Rz(yaw) Ry(pitch) Rx(roll), utils.hpp:452-460) */
 } dcreg_lin_params;
 
-enum dcreg_parameterization { DCREG_PARAM_SO3 = 0, DCREG_PARAM_EULER = 1 };
+/* DCREG_PARAM_SO3         right perturbation on SO(3), math_utils.hpp:102-121 (first engine, icp_test_runner.cpp:1863-1907);
+ * DCREG_PARAM_EULER       the roll / pitch / yaw row of the second engine AS THE REFERENCE WRITES IT, icp_test_runner.cpp:2299-2346:
+ *                         LOAM's three brackets per angle, multiplied by coeff.z, coeff.x, coeff.y (:2323-2335) where LOAM / LIO-SAM
+ *                         multiply by coeff.x, coeff.y, coeff.z.  With the reference's order the rotation columns are not the
+ *                         derivative of the residual; this value reproduces the reference, term by term;
+ * DCREG_PARAM_EULER_EXACT additive, not in the reference: the exact derivative of c . (Rz(yaw) Ry(pitch) Rx(roll) p) by roll /
+ *                         pitch / yaw (= LOAM's coefficient order). */
+enum dcreg_parameterization { DCREG_PARAM_SO3 = 0, DCREG_PARAM_EULER = 1, DCREG_PARAM_EULER_EXACT = 2 };
 
 typedef struct dcreg_lin_out {
     double H_upper[21]; /* A^T A, row-major upper triangle, order [wx wy wz x y z] (hessian_computer.h:89-94) */
@@ -191,6 +197,9 @@ typedef struct dcreg_config {
     double STD_REG_GAMMA, ADAPTIVE_REG_ALPHA;
     int use_weight_derivative;  /* additive key: icp_test_runner.cpp:1691 as a switch */
     int always_compute_schur;   /* additive key: fill Schur/diag numbers for every method (paper traces) */
+    int euler_exact_jacobian;   /* additive key, dcreg_icp_run_euler only: 0 (default) = the reference's row (DCREG_PARAM_EULER),
+                                   1 = the exact derivative (DCREG_PARAM_EULER_EXACT) */
+    int reserved_cfg_;
     double gt_matrix[16];       /* row-major */
 } dcreg_config;
 
@@ -283,8 +292,9 @@ int dcreg_icp_run_sharded_rccl(dcreg_ctx *, const double R0[9], const double t0[
                                dcreg_icp_result *);
 
 /* The second engine of the reference (selected by Config::use_so3_parameterization == false, icp_test_runner.cpp:443-458):
- * state = Pose6D {roll, pitch, yaw, x, y, z}, LOAM Jacobian with the float-stored weighted normal and no weight
- * derivative (:2296-2347), additive update (:2633-2638), convergence on |d rmse| < 1e-4 && |d fitness| < 1e-4
+ * state = Pose6D {roll, pitch, yaw, x, y, z}, the Jacobian of :2299-2346 with the float-stored weighted normal and no weight
+ * derivative - literally, coefficient permutation included (enum dcreg_parameterization above; dcreg_config::euler_exact_jacobian
+ * selects the exact derivative instead) -, additive update (:2633-2638), convergence on |d rmse| < 1e-4 && |d fitness| < 1e-4
  * (:2679-2687), covariance mapped through the Euler->Lie Jacobian (:2695-2738).  pose6d = {roll, pitch, yaw, x, y, z};
  * final_pose6d receives the optimised pose (may be NULL).  The 6x6 analysis / handling step goes through the solver
  * seam above (the reference inlines a copy of it in this engine).  No committed trace of the reference exercises this

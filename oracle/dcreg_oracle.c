@@ -419,12 +419,43 @@ void orc_euler_dR(double roll, double pitch, double yaw, double dR[27]) {
     mat3_mul3(Rz, Ry, dRx, dR); mat3_mul3(Rz, dRy, Rx, dR + 9); mat3_mul3(dRz, Ry, Rx, dR + 18);
 }
 
-/* second engine, :2296-2347: LOAM's arz/arx/ary are the derivatives of (Rz(yaw) Ry(pitch) Rx(roll) p) . c with respect to
- * roll / pitch / yaw (its x<-y, y<-z, z<-x axis relabelling undone), c = the float-stored weighted normal; translation
- * columns = c; no weight derivative, no division by s.  Kept out of line so that the pinned SO(3) row compiles exactly as
- * before (inlining it changed that path's rounding in the 16th digit, which ME-TReg's trace amplifies). */
-static __attribute__((noinline)) void orc_euler_row(const orc_lin_params *prm, double px, double py, double pz,
+/* second engine, icp_test_runner.cpp:2299-2346, RESTATED AS WRITTEN (parameterization 1).  The reference names its trigonometric
+ * terms after LOAM's camera frame - srx / crx = sin / cos(pitch), sry / cry of yaw, srz / crz of roll (:2299-2304) -, relabels the
+ * axes of the body-frame point and of the float-stored weighted normal (x <- y, y <- z, z <- x, :2309-2315) and then multiplies the
+ * three brackets of arx by coeff.z, coeff.x, coeff.y (:2323-2326), those of ary by coeff.z, coeff.y (:2327-2330) and those of arz by
+ * coeff.z, coeff.x, coeff.y (:2331-2335).  LOAM / LIO-SAM multiply the same brackets by coeff.x, coeff.y, coeff.z: with that order the
+ * row is the derivative of c . (Rz(yaw) Ry(pitch) Rx(roll) p) by roll / pitch / yaw (orc_euler_row_exact below); with the reference's
+ * cyclic permutation it is NOT (tests/test_euler_engine.py measures the difference).  Bar of this tier = what the reference
+ * computes, so this is the default; every product and sum below is taken in the order of the source text (double arithmetic,
+ * -ffp-contract=off).  Row order :2338-2343: [arz, arx, ary, coeff.z, coeff.x, coeff.y].  Kept out of line so that the pinned SO(3)
+ * row compiles exactly as before (inlining changed that path's rounding in the 16th digit, which ME-TReg's trace amplifies). */
+static __attribute__((noinline)) void orc_euler_row(const orc_lin_params *prm, float px, float py, float pz,
                                                     float cx, float cy, float cz, double a[6]) {
+    const double srx = sin(prm->euler_rpy[1]), crx = cos(prm->euler_rpy[1]);   /* :2299-2300 (pitch) */
+    const double sry = sin(prm->euler_rpy[2]), cry = cos(prm->euler_rpy[2]);   /* :2301-2302 (yaw) */
+    const double srz = sin(prm->euler_rpy[0]), crz = cos(prm->euler_rpy[0]);   /* :2303-2304 (roll) */
+    struct { float x, y, z; } pointOri, coeff;
+    pointOri.x = py; pointOri.y = pz; pointOri.z = px;                          /* :2309-2311 */
+    coeff.x = cy; coeff.y = cz; coeff.z = cx;                                   /* :2313-2315 */
+    const double crx_sry = crx * sry, crz_sry = crz * sry, srx_sry = srx * sry, srx_srz = srx * srz;   /* :2319-2322 */
+    const double arx = (crx_sry * srz * pointOri.x + crx * crz_sry * pointOri.y - srx_sry * pointOri.z) * coeff.z +
+                       (-srx_srz * pointOri.x - crz * srx * pointOri.y - crx * pointOri.z) * coeff.x +
+                       (crx * cry * srz * pointOri.x + crx * cry * crz * pointOri.y - cry * srx * pointOri.z) * coeff.y;
+    const double ary = ((cry * srx_srz - crz_sry) * pointOri.x + (sry * srz + cry * crz * srx) * pointOri.y +
+                        crx * cry * pointOri.z) * coeff.z +
+                       ((-cry * crz - srx_sry * srz) * pointOri.x + (cry * srz - crz * srx_sry) * pointOri.y -
+                        crx_sry * pointOri.z) * coeff.y;
+    const double arz = ((crz * srx_sry - cry * srz) * pointOri.x + (-cry * crz - srx_sry * srz) * pointOri.y) * coeff.z +
+                       (crx * crz * pointOri.x - crx * srz * pointOri.y) * coeff.x +
+                       ((sry * srz + cry * crz * srx) * pointOri.x + (crz_sry - cry * srx_srz) * pointOri.y) * coeff.y;
+    a[0] = arz; a[1] = arx; a[2] = ary;                                         /* :2338-2340 */
+    a[3] = coeff.z; a[4] = coeff.x; a[5] = coeff.y;                             /* :2341-2343 */
+}
+
+/* parameterization 2 (additive, not in the reference): the exact derivative of c . (Rz(yaw) Ry(pitch) Rx(roll) p) by roll / pitch /
+ * yaw = LOAM's / LIO-SAM's row with its x<-y, y<-z, z<-x relabelling undone; translation columns = c. */
+static __attribute__((noinline)) void orc_euler_row_exact(const orc_lin_params *prm, double px, double py, double pz,
+                                                          float cx, float cy, float cz, double a[6]) {
     double dR[27];
     orc_euler_dR(prm->euler_rpy[0], prm->euler_rpy[1], prm->euler_rpy[2], dR);
     const double c[3] = {(double)cx, (double)cy, (double)cz};
@@ -434,6 +465,15 @@ static __attribute__((noinline)) void orc_euler_row(const orc_lin_params *prm, d
                c[2] * (D[6] * px + D[7] * py + D[8] * pz);
         a[3 + k] = c[k];
     }
+}
+
+/* both rows for one point and one weighted normal (tests: the restatement against the reference's text, and the permutation) */
+void orc_euler_rows(const double rpy[3], const float p[3], const float c[3], double literal[6], double exact[6]) {
+    orc_lin_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.euler_rpy[0] = rpy[0]; prm.euler_rpy[1] = rpy[1]; prm.euler_rpy[2] = rpy[2];
+    orc_euler_row(&prm, p[0], p[1], p[2], c[0], c[1], c[2], literal);
+    orc_euler_row_exact(&prm, (double)p[0], (double)p[1], (double)p[2], c[0], c[1], c[2], exact);
 }
 
 static void orc_point_row(const orc_kdtree *tree, const float *P, const double R[9], const double t[3],
@@ -493,7 +533,8 @@ static void orc_point_row(const orc_kdtree *tree, const float *P, const double R
     double w = s + r * ds;                                       /* :1898 */
     row->a[0] = w * c0; row->a[1] = w * c1; row->a[2] = w * c2;
     row->a[3] = w * m0; row->a[4] = w * m1; row->a[5] = w * m2;
-    if (prm->parameterization == 1) orc_euler_row(prm, px, py, pz, cx, cy, cz, row->a);
+    if (prm->parameterization == 1) orc_euler_row(prm, P[0], P[1], P[2], cx, cy, cz, row->a);
+    else if (prm->parameterization == 2) orc_euler_row_exact(prm, px, py, pz, cx, cy, cz, row->a);
     row->b = -(double)ci;                                        /* :1906 */
     row->r = r;
     row->flag = 1;
@@ -918,7 +959,7 @@ int orc_icp_run_euler(const orc_kdtree *tree, const float *src, int64_t n_src, i
     memcpy(pose, pose6d, sizeof(pose));
     memset(res, 0, sizeof(*res));
     for (int i = 0; i < 36; ++i) res->cov[i] = (i % 7 == 0) ? 1e6 : 0.0;
-    orc_lin_params prm = {cfg->search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, 0, cfg->num_threads, 1, 0, {0.0, 0.0, 0.0}};
+    orc_lin_params prm = {cfg->search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, 0, cfg->num_threads, cfg->euler_exact_jacobian ? 2 : 1, 0, {0.0, 0.0, 0.0}};
     if (!tree || orc_kdtree_size(tree) == 0 || n_src <= 0) { res->status = 3; return 0; }
     double prev_rmse = DBL_MAX, prev_fit = 0.0;                 /* :2115-2116 */
     for (int it = 0; it < cfg->max_iterations; ++it) {

@@ -61,10 +61,11 @@ typedef struct orc_lin_params {
     double weight_min;             /* 0.1  */
     int use_weight_derivative;     /* 0 = released source, 1 = paper traces */
     int num_threads;               /* 0 = OpenMP default; reference hard-codes 8 */
-    int parameterization;          /* 0 = SO(3) right perturbation (math_utils.hpp:102-121), 1 = Euler / LOAM row of the
-                                      second engine (icp_test_runner.cpp:2296-2347) */
+    int parameterization;          /* 0 = SO(3) right perturbation (math_utils.hpp:102-121), 1 = the Euler row of the second engine
+                                      as the reference writes it (icp_test_runner.cpp:2299-2346: LOAM's brackets times coeff z,x,y),
+                                      2 = the exact roll / pitch / yaw derivative (LOAM's own coefficient order; not in the reference) */
     int reserved_;
-    double euler_rpy[3];           /* parameterization 1: roll, pitch, yaw the R was built from (utils.hpp:452-460) */
+    double euler_rpy[3];           /* parameterization 1, 2: roll, pitch, yaw the R was built from (utils.hpp:452-460) */
 } orc_lin_params;
 
 typedef struct orc_lin_out {
@@ -100,6 +101,7 @@ typedef struct orc_config {
     int use_weight_derivative;
     int always_compute_schur;  /* 1: fill Schur/diag condition numbers for every method (paper traces) */
     int num_threads;
+    int euler_exact_jacobian;  /* orc_icp_run_euler: 0 (default) = the reference's row (parameterization 1), 1 = parameterization 2 */
     double gt[16];             /* row-major 4x4 ground truth */
 } orc_config;
 
@@ -196,6 +198,9 @@ int orc_icp_run_euler(const orc_kdtree *, const float *src_xyz, int64_t n_src, i
                       orc_iter_log *log, int log_capacity, orc_icp_result *, double final_pose6d[6]);
 /* dR/droll, dR/dpitch, dR/dyaw (row-major 3x3 each) of R = Rz(yaw) Ry(pitch) Rx(roll) */
 void orc_euler_dR(double roll, double pitch, double yaw, double dR[27]);
+/* the Euler row of one point p (body frame, float) and one float-stored weighted normal c: as the reference writes it
+ * (icp_test_runner.cpp:2299-2346, parameterization 1) and the exact derivative (parameterization 2) */
+void orc_euler_rows(const double rpy[3], const float p[3], const float c[3], double literal[6], double exact[6]);
 
 void orc_p2p_error(const float *aligned_xyz, int64_t n_a, const orc_kdtree *target_tree,
                    const float *target_xyz, int64_t n_t, double error_threshold,

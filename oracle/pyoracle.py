@@ -54,7 +54,7 @@ class Config(C.Structure):
                 ("pcg_max_iter", C.c_int), ("std_reg_gamma", C.c_double),
                 ("adaptive_reg_alpha", C.c_double), ("use_weight_derivative", C.c_int),
                 ("always_compute_schur", C.c_int), ("num_threads", C.c_int),
-                ("gt", C.c_double * 16)]
+                ("euler_exact_jacobian", C.c_int), ("gt", C.c_double * 16)]
 
 
 class Analysis(C.Structure):
@@ -135,6 +135,7 @@ def lib():
     L.orc_icp_run_euler.argtypes = [C.c_void_p, fp, C.c_int64, C.c_int64, dp, C.c_int, C.c_int, C.POINTER(Config),
                                     C.POINTER(IterLog), C.c_int, C.POINTER(IcpResult), dp]
     L.orc_euler_dR.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+    L.orc_euler_rows.argtypes = [dp, fp, fp, dp, dp]
     L.orc_p2p_error.argtypes = [fp, C.c_int64, C.c_void_p, fp, C.c_int64, C.c_double, dp, dp, dp,
                                 C.POINTER(C.c_int64)]
     L.orc_sizeof_iter_log.restype = C.c_size_t
@@ -164,12 +165,13 @@ def default_config(**kw):
     return cfg
 
 
-def default_lin_params(search_radius=1.0, use_weight_derivative=0, num_threads=0, euler_rpy=None):
-    """euler_rpy = (roll, pitch, yaw) selects the Euler / LOAM row of the second engine (the R, t passed to
-    linearize must be the Pose6D2Matrix of that pose)."""
+def default_lin_params(search_radius=1.0, use_weight_derivative=0, num_threads=0, euler_rpy=None, euler_exact=False):
+    """euler_rpy = (roll, pitch, yaw) selects the Euler row of the second engine (the R, t passed to linearize must be the
+    Pose6D2Matrix of that pose): as the reference writes it (icp_test_runner.cpp:2299-2346), or with euler_exact the exact
+    roll / pitch / yaw derivative (LOAM's coefficient order)."""
     p = LinParams(search_radius, 0.2 * 0.2, 1e-6, 0.9, 0.1, use_weight_derivative, num_threads)
     if euler_rpy is not None:
-        p.parameterization = 1
+        p.parameterization = 2 if euler_exact else 1
         p.euler_rpy[:] = [float(v) for v in euler_rpy]
     return p
 
@@ -289,6 +291,15 @@ def icp_run_euler(tree, src, pose6d, method, cfg, log_capacity=None):
     lib().orc_icp_run_euler(tree.ptr, _fp(src), src.shape[0], 3, _dp(p0), DET[det], HAND[hand], C.byref(cfg), logs, cap,
                             C.byref(res), _dp(pf))
     return res, [logs[i] for i in range(max(min(res.iterations, cap), 0))], pf
+
+
+def euler_rows(rpy, p, c):
+    """(literal, exact) Euler rows of one point / weighted normal: orc_euler_rows."""
+    lit, ex = np.zeros(6), np.zeros(6)
+    r = np.asarray(rpy, dtype=np.float64)
+    pf, cf = np.asarray(p, dtype=np.float32), np.asarray(c, dtype=np.float32)
+    lib().orc_euler_rows(_dp(r), _fp(pf), _fp(cf), _dp(lit), _dp(ex))
+    return lit, ex
 
 
 def euler_dR(roll, pitch, yaw):
