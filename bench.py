@@ -9,14 +9,17 @@ Default workload = BASELINE.json configs[3], the largest single-GPU configuratio
 quoted on: 1 M x 1 M-point synthetic corridor, runs of 50 ICP iterations, method Ours (Schur detection + PCG).  The steps
 are consecutive iterations of back-to-back 50-iteration runs from the same initial misalignment (a run's first iterations,
 0.87 m off at the corridor ends, cost several times an aligned one: they are part of the workload and of `value`).  The
-timed region of --steps K iterations is repeated --repeats times (each bracketed by barrier + synchronize, max over
-ranks); `value` = all timed steps / all timed time, `ms_per_step` = the same mean, with median / min / max alongside.
+timed region of --steps K iterations is repeated (each repeat bracketed by barrier + synchronize, max over ranks) until the
+timed regions hold --min-seconds of work (default 10 s: a monitor sampling the device around the command then sees it busy);
+`value` = all timed steps / all timed time, `ms_per_step` = the same mean, with median / min / max alongside.  No HIP event is
+recorded inside a timed region: `roofline.kernel_us_avg` comes from a separate, untimed pass over whole runs (kernel_pass).
 The other BASELINE configs (C1 fixture, C2 100 k cylinder, C3 PK01-like 200 k, C5 = the 5000-trial Monte-Carlo experiment end
 to end) are measured briefly afterwards and reported under "configs", each with its own roofline block.
 
 On the same line (N = 1): `roofline_by_regime` (every launch of a few whole runs timed with HIP events and bucketed by the fraction of
 its points that went through the search - the launch reports it itself), `converged_run` (the same pair with the reference's
-convergence thresholds on), `configs.c3_pk01_8k_registration` (what ONE registration of an 8 k-point frame costs from host buffers:
+convergence thresholds on), `cold_run` (the same with the neighbour state dropped before every run = the reference's fresh
+ICPContext per run, icp_test_runner.cpp:408-409), `configs.c3_pk01_8k_registration` (what ONE registration of an 8 k-point frame costs from host buffers:
 dcreg_set_source + run to convergence, the reference's own metric, icp_test_runner.cpp:442-461) and the C5 experiment at 2 / 4 / all host
 threads.
 
@@ -42,8 +45,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_QUERY = 72           # 12 B source point + 5 x 12 B neighbours
 N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max shader clock (MI355X_MICROARCH.md)
 MC_TRIALS, MC_SLOTS, MC_SEED = 5000, 256, 2024
-KERNEL_TIMING_STRIDE = 13      # HIP-event pair around every 13th launch of the timed region (an event pair costs ~10 us of host time; 13 is
-                               # coprime with the run lengths 20 / 30 / 50, so every iteration of a run gets sampled - 8 never timed the odd ones)
+MC_KERNEL_TIMING_STRIDE = 13   # kernel pass of the Monte-Carlo experiment: a HIP-event pair around every 13th batched launch (an event pair costs
+                               # ~10 us of host time and the experiment is thousands of launches).  The kernel pass is a SEPARATE, untimed pass:
+                               # no launch of the region `value` is computed from carries events (kernel_pass below)
+MIN_SECONDS = 10.0             # the headline's timed regions are repeated until they hold at least this much device work
 
 # name: scene, points, radius, iterations per ICP run, weight-derivative Jacobian, BASELINE config
 WORKLOADS = {
@@ -87,11 +92,15 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--repeats", type=int, default=300, help="the timed region of --steps iterations is repeated this many times")
+    ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps iterations is repeated this many times (0 = as often as "
+                                                             "--min-seconds asks)")
+    ap.add_argument("--min-seconds", type=float, default=MIN_SECONDS,
+                    help="headline only: repeat the timed region until at least this many seconds of it have been timed, so that a sampling "
+                         "monitor around the command sees the device busy (each repeat is still exactly --steps steps between two fences)")
     ap.add_argument("--workload", default="c4_corridor_1m", choices=list(WORKLOADS))
     ap.add_argument("--method", default="Ours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-configs", action="store_true", help="skip the brief measurements of the other BASELINE configs")
     ap.add_argument("--no-regimes", action="store_true", help="skip the per-regime roofline and the thresholds-on run of the main workload")
     ap.add_argument("--sharding", default="pairs", choices=["pairs", "points"],
@@ -302,36 +311,63 @@ class Pair:
         self.ctx.close()
 
 
-def measure(P, D, steps, warmup, repeats):
-    """warm-up, then `repeats` timed regions of exactly `steps` steps, each bracketed by the fence; times are
-    max-over-ranks.  Returns dict(times=[s per block], kernel_us, iters_per_step, points_per_launch, poses_per_launch)."""
-    P.run_steps(warmup)
-    P.ctx.set_option("time_kernels", KERNEL_TIMING_STRIDE)
+def kernel_pass(P, steps):
+    """Mean device time of one linearisation (all kernels of a launch between one HIP-event pair on the context's stream), from a pass of its
+    own: `steps` untimed steps of the same workload with the events on.  Nothing of this pass is inside a region `value` is computed from."""
+    stride = MC_KERNEL_TIMING_STRIDE if P.mc else 1
+    if not P.mc:
+        P._restart()
+    P.ctx.set_option("time_kernels", stride)
     P.ctx.kernel_time(reset=True)
     P.ctx.launch_stats(reset=True)
+    P.run_steps(steps)
+    kern_ms, kern_n = P.ctx.kernel_time(reset=True)
+    st = P.ctx.launch_stats(reset=True)
+    P.ctx.set_option("time_kernels", 0)
+    if not P.mc:
+        P._restart()
+    return {"kernel_us": 1e3 * kern_ms / max(kern_n, 1), "launches_timed": int(kern_n),
+            "points_per_launch": st["points"] / max(st["launches"], 1), "poses_per_launch": st["poses"] / max(st["launches"], 1),
+            "source": "separate pass: HIP events around %s launch of %d steps (%s), outside the timed regions" % (
+                "every" if stride == 1 else "every %dth" % stride, steps, "whole runs from the initial pose" if not P.mc else "one whole experiment")}
+
+
+def measure(P, D, steps, warmup, repeats, min_seconds=0.0, kernel_steps=None):
+    """warm-up, then `repeats` timed regions of exactly `steps` steps, each bracketed by the fence; times are max-over-ranks.  min_seconds > 0:
+    the region is repeated until the timed regions add up to that much (all ranks take the count from rank 0's calibration).  No HIP event is
+    recorded inside a timed region; the kernel time comes from kernel_pass afterwards.
+    Returns dict(times=[s per block], kernel_us, iters_per_step, points_per_launch, poses_per_launch)."""
+    P.run_steps(warmup)
+    P.ctx.set_option("time_kernels", 0)
     mc0 = P.mc_iters
     times = []
     import gc
     gc.collect()
     gc.disable()          # (a generation-2 collection of this process - torch imported, a million-point scene in numpy - takes 30 ms and
     try:                  #  lands in whichever repeat crosses the allocation threshold: it was 7 % of the timed region at --steps 20)
-        for _ in range(repeats):
+        def one():
             D.fence()
             t0 = time.perf_counter()
             P.run_steps(steps)
             D.fence()
             times.append(D.max_over_ranks(time.perf_counter() - t0))
+        n = max(int(repeats), 1)
+        if min_seconds > 0.0:
+            for _ in range(3):
+                one()
+            n = max(n, int(np.ceil(min_seconds / max(float(np.mean(times)), 1e-6))))      # (max-over-ranks times: the same count on every rank)
+        while len(times) < n:
+            one()
     finally:
         gc.enable()
-    kern_ms, kern_n = P.ctx.kernel_time(reset=True)
-    st = P.ctx.launch_stats(reset=True)
-    P.ctx.set_option("time_kernels", 0)
-    per_step = (P.mc_iters - mc0) / float(steps * repeats) if P.mc else 1.0
-    return {"times": times, "kernel_us": 1e3 * kern_ms / max(kern_n, 1), "iters_per_step": per_step,
-            "points_per_launch": st["points"] / max(st["launches"], 1), "poses_per_launch": st["poses"] / max(st["launches"], 1)}
+    per_step = (P.mc_iters - mc0) / float(steps * len(times)) if P.mc else 1.0
+    run_len = P.w["run_len"]
+    kp = kernel_pass(P, kernel_steps if kernel_steps is not None else (1 if P.mc else 3 * run_len))
+    return {"times": times, "kernel_us": kp["kernel_us"], "kernel_source": kp["source"], "iters_per_step": per_step,
+            "points_per_launch": kp["points_per_launch"], "poses_per_launch": kp["poses_per_launch"]}
 
 
-def roofline_blocks(name, n_queries_per_launch, kern_us):
+def roofline_blocks(name, n_queries_per_launch, kern_us, kern_source=None):
     """The HBM block the contract asks for + the VALU-issue block (what actually binds the kernel).  `achieved` is live:
     algorithmic bytes of the points ONE launch linearises / the HIP-event time of that launch in THIS run; `traffic` and the
     instruction count are per-launch PMC figures of the same workload read from the committed rocprofv3 summaries (labelled with
@@ -345,7 +381,7 @@ def roofline_blocks(name, n_queries_per_launch, kern_us):
            "kernel": "k_lin (certificate test, exact 6-NN search where needed, plane fit, point-to-plane row, J^T J / J^T r reduction) + the advance pass "
                      "the host puts in front of it in some launches (k_advance / k_advance_team: the searches and refits in dense waves / by teams of 16 lanes); "
                      "kernel_us_avg brackets all kernels of a linearisation",
-           "kernel_us_avg": kern_us, "points_per_launch": n_queries_per_launch, "algorithmic_bytes_per_launch": algo}
+           "kernel_us_avg": kern_us, "kernel_us_source": kern_source, "points_per_launch": n_queries_per_launch, "algorithmic_bytes_per_launch": algo}
     out = {"roofline": hbm}
     mix = valu_mix()
     if prof.get("valu_insts_per_launch") and kern_us > 0 and mix:
@@ -412,7 +448,8 @@ def summarize(name, P, D, m, steps, n_gpus):
                name, w["cfg"], P.n_src_total, len(P.tgt), w["radius"], MC_TRIALS, w["run_len"], P.method)) if P.mc else
                        ("%s [%s]: %d-pt source x %d-pt target, radius %.2f, back-to-back runs of %d ICP iterations, method %s" % (
                name, w["cfg"], P.n_src_total, len(P.tgt), w["radius"], w["run_len"], P.method))}
-    rec.update(roofline_blocks(name, m["points_per_launch"], m["kernel_us"]))
+    rec.update(roofline_blocks(name, m["points_per_launch"], m["kernel_us"], m.get("kernel_source")))
+    rec["timed_seconds"] = float(times.sum())
     rec["poses_per_launch"] = m["poses_per_launch"]
     if P.mc:
         rec["n_gpus"] = n_gpus
@@ -466,9 +503,13 @@ def regime_probe(P, runs=6):
     return out
 
 
-def converged_run(P, D, repeats=10):
+def converged_run(P, D, repeats=10, cold=False):
     """The workload's pair with the reference's convergence test on (icp_test_runner.cpp:1957-1975; thresholds = dcreg_default_config =
-    utils.hpp:139-140): runs from the same initial pose until convergence."""
+    utils.hpp:139-140): runs from the same initial pose until convergence.  cold: the context's neighbour state is dropped before every
+    run (dcreg_reset_warm_state(ctx, -1), outside the timed part) - the reference builds a fresh ICPContext per run
+    (icp_test_runner.cpp:408-409), so nothing a previous run found is known when the next one starts; clouds and index stay resident as
+    they do there (setTargetCloud is outside the reference's timed part too, :408-442).  Without it a run starts from what the previous
+    run's converged pose left in the state (bounds from neighbours 0.87 m away)."""
     api, C, L = P.api, P.C, P.L
     cfg = api.default_config(search_radius=P.w["radius"], max_iterations=P.w["run_len"], KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0,
                              use_weight_derivative=P.w["wd"], always_compute_schur=1)
@@ -477,6 +518,8 @@ def converged_run(P, D, repeats=10):
     res = api.IcpResult()
     its, times = [], []
     for rep in range(repeats + 1):
+        if cold:
+            P.ctx.reset_warm_state(-1)
         D.fence()
         ta = time.perf_counter()
         rc = L.dcreg_icp_run(P.ctx._h, R0.ctypes.data_as(P.dp), t0.ctypes.data_as(P.dp), api.DETECTION[P.det], api.HANDLING[P.hand], C.byref(cfg), None, 0, C.byref(res))
@@ -487,7 +530,9 @@ def converged_run(P, D, repeats=10):
             times.append(time.perf_counter() - ta); its.append(res.iterations)
     P._restart()
     t = np.array(times)
-    return {"thresholds": {"rot_rad": cfg.CONVERGENCE_THRESH_ROT, "trans_m": cfg.CONVERGENCE_THRESH_TRANS, "source": "dcreg_default_config = DCReg/include/utils.hpp:139-140"},
+    return {"neighbour_state_at_start": "empty (dropped before every run: a fresh ICPContext, icp_test_runner.cpp:408-409)" if cold else
+            "what the previous run left at its converged pose",
+            "thresholds": {"rot_rad": cfg.CONVERGENCE_THRESH_ROT, "trans_m": cfg.CONVERGENCE_THRESH_TRANS, "source": "dcreg_default_config = DCReg/include/utils.hpp:139-140"},
             "converged": int(res.converged), "iterations_to_convergence": float(np.mean(its)), "ms_per_run": 1e3 * float(t.mean()),
             "ms_per_run_min": 1e3 * float(t.min()), "iterations_per_s": float(np.sum(its) / t.sum()), "repeats": repeats,
             "note": "runs from the bench's initial pose until |d rot| < %.0e rad and |d trans| < %.0e m; max %d iterations" % (
@@ -669,13 +714,14 @@ def main(argv=None):
     host_threads = api.set_host_threads(want_threads)
 
     P = Pair(args.workload, D, args, seed=100 + (0 if args.sharding == "points" else D.rank))   # pairs: every rank its own scan pair
-    m = measure(P, D, args.steps, args.warmup, args.repeats)
+    m = measure(P, D, args.steps, args.warmup, args.repeats, min_seconds=args.min_seconds)
     main_rec = summarize(args.workload, P, D, m, args.steps, n_gpus)
 
-    regimes = conv = None
+    regimes = conv = cold = None
     if not P.mc and not P.by_points and n_gpus == 1 and not args.no_regimes:
         regimes = regime_probe(P)
         conv = converged_run(P, D)
+        cold = converged_run(P, D, cold=True)
 
     conc = None
     if args.concurrent_pairs > 1 and not P.mc and not P.by_points and n_gpus == 1:
@@ -709,6 +755,8 @@ def main(argv=None):
             sub[name]["host_threads_per_rank"] = host_threads
             if n_gpus == 1 and not mc and not args.no_regimes:
                 sub[name]["roofline_by_regime"] = regime_probe(Q, runs=4)
+                sub[name]["converged_run"] = converged_run(Q, D, repeats=5)
+                sub[name]["cold_run"] = converged_run(Q, D, repeats=5, cold=True)
             Q.close()
         if n_gpus == 1:
             sub["c3_pk01_8k_registration"] = c3_registration(D, args)
@@ -719,7 +767,7 @@ def main(argv=None):
     if D.rank == 0:
         result = {
             "metric": "ICP iterations/sec", "value": main_rec["value"], "unit": "iterations/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "repeats": args.repeats,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "repeats": main_rec["repeats"], "timed_seconds": main_rec["timed_seconds"],
             "ms_per_step": main_rec["ms_per_step"], "ms_per_step_median": main_rec["ms_per_step_median"],
             "ms_per_step_min": main_rec["ms_per_step_min"], "ms_per_step_max": main_rec["ms_per_step_max"],
             "slowest_repeats": main_rec["slowest_repeats"],
@@ -741,6 +789,8 @@ def main(argv=None):
             result["roofline_by_regime"] = regimes
         if conv is not None:
             result["converged_run"] = conv
+        if cold is not None:
+            result["cold_run"] = cold
         if conc is not None:
             result["concurrent_pairs"] = conc
         if sub:

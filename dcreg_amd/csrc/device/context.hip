@@ -73,7 +73,10 @@ static void host_bounds(const float *xyz, int64_t n, int64_t stride, double mn[3
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = 0; i < n; ++i) {
         const float *p = xyz + i * stride;
-        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]);
+            if (!(std::fabs(p[a]) <= 3.4e38f)) hi[0] = INFINITY;       // (a NaN compares false everywhere: make it visible, as k_bounds does)
+        }
     }
     for (int a = 0; a < 3; ++a) { mn[a] = lo[a]; mx[a] = hi[a]; }
 }
@@ -237,6 +240,10 @@ int build_aux_index(dcreg_ctx *c) {
     return DCREG_OK;
 }
 
+// a frame from a host buffer small enough for the registration path (icp_test_runner.cpp:442-461): staged through pinned memory, bounds on the
+// host, no stream synchronise in dcreg_set_source
+static bool small_host_frame(int64_t n, int64_t stride) { return n <= 65536 && n * stride <= (int64_t)1 << 20; }
+
 static int upload_cloud(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride, bool on_device, float4 *&raw, size_t &raw_cap) {
     if (!xyz || n < 0 || stride < 3) { c->fail("invalid cloud arguments"); return DCREG_E_INVALID; }
     if (n >= ((int64_t)1 << 31)) { c->fail("cloud too large (%lld points)", (long long)n); return DCREG_E_INVALID; }
@@ -245,7 +252,23 @@ static int upload_cloud(dcreg_ctx *c, const float *xyz, int64_t n, int64_t strid
     const float *src = xyz;
     if (!on_device) {
         if (ensure(c, c->d_stage, c->stage_cap, (size_t)(n * stride))) return DCREG_E_NOMEM;
-        HIP_TRY(c, hipMemcpyAsync(c->d_stage, xyz, sizeof(float) * (size_t)(n * stride), hipMemcpyHostToDevice, c->stream));
+        const float *from = xyz;
+        const size_t words = (size_t)(n * stride);
+        if (small_host_frame(n, stride)) {
+            // through the context's own pinned block: safe for pageable, pinned and registered buffers alike, and the
+            // copy engine reads pinned memory without the runtime's staging pass
+            if (words > c->h_stage_cap) {
+                if (c->h_stage) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; c->h_stage_busy = false; }
+                HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, sizeof(float) * words, hipHostMallocDefault));
+                c->h_stage_cap = words;
+            }
+            if (!c->h_stage_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->h_stage_ev, hipEventDisableTiming));
+            if (c->h_stage_busy) { HIP_TRY(c, hipEventSynchronize(c->h_stage_ev)); c->h_stage_busy = false; }   // (the previous frame's upload: long done)
+            std::memcpy(c->h_stage, xyz, sizeof(float) * words);
+            from = c->h_stage;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage, from, sizeof(float) * words, hipMemcpyHostToDevice, c->stream));
+        if (from == c->h_stage) { HIP_TRY(c, hipEventRecord(c->h_stage_ev, c->stream)); c->h_stage_busy = true; }
         src = c->d_stage;
     }
     hipLaunchKernelGGL(k_pack, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, src, n, stride, raw);
@@ -283,13 +306,14 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (rc) return rc;
     // Hilbert-curve order in the body frame (pose independent: a rigid motion keeps neighbours neighbours)
     double mn[3], mx[3];
-    const bool small_host = !on_device && n <= 65536;        // a frame from a host buffer: the registration path (icp_test_runner.cpp:442-461)
+    const bool small_host = !on_device && small_host_frame(n, stride);   // a frame from a host buffer: the registration path (icp_test_runner.cpp:442-461)
     if (small_host) {
         host_bounds(xyz, n, stride, mn, mx);
     } else {
         rc = device_bounds(c, c->d_src_raw, n, mn, mx);
         if (rc) return rc;
     }
+    for (int a = 0; a < 3; ++a) if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) { c->fail("source cloud has non-finite coordinates"); return DCREG_E_INVALID; }
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
     const double inv_q = 2097151.0 / ext * 0.999999;
     {   // farthest corner of the bounding box: no point is farther from the body-frame origin
@@ -314,17 +338,10 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         if (rc) return rc;
         hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
     }
-    // A small frame from a PAGEABLE host buffer: no stream synchronise - the runtime has staged the caller's buffer when hipMemcpyAsync
-    // returns, the first linearisation queues behind the sort, and a device fault surfaces at that linearisation (include/dcreg.h says
-    // so).  A pinned / registered buffer (hipHostMalloc, hipHostRegister, torch pin_memory) is read by the DMA engine asynchronously:
-    // the caller may reuse or free the frame as soon as this returns, so the call waits for the copy (the event behind it) first.
-    bool must_wait = !small_host;
-    if (small_host) {
-        hipPointerAttribute_t at{};
-        const hipError_t pe = hipPointerGetAttributes(&at, xyz);
-        if (pe != hipSuccess) (void)hipGetLastError();                     // (older runtimes: "invalid value" for plain malloc memory)
-        else if (at.type != hipMemoryTypeUnregistered) must_wait = true;   // host-registered, managed, or a device pointer after all
-    }
+    // A small frame from a host buffer went through the context's pinned block (upload_cloud): the caller's buffer is consumed, whatever
+    // kind of memory it is, and nothing has to be waited for - the first linearisation queues behind the sort, and a device fault surfaces
+    // at that linearisation (include/dcreg.h says so).  Everything else is waited for here.
+    const bool must_wait = !small_host;
     if (must_wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->n_src = n;
@@ -720,6 +737,13 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         }
         a.adv_counts = c->d_adv_counts;
     }
+    unsigned long long *team_stamps = nullptr;
+    if (team && c->opt_team_stamps) {          // timing probe (dcreg_debug.h dcreg_team_pass_stamps): eight clock words per block of the pass.  Grown HERE,
+        // before any kernel of this launch is queued: a hipFree behind a gate kernel that waits for the host would wait for it
+        if (ensure(c, c->d_team_stamps, c->team_stamps_cap, (size_t)8 * (n_tiles + 1))) return DCREG_E_NOMEM;
+        HIP_TRY(c, hipMemsetAsync(c->d_team_stamps, 0, sizeof(unsigned long long) * 8 * (n_tiles + 1), c->stream));
+        team_stamps = c->d_team_stamps; c->team_stamps_n = n_tiles;
+    }
     DebugDev dd{};
     free_tmp(S);
     if (dbg_host) {
@@ -758,7 +782,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     };
     // A gated launch the device holds at once (at most kChunk query blocks) waits for its pose in its FIRST kernel instead of behind a
     // gate kernel (kernels.hpp gate_wait: one kernel boundary less on a launch that lasts a few microseconds); larger launches keep
-    // k_gate (every wave would pay for the wait: profiles/r04_gate_in_kernel.txt)
+    // k_gate (every wave would pay for the wait: profiles/r04_gate_in_kernel.txt).  What this relies on and costs: every
+    // wave of the gated kernel - at most 64 x 4 of k_lin, at most 4096 one-wave blocks of the teams - is resident and polls the DEVICE copy
+    // of the record while the host takes its step; only the first wave of block 0 polls the host record and fills the copy, so progress
+    // rests on block 0 being dispatched before the device is full, which holds while blocks are dispatched in index order and the launch
+    // fits the device (nbx <= kChunk: it does).  A context that shares its device with other busy contexts holds wave slots idle that way;
+    // option "gate_in_kernel" = 0 puts the one-wave k_gate back in front.
     GateArgs gt{nullptr, nullptr, 0ull, nullptr, nullptr, 0u};
     const bool gate_inside = gated && c->opt_gate_in_kernel && nbx <= (uint32_t)kChunk && !adv && !dbg_host;
     const PoseArg *lin_poses = d_poses;            // what k_lin reads its pose from (null: pose1)
@@ -786,12 +815,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         c->n_advance_launches += 1;
     }
     if (team) {
-        unsigned long long *stamps = nullptr;
-        if (c->opt_team_stamps) {          // timing probe (dcreg_debug.h dcreg_team_pass_stamps): eight clock words per block of the pass
-            if (ensure(c, c->d_team_stamps, c->team_stamps_cap, (size_t)8 * (n_tiles + 1))) return DCREG_E_NOMEM;
-            (void)hipMemsetAsync(c->d_team_stamps, 0, sizeof(unsigned long long) * 8 * (n_tiles + 1), c->stream);
-            stamps = c->d_team_stamps; c->team_stamps_n = n_tiles;
-        }
+        unsigned long long *stamps = team_stamps;
         if (gate_inside) {      // the teams are the gated kernel
             if (fast) hipLaunchKernelGGL((k_advance_team<true, true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, (const PoseArg *)nullptr, a, c->d_adv_counts, (const uint32_t *)nullptr, stamps, gt);
             else hipLaunchKernelGGL((k_advance_team<false, true>), dim3(n_tiles), dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, (const PoseArg *)nullptr, a, c->d_adv_counts, (const uint32_t *)nullptr, stamps, gt);
@@ -982,7 +1006,12 @@ static int linearize_end(dcreg_ctx *c, int slot, dcreg_lin_out *outs) {
         }
         outs[i].n_eff = c29; outs[i].n_pt = c30;
     }
-    c->last_searched = searched; c->last_refitted = refitted; c->last_points = (int64_t)S.n_poses * c->n_src;
+    c->last_points = (int64_t)S.n_poses * c->n_src;
+    // (a point whose new certificate has no slack at all - distance ties - is served by an advance pass and searched again by k_lin: it is
+    // counted twice.  The scheduling rules and the launch log read fractions: never more than every point.  ADVICE round 5)
+    if (searched > c->last_points) searched = c->last_points;
+    if (refitted > c->last_points) refitted = c->last_points;
+    c->last_searched = searched; c->last_refitted = refitted;
     if (c->opt_record_launches && c->launch_series.size() < ((size_t)1 << 20))
         c->launch_series.push_back(dcreg_ctx::LaunchRec{(double)launch_ms, searched, refitted, c->last_points, S.advanced});
     return DCREG_OK;
@@ -1100,6 +1129,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->h_gate) (void)hipHostFree(c->h_gate);
     if (c->h_euler) (void)hipHostFree(c->h_euler);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_stage_ev) (void)hipEventDestroy(c->h_stage_ev);
     if (c->d_euler) (void)hipFree(c->d_euler);
     if (c->d_gate_pose) (void)hipFree(c->d_gate_pose);
     if (c->d_gate_abort) (void)hipFree(c->d_gate_abort);
@@ -1235,6 +1266,12 @@ int dcreg_hint_misalignment(dcreg_ctx *c, double metres) {
 }
 int dcreg_reset_warm_state(dcreg_ctx *c, int64_t state_id) {
     if (!c) return DCREG_E_INVALID;
+    if (state_id == -1) {            // the context's own state (single-pose launches): as after dcreg_set_source - what a fresh ICPContext holds
+        if (c->gate_slot >= 0) { c->fail("a gated linearisation is queued: open or abort it before dropping the neighbour state"); return DCREG_E_STATE; }
+        for (const LinSlot &S : c->slots) if (S.pending) { c->fail("a linearisation is still in flight"); return DCREG_E_STATE; }
+        c->state_valid = false;
+        return DCREG_OK;
+    }
     if (state_id < 0 || state_id >= c->n_batch_states) { c->fail("warm state %lld was not reserved", (long long)state_id); return DCREG_E_INVALID; }
     c->batch_state_valid[(size_t)state_id] = 0;
     return DCREG_OK;

@@ -98,6 +98,10 @@ struct dcreg_ctx {
 
     // build scratch
     float *d_stage = nullptr; size_t stage_cap = 0;
+    // small frames from host buffers (the registration path): the caller's floats are copied into this pinned block with a plain memcpy and
+    // uploaded from there - the caller's buffer is consumed when dcreg_set_source returns whatever kind of memory it is, without a
+    // stream synchronise; h_stage_ev = the upload behind the last use of the block
+    float *h_stage = nullptr; size_t h_stage_cap = 0; hipEvent_t h_stage_ev = nullptr; bool h_stage_busy = false;
     uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
     size_t keys_cap = 0, keys2_cap = 0, vals_cap = 0, vals2_cap = 0;
     uint64_t *d_mkeys = nullptr, *d_mkeys2 = nullptr; size_t mkeys_cap = 0, mkeys2_cap = 0;

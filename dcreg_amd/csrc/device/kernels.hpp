@@ -1232,6 +1232,8 @@ static __global__ void k_bounds(const float4 *__restrict__ p, int64_t n, uint32_
         const float4 c = p[i];
         mn[0] = fminf(mn[0], c.x); mn[1] = fminf(mn[1], c.y); mn[2] = fminf(mn[2], c.z);
         mx[0] = fmaxf(mx[0], c.x); mx[1] = fmaxf(mx[1], c.y); mx[2] = fmaxf(mx[2], c.z);
+        // a NaN passes through fminf / fmaxf unnoticed: any non-finite coordinate makes the upper bound infinite, which the host rejects
+        if (!(fabsf(c.x) <= 3.4e38f) || !(fabsf(c.y) <= 3.4e38f) || !(fabsf(c.z) <= 3.4e38f)) mx[0] = __builtin_inff();
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

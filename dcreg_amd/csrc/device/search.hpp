@@ -608,7 +608,7 @@ DCREG_DEVFN void knn_search(const GridDev &g, RunList &rl, float qx, float qy, f
             if (have) {
                 DCREG_STAT(trips);
                 // one address, four loads at immediate offsets: slots past the end of the run read the next points of the
-                // sorted array (it is padded by 8 entries) and are masked out by their position when consumed
+                // sorted array (it is padded by kPtsPad entries) and are masked out by their position when consumed
                 const float4 *cp4 = g.pts + p;
 #pragma unroll
                 for (int u = 0; u < W; ++u) sl.c[u] = cp4[u];

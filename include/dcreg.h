@@ -136,9 +136,10 @@ int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 int dcreg_set_target(dcreg_ctx *, const float *xyz, int64_t n, int64_t stride_floats, double search_radius_hint);
 int dcreg_set_target_device(dcreg_ctx *, const float *d_xyz, int64_t n, int64_t stride_floats, double search_radius_hint);
 /* source ("measure") cloud: copies, orders along a space-filling curve.  The caller's buffer is consumed when the call returns - it
- * may be reused or freed at once, pageable or pinned (for pinned / registered memory the call waits for the DMA to finish).  A frame
- * of at most 65536 points from a PAGEABLE host buffer is queued without a stream synchronise (the registration path: the first
- * linearisation runs behind the sort): a device fault of the upload or the sort then surfaces at that linearisation, not here. */
+ * may be reused or freed at once, whatever kind of host memory it is.  A frame of at most 65536 points (and 2^20 floats) is copied
+ * into the context's own pinned block and queued from there without a stream synchronise (the registration path: the first
+ * linearisation runs behind the sort): a device fault of the upload or the sort then surfaces at that linearisation, not here.
+ * Clouds with non-finite coordinates are refused (DCREG_E_INVALID), source and target alike. */
 int dcreg_set_source(dcreg_ctx *, const float *xyz, int64_t n, int64_t stride_floats);
 int dcreg_set_source_device(dcreg_ctx *, const float *d_xyz, int64_t n, int64_t stride_floats);
 int dcreg_default_lin_params(dcreg_lin_params *, double search_radius);
@@ -168,7 +169,10 @@ int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
  * has filled it), then name the state of every pose in state_ids (0 <= id < n_states, each id at most once per launch,
  * -1 = search from scratch, keep nothing).  A state is read and updated by the launch, so consecutive launches of one
  * Monte-Carlo trial under the same id skip the searches their certificates cover.  dcreg_reset_warm_state marks one state
- * empty again (a trial slot that takes the next trial).  Results are identical with or without states.
+ * empty again (a trial slot that takes the next trial); state_id = -1 names the context's OWN state, the one single-pose launches and
+ * dcreg_icp_run keep: after it the next launch searches every point from scratch, as the first launch after dcreg_set_source does
+ * (the reference builds a fresh ICPContext for every run, icp_test_runner.cpp:408-409: bench.py's `cold_run`).  Results are identical
+ * with or without states.
  * dcreg_set_target / dcreg_set_source drop all states. */
 /* Scheduling hint, never needed for correctness: how far (metres, roughly) the source points are expected to lie from the map at the
  * poses of the next single-pose linearisations - e.g. the RMS residual of the last iteration.  While it is above half a grid cell

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r02}; WL=${2:-c4_corridor_1m}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_${TAG}_${WL}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps ${STEPS:-50} --warmup ${WARMUP:-50} --repeats ${REPEATS:-4} --no-cpu-baseline --no-configs --no-regimes --concurrent-pairs 0 --workload $WL"   # the timed one-pair region only
+BENCH="python $R/bench.py --steps ${STEPS:-50} --warmup ${WARMUP:-50} --repeats ${REPEATS:-4} --min-seconds 0 --no-cpu-baseline --no-configs --no-regimes --concurrent-pairs 0 --workload $WL"   # the timed one-pair region only
 $BENCH > $O/bench_plain.json 2> $O/bench_plain.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH > $O/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $BENCH > $O/fetch.log 2>&1

@@ -11,6 +11,22 @@ def one(pattern):
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()[:60]
 
+def library_kernels():
+    """the kernel instantiations dcreg_amd/lib/libdcreg_hip.so exports (demangled, argument lists cut) - a profile whose dcreg:: kernels are
+    not among them was taken with another build and must not be summarised under this tree's name"""
+    import subprocess
+    lib = os.path.join(ROOT, "dcreg_amd", "lib", "libdcreg_hip.so")
+    raw = subprocess.run(["strings", "-a", lib], capture_output=True, text=True, check=True).stdout.split("\n")
+    syms = sorted({s for s in raw if s.startswith("_Z") and "dcreg" in s})
+    dem = subprocess.run(["c++filt"], input="\n".join(syms), capture_output=True, text=True, check=True).stdout.split("\n")
+    return {short(d) for d in dem if "dcreg::" in d and "__device_stub__" not in d}
+
+def check_kernels(names):
+    have = library_kernels()
+    bad = sorted({short(n) for n in names if "dcreg::" in n and short(n) not in have})
+    if bad:
+        sys.exit("summarize_profiles: the trace holds dcreg kernels this tree's library does not export (stale profile?): %s" % ", ".join(bad))
+
 ALL_LIN = "dcreg::k_lin (all instantiations)"
 # one linearisation = one k_lin dispatch + the advance pass that may run in front of it (k_advance / k_advance_team): per-linearisation
 # figures are the totals over all of those kernels divided by the number of k_lin dispatches
@@ -19,7 +35,7 @@ def is_lin(name): return "k_lin" in name or "k_advance" in name
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
-      "Command: `python bench.py --steps 50 --warmup 50 --repeats 4 --no-cpu-baseline --no-configs --no-regimes --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
+      "Command: `python bench.py --steps 50 --warmup 50 --repeats 4 --min-seconds 0 --no-cpu-baseline --no-configs --no-regimes --concurrent-pairs 0 --workload %s` (the one-pair timed region only) under", 
       "`rocprofv3 --kernel-trace --stats` and separate `--pmc` passes (scripts/collect_profiles.sh).", ""]
 md[2] = md[2] % wl
 bp = os.path.join(src, "bench_plain.json")
@@ -35,6 +51,7 @@ if os.path.exists(bp) and os.path.getsize(bp):
 kt = one("trace/**/*kernel_trace.csv")
 if kt:
     agg = collections.defaultdict(list)
+    check_kernels({r["Kernel_Name"] for r in csv.DictReader(open(kt))})
     for r in csv.DictReader(open(kt)):
         agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         if "k_lin" in r["Kernel_Name"]:        # the launches of a run use several instantiations (warm-bound form): one row for all
@@ -65,6 +82,7 @@ def counters(sub):
     f = one(sub + "/**/*counter_collection.csv")
     res = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
+        check_kernels({r["Kernel_Name"] for r in csv.DictReader(open(f))})
         for r in csv.DictReader(open(f)):
             res[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if "k_lin" in r["Kernel_Name"]:

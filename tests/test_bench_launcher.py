@@ -79,7 +79,7 @@ def test_refuses_a_job_it_cannot_run():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("sharding", ["pairs", "points"])
 def test_two_ranks_on_one_device_real_workload(sharding):
-    p = _bench(["--gpus", "2", "--steps", "20", "--warmup", "20", "--repeats", "3", "--workload", "c2_cylinder_100k", "--sharding", sharding,
+    p = _bench(["--gpus", "2", "--steps", "20", "--warmup", "20", "--repeats", "3", "--min-seconds", "0", "--workload", "c2_cylinder_100k", "--sharding", sharding,
                 "--no-cpu-baseline", "--no-configs", "--concurrent-pairs", "0"],
                {"DCREG_BENCH_BACKEND": "gloo", "DCREG_BENCH_LOCAL_RANK": "0"}, timeout=800)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -99,7 +99,7 @@ def test_two_ranks_run_the_montecarlo_experiment_as_one_job():
     """N > 1 without extra flags: after the weak-scaling measurement of the main workload the 5000-trial Monte-Carlo experiment runs ONCE
     across the ranks (trials k = rank mod N), its trial records are gathered inside the timed region and rank 0 takes the statistics -
     here with two ranks sharing the box's one device over gloo."""
-    p = _bench(["--gpus", "2", "--steps", "30", "--warmup", "30", "--repeats", "2", "--workload", "c1_fixture_7562", "--no-cpu-baseline",
+    p = _bench(["--gpus", "2", "--steps", "30", "--warmup", "30", "--repeats", "2", "--min-seconds", "0", "--workload", "c1_fixture_7562", "--no-cpu-baseline",
                 "--concurrent-pairs", "0"], {"DCREG_BENCH_BACKEND": "gloo", "DCREG_BENCH_LOCAL_RANK": "0"}, timeout=800)
     assert p.returncode == 0, p.stderr[-3000:]
     j = _json_line(p)

@@ -1,0 +1,95 @@
+"""GPU tests added in round 6 (run with -m gpu on an MI355X; everything through the C-ABI):
+  * clouds with non-finite coordinates are refused, source and target alike (NaN as well as infinity);
+  * dcreg_reset_warm_state(ctx, -1) drops the context's own neighbour state: the next run is bitwise the run of a fresh context (the
+    reference's fresh ICPContext per run, icp_test_runner.cpp:408-409 - what bench.py's `cold_run` times);
+  * small frames from host buffers go through the context's pinned block: the caller's buffer may be overwritten as soon as
+    dcreg_set_source returns."""
+import numpy as np
+import pytest
+
+import helpers as h
+from dcreg_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize("n", [5_000, 120_000])          # the host-bounds path of small frames and the device-bounds path
+def test_non_finite_clouds_are_refused(bad, n):
+    tgt = h.scene_cylinder(n, seed=3, noise=0.01)
+    ctx = api.Context(0)
+    try:
+        ctx.set_target(tgt, 1.0)
+        ctx.set_source(tgt[::2].copy())
+        good = ctx.linearize(np.eye(3), np.zeros(3), api.default_lin_params(1.0, 0))
+        for axis in range(3):
+            src = tgt[::2].copy()
+            src[len(src) // 3, axis] = bad
+            with pytest.raises(api.DcregError) as e:
+                ctx.set_source(src)
+            assert "non-finite" in str(e.value)
+            t2 = tgt.copy()
+            t2[len(t2) // 5, axis] = bad
+            with pytest.raises(api.DcregError) as e:
+                ctx.set_target(t2, 1.0)
+            assert "non-finite" in str(e.value)
+        # the context is still usable afterwards
+        ctx.set_target(tgt, 1.0)
+        ctx.set_source(tgt[::2].copy())
+        again = ctx.linearize(np.eye(3), np.zeros(3), api.default_lin_params(1.0, 0))
+        assert again["n_eff"] == good["n_eff"] and np.array_equal(again["H_upper"], good["H_upper"])
+    finally:
+        ctx.close()
+
+
+def test_dropping_the_own_state_gives_the_run_of_a_fresh_context():
+    tgt = h.scene_corridor(200_000, seed=9)
+    rng = np.random.default_rng(1)
+    src = (tgt + rng.normal(0, 0.01, tgt.shape)).astype(np.float32)
+    T0 = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
+    cfg = api.default_config(search_radius=1.0, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, use_weight_derivative=1, always_compute_schur=1)
+
+    def run(ctx):
+        res, logs = ctx.icp_run(T0, "Ours", cfg)
+        return res, [(L.effective_points, L.corr_pt_count, tuple(L.update_dx[:]), tuple(L.H_upper[:])) for L in logs]
+
+    fresh = api.Context(0)
+    fresh.set_option("record_launches", 1)
+    fresh.set_target(tgt, 1.0); fresh.set_source(src)
+    r0, l0 = run(fresh)
+    s0 = fresh.launch_series(reset=True)
+    r1, l1 = run(fresh)                 # warm: starts from what the converged pose left
+    s1 = fresh.launch_series(reset=True)
+    fresh.reset_warm_state(-1)
+    r2, l2 = run(fresh)                 # cold again
+    s2 = fresh.launch_series(reset=True)
+    fresh.close()
+    assert r0.converged == 1 and r0.iterations == r1.iterations == r2.iterations
+    assert l0 == l1 == l2                                               # history independence: bitwise the same run every time
+    assert s0["searched"][0] == s2["searched"][0] == len(src)           # a cold first launch searches every point ...
+    assert np.array_equal(s0["searched"], s2["searched"])               # ... and the dropped state behaves like the fresh one launch by launch
+    c2 = api.Context(0)
+    with pytest.raises(api.DcregError):
+        c2.reset_warm_state(0)                                          # (no batch states reserved: only -1 names a state)
+    c2.close()
+
+
+def test_small_host_frames_are_consumed_when_set_source_returns():
+    tgt = h.scene_cylinder(60_000, seed=2, noise=0.01)
+    frame = tgt[::8].copy()
+    prm = api.default_lin_params(1.0, 0)
+    ctx = api.Context(0)
+    try:
+        ctx.set_target(tgt, 1.0)
+        ctx.set_source(frame)
+        want = ctx.linearize(np.eye(3), np.zeros(3), prm)
+        for stride_pad in (0, 1):        # xyz and xyzi layouts
+            buf = np.zeros((len(frame), 3 + stride_pad), np.float32)
+            for rep in range(20):
+                buf[:, :3] = frame
+                ctx.set_source(buf)                               # (float32, contiguous: passed as is, stride 3 or 4)
+                buf[:] = 1e9                                      # scribble over the caller's buffer at once
+                got = ctx.linearize(np.eye(3), np.zeros(3), prm)
+                assert got["n_eff"] == want["n_eff"] and np.array_equal(got["H_upper"], want["H_upper"]) and np.array_equal(got["g"], want["g"])
+    finally:
+        ctx.close()
