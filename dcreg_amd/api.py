@@ -50,7 +50,7 @@ class LinDebug(C.Structure):
 
 class LaunchStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("poses", C.c_int64), ("points", C.c_int64), ("points_searched", C.c_int64),
-                ("points_team", C.c_int64), ("points_tile", C.c_int64)]
+                ("points_team", C.c_int64)]
 
 
 class IndexInfo(C.Structure):

@@ -381,8 +381,6 @@ static int make_lin_args(dcreg_ctx *c, const dcreg_lin_params *p, LinArgs &a) {
     a.warm = c->opt_warm ? 1 : 0;
     a.team_max = std::min(std::max(c->opt_team_max, 0), kTeamMax);
     a.far_loose = (float)c->opt_far_loose;
-    a.tile_mode = c->opt_tile_search; a.tile_min_lanes = (uint32_t)c->opt_tile_min_lanes; a.tile_far = (float)c->opt_tile_far;
-    a.tile_max_rows = (uint32_t)c->opt_tile_max_rows; a.tile_max_pts = (uint32_t)c->opt_tile_max_pts;
     a.prune_infl = (float)((1.0 + c->opt_cert_inflate) * (1.0 + c->opt_cert_inflate));
     a.infl_max_d2 = (float)(4.0 * c->grid.h * c->grid.h);
     int k = 1;
@@ -1195,11 +1193,6 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
-    else if (k == "tile_search") c->opt_tile_search = v >= 2.0 ? 2 : (v >= 1.0 ? 1 : 0);        // search.hpp tile_search6: 0 never, 1 by the rule, 2 whenever possible
-    else if (k == "tile_min_lanes") c->opt_tile_min_lanes = std::min(std::max((int)v, 1), 64);
-    else if (k == "tile_far") c->opt_tile_far = v >= 0.0 ? v : 2.0;
-    else if (k == "tile_max_rows") c->opt_tile_max_rows = std::min(std::max((int)v, 1), 9 * 64);
-    else if (k == "tile_max_pts") c->opt_tile_max_pts = std::max((int)v, 1);
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)
@@ -1341,16 +1334,15 @@ int dcreg_index_info_get(const dcreg_ctx *c, dcreg_index_info *info) {
 int dcreg_launch_stats_get(dcreg_ctx *c, dcreg_launch_stats *st, int reset) {
     if (!c || !st) return DCREG_E_INVALID;
     st->launches = c->n_launches; st->poses = c->n_poses_launched; st->points = c->n_points_launched;
-    st->points_searched = -1; st->points_team = -1; st->points_tile = -1;
+    st->points_searched = -1; st->points_team = -1;
     if (c->opt_count_searches && c->d_search_count) {      // synchronous: every launch so far has finished when this returns
         std::vector<unsigned long long> v(kSearchCountBytes / sizeof(unsigned long long));
         HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_search_count, kSearchCountBytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        unsigned long long tot = 0, team = 0, tile = 0;
-        for (size_t k = 0; k < v.size(); k += kCounterStride / 2) { tot += v[k]; team += v[k + 1]; tile += v[k + 2]; }
+        unsigned long long tot = 0, team = 0;
+        for (size_t k = 0; k < v.size(); k += kCounterStride / 2) { tot += v[k]; team += v[k + 1]; }
         st->points_searched = (int64_t)tot;
         st->points_team = (int64_t)team;
-        st->points_tile = (int64_t)tile;
         if (reset) HIP_TRY(c, hipMemsetAsync(c->d_search_count, 0, kSearchCountBytes, c->stream));
     }
     if (reset) { c->n_launches = 0; c->n_poses_launched = 0; c->n_points_launched = 0; }

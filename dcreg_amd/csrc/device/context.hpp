@@ -174,8 +174,6 @@ struct dcreg_ctx {
     bool last_pose_valid = false;
     bool opt_fused_batches = true; // batched launches of one-chunk poses sum and publish per pose inside k_lin (kernels.hpp FinArgs::chunks_per_pose)
     double opt_curve_x_scale = 1.0;  // kernels.hpp k_curve_keys: < 1 stretches the patches of the source's curve order along x
-    int opt_tile_search = 1;       // search.hpp tile_search6 (round 6): dense waves with loose bounds search one shared candidate tile
-    int opt_tile_min_lanes = 48; double opt_tile_far = 2.0; int opt_tile_max_rows = 9 * 64; int opt_tile_max_pts = 768;
     double opt_far_loose = 1.5;    // search.hpp lin_search6: when a start bound is loose enough to be worth a probe (cells)
     // the advance pass (kernels.hpp k_advance): 0 never, 1 by the rule below, 2 whenever a launch can take it (tests)
     int opt_advance = 1;

@@ -569,7 +569,7 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
             if (!by_team) {
                 Set6 s6;
                 uint32_t c2;
-                lin_search6<kLinSweep, kLinDepth, true>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
+                lin_search6<kLinSweep, kLinDepth>(g, runs[wave], a, need, warm, pos6, qx, qy, qz, s6, c2);
                 if (need) {
                     cert = c2;
 #pragma unroll

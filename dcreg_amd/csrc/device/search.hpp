@@ -146,10 +146,6 @@ struct LinArgs {
                                   // launch the points the pass searched and refitted among its points, [n_blocks][32] (a line each: words 0, 1); the
                                   // block adds them to the counts it reports (count_scale) and zeroes them again for the next launch.
                                   // null: no pass in front
-    int tile_mode;                // 0: never, 1: by the rule, 2: whenever possible - the wave-cooperative tile search of dense far waves (tile_search6)
-    uint32_t tile_min_lanes;      //   rule: at least this many lanes of the wave search ...
-    float tile_far;               //   ... and some bound reaches beyond this many cells
-    uint32_t tile_max_rows, tile_max_pts;   // a tile of more row slots / candidates than this is left to the lock-step search
     float far_loose;              // a start bound counts as loose - worth a probe of the points around the nearest occupied cell - when it
                                   // reaches this many cells beyond the distance to that cell (lin_search6)
     int euler;                    // 1: roll/pitch/yaw row of the second engine (:2299-2346) instead of the SO(3) row
@@ -1336,226 +1332,8 @@ DCREG_DEVFN float warm_bound6(const GridDev &g, const uint32_t (&oldpos)[6], flo
     return fminf(bound, incl);
 }
 
-// ---------------------------------------------------------------- wave-cooperative search of a DENSE wave far from its surface (round 6)
-// The lock-step search above costs a wave what its slowest lane costs: per lane a table phase, a row sweep over its own ball and a
-// candidate loop whose run switches diverge.  In the first launches of a run (the clouds decimetres apart) that is 6 000 - 7 000 vector
-// instructions per wave for searches whose answers lie in a patch of the surface a few decimetres across - and the 64 queries of a wave
-// are Hilbert neighbours displaced by the same rigid motion: their balls overlap almost entirely.  A wave in which (nearly) every lane
-// searches with a loose bound therefore turns the search round (tile_search6, device only):
-//   * ONE box around the wave's queries, ONE radius B = the largest of their bounds;
-//   * the (y,z) rows of cells the box grown by sqrt(B) reaches, one row per lane and round (tile_row below: both table loads of 64 rows
-//     in flight together, the x-run cut to what the grown box can reach), kept in the wave's run list;
-//   * every lane scans the SAME runs: the candidate's address is uniform, so it arrives through the scalar cache in SGPRs - no vector
-//     load, no registers, no per-lane run switching, no divergence: six vector instructions for the un-fused float distance, one compare
-//     against the lane's pruning bound, and the deferred insertion of the lock-step search for the few that pass.
-// Everything within sqrt(bound) of a query lies within sqrt(B) of the box, hence in the tile: "never looked at => at least the bound
-// away" holds as for the lock-step search, candidates reach the heap in scan order, and the 5th / 6th tie falls back to the lock-step
-// search with exact keys - neighbour sets, certificates' premises and with them every sum are those of the other searches (history
-// independence: tests/test_gpu_round6.py).  The tile holds several times the candidates ONE lane's ball holds (the union of 64 balls),
-// which is why an ALIGNED dense wave stays with the lock-step search (round 1 measured the brute-force box there: 2 x slower).
-
-// [s, e) of the row (y, z) cut to the x sub-cells that balls of squared radius B around the points of the box [f?0, f?1] (cell units,
-// double: the arithmetic the index was built with) can reach; empty where the row lies outside the grid or beyond the grown box.
-// Conservative like ball_row: 1e-5 relative + 1e-4 of a sub-cell.
-DCREG_DEVFN void tile_row(const GridDev &g, double fx0, double fx1, double fy0, double fy1, double fz0, double fz1, float B, int y, int z,
-                          uint32_t &s_out, uint32_t &e_out) {
-    const float hf = (float)g.h;
-    // gap (cells) between the row's slab [y, y + 1] x [z, z + 1] and the box: 0 where they overlap
-    const float gy = (float)fmax(fmax((double)y - fy1, fy0 - (double)(y + 1)), 0.0) * hf;
-    const float gz = (float)fmax(fmax((double)z - fz1, fz0 - (double)(z + 1)), 0.0) * hf;
-    const float dyz = (gy * gy + gz * gz) * 0.99999f;
-    const int sx = g.sx, nxf = g.nx * sx;
-    const float xr = fminf((sqrt_approx(fmaxf(B - dyz, 0.f)) * 1.00001f) * ((float)g.inv_h * (float)sx) + 1e-4f, 1.0e6f);   // sub-cells
-    const double big = 6.0e7 * 16.0;
-    const double lo = floor(fmin(fmax(fx0 * (double)sx - (double)xr, -big), big)), hi = floor(fmin(fmax(fx1 * (double)sx + (double)xr, -big), big));
-    const int x0 = max((int)lo, 0), x1 = min((int)hi, nxf - 1) + 1;
-    const bool ok = !(dyz > B) && y >= 0 && y < g.ny && z >= 0 && z < g.nz && x1 > x0;
-    const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)nxf;     // (garbage when outside: not used then)
-    s_out = g.cell_start[ok ? row + (uint32_t)x0 : 0u];
-    e_out = g.cell_start[ok ? row + (uint32_t)x1 : 0u];
-}
-// the rows of a tile, centre-out: k = 0, 1, 2, 3, 4 ... -> offsets 0, -1, +1, -2, +2 ...
-DCREG_DEVFN int tile_zig(int k) { return (k & 1) ? -((k + 1) >> 1) : (k >> 1); }
-struct TileRows { int ycen, zcen, nky, nkz, ylo, yhi, zlo, zhi; };
-// which rows the box grown by sqrt(B) reaches (clipped to the grid); nky * nkz row slots (some of them outside [lo, hi]: empty)
-DCREG_DEVFN TileRows tile_rows(const GridDev &g, double fy0, double fy1, double fz0, double fz1, float B) {
-    const float rc = fminf(sqrt_approx(fmaxf(B, 0.f)) * 1.00001f * (float)g.inv_h + 1e-4f, 1.0e6f);
-    const double big = 6.0e7;
-    TileRows t;
-    t.ylo = max((int)floor(fmin(fmax(fy0 - (double)rc, -big), big)), 0); t.yhi = min((int)floor(fmin(fmax(fy1 + (double)rc, -big), big)), g.ny - 1);
-    t.zlo = max((int)floor(fmin(fmax(fz0 - (double)rc, -big), big)), 0); t.zhi = min((int)floor(fmin(fmax(fz1 + (double)rc, -big), big)), g.nz - 1);
-    t.ycen = clampi((int)floor(fmin(fmax(0.5 * (fy0 + fy1), -big), big)), min(t.ylo, t.yhi), max(t.ylo, t.yhi));
-    t.zcen = clampi((int)floor(fmin(fmax(0.5 * (fz0 + fz1), -big), big)), min(t.zlo, t.zhi), max(t.zlo, t.zhi));
-    t.nky = (t.yhi < t.ylo) ? 0 : 2 * max(t.ycen - t.ylo, t.yhi - t.ycen) + 1;
-    t.nkz = (t.zhi < t.zlo) ? 0 : 2 * max(t.zcen - t.zlo, t.zhi - t.zcen) + 1;
-    return t;
-}
-
-#if DCREG_ON_DEVICE
-typedef float f4raw __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) f4raw *cptr_f4;      // a load through it at a uniform address is a scalar load
-DCREG_DEVFN float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
-DCREG_DEVFN uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-DCREG_DEVFN float shfl_f(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)__float_as_uint(v))); }
-template <int CTRL, int ROW_MASK>
-DCREG_DEVFN float dpp_get_f(float ident, float v) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(ident), (int)__float_as_uint(v), CTRL, ROW_MASK, 0xF, false));
-}
-DCREG_DEVFN float wave_min_f(float v) {
-    const float I = __builtin_inff();
-    v = fminf(v, dpp_get_f<0x111, 0xF>(I, v)); v = fminf(v, dpp_get_f<0x112, 0xF>(I, v)); v = fminf(v, dpp_get_f<0x114, 0xF>(I, v));
-    v = fminf(v, dpp_get_f<0x118, 0xF>(I, v)); v = fminf(v, dpp_get_f<0x142, 0xA>(I, v)); v = fminf(v, dpp_get_f<0x143, 0xC>(I, v));
-    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
-}
-DCREG_DEVFN float wave_max_f(float v) { return -wave_min_f(-v); }
-constexpr int kTileRounds = 9;          // rounds of 64 rows the run list holds (RunList::s / e)
-
-// in: the lanes that search (`go`: need && reach), their queries and bounds (inflated, <= the search radius; in / out).  Returns false -
-// uniform - when the tile is not worth it or cannot be held (more than max_rows row slots or max_pts candidates): the caller runs the
-// lock-step search then, from `bound` - which may have come back tighter (six real points lie within it).  Also false when a lane ends
-// with a 5th / 6th tie (the exact-key search decides such a set).  true: `st` of every lane that went holds its six nearest, their float
-// distances and the 7th neighbour's lower bound as search6 leaves them.
-//
-// Two passes.  The radius the tile is grown by decides its size, and ONE lane without a good start bound (its probe found fewer than
-// six points) would set it to the search radius for all 64.  So pass 1 takes the SMALLEST of the wave's bounds, B1: every lane scans
-// the tile of B1 with its own bound as the filter.  A lane whose bound (now: the smaller of what it came with and the sixth distance it
-// found, both distances to six real points) is at most B1 has seen every point inside its ball: it is finished, exactly.  If lanes are
-// left, pass 2 restarts THEIR heaps and scans the tile of the largest of their bounds - tight now, because pass 1 measured it.
-DCREG_DEVFN bool tile_search6(const GridDev &g, RunList &rl, bool go, float qx, float qy, float qz, float &bound, float infl, float cap,
-                              float radius_sq_f, uint32_t max_rows, uint32_t max_pts, Set6 &st) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const float I = __builtin_inff();
-    const float bx0 = wave_min_f(go ? qx : I), bx1 = wave_max_f(go ? qx : -I);
-    const float by0 = wave_min_f(go ? qy : I), by1 = wave_max_f(go ? qy : -I);
-    const float bz0 = wave_min_f(go ? qz : I), bz1 = wave_max_f(go ? qz : -I);
-    const double fx0 = ((double)bx0 - g.ox) * g.inv_h, fx1 = ((double)bx1 - g.ox) * g.inv_h;
-    const double fy0 = ((double)by0 - g.oy) * g.inv_h, fy1 = ((double)by1 - g.oy) * g.inv_h;
-    const double fz0 = ((double)bz0 - g.oz) * g.inv_h, fz1 = ((double)bz1 - g.oz) * g.inv_h;
-    const cptr_f4 cp = (cptr_f4)(uintptr_t)g.pts;
-    HeapFast<6> hf;
-    bool open = go;                          // lanes whose search is not finished yet
-    float B = wave_min_f(go ? bound : I);
-    float lb_tile = I;                       // the B of the pass that finished this lane: what it never looked at lies beyond it
-    uint32_t seen = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        // ---- the runs of all rows of the tile of B -> run list; tile size
-        const TileRows tr = tile_rows(g, fy0, fy1, fz0, fz1, B);
-        if (tr.nky > 4096 || tr.nkz > 4096) return false;
-        const uint32_t nslots = (uint32_t)tr.nky * (uint32_t)tr.nkz;
-        if (nslots > max_rows || nslots > (uint32_t)(kTileRounds * kWave)) return false;
-        uint32_t mine = 0;
-        const uint32_t nrounds = (nslots + kWave - 1) / kWave;
-        for (uint32_t r = 0; r < nrounds; ++r) {
-            const uint32_t slot = r * kWave + (uint32_t)lane;
-            uint32_t s_ = 0, e_ = 0;
-            if (slot < nslots) {
-                const int kz = (int)(slot / (uint32_t)tr.nky), ky = (int)(slot - (uint32_t)kz * (uint32_t)tr.nky);
-                const int y = tr.ycen + tile_zig(ky), z = tr.zcen + tile_zig(kz);
-                if (y >= tr.ylo && y <= tr.yhi && z >= tr.zlo && z <= tr.zhi) tile_row(g, fx0, fx1, fy0, fy1, fz0, fz1, B, y, z, s_, e_);
-            }
-            rl.s[r][lane] = s_; rl.e[r][lane] = e_;
-            mine += e_ > s_ ? e_ - s_ : 0u;
-        }
-        uint32_t total = mine;
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) total += (uint32_t)__shfl_xor((int)total, m);
-        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
-        if (total > max_pts) return false;
-        seen += total;
-        // ---- every open lane scans every run
-        if (open || pass == 0) hf.init(bound, infl, cap);       // (a lane pass 1 finished keeps its heap through pass 2)
-        float lim = open ? bound : 0.f;          // nothing at or beyond it can enter (a lane that is not searching takes nothing); tightened at every flush
-        int cnt = 0;
-        auto flush = [&]() {
-            for (int j = 0; j < cnt; ++j) {
-                const PendEntry pe = rl.pend[j][lane];
-                hf.template push<false>(__uint_as_float(pe.d2_bits), 0u, pe.pos, true);
-            }
-            cnt = 0;
-            lim = open ? hf.worst_d2() : 0.f;
-        };
-        auto take = [&](const float4 &c, uint32_t p) {
-            const float d2 = dist2_nofma(qx, qy, qz, c);
-            if (d2 < lim) { rl.pend[cnt][lane] = PendEntry{__float_as_uint(d2), p}; ++cnt; }
-        };
-        // The runs are walked in groups of four candidates, software-pipelined over two SGPR sets: scalar loads return out of order, so
-        // their counter can only be waited down to zero - the group about to be consumed is waited for FIRST (ready(): an empty asm that
-        // reads it), then the next group's loads are issued, then the vector work on the first runs under them.  Slots past the end of a
-        // run read on in the padded array (kPtsPad) and are not taken.
-        uint32_t r = 0, pc = 0, ec = 0;
-        uint32_t rs = 0, re = 0;
-        unsigned long long live = 0ull;
-        if (nrounds > 0u) { rs = rl.s[0][lane]; re = rl.e[0][lane]; live = __builtin_amdgcn_ballot_w64(re > rs); }
-        auto advance = [&]() -> bool {          // the next group: (pc, ec) = its first candidate and the end of its run; uniform
-            pc += 4u;
-            if (pc < ec) return true;
-            for (;;) {
-                if (live == 0ull) {
-                    ++r;
-                    if (r >= nrounds) return false;
-                    rs = rl.s[r][lane]; re = rl.e[r][lane];
-                    live = __builtin_amdgcn_ballot_w64(re > rs);
-                    continue;
-                }
-                const int L = __builtin_ctzll(live);
-                live &= live - 1ull;
-                pc = readlane_u(rs, L); ec = readlane_u(re, L);
-                return true;
-            }
-        };
-        auto ld4 = [&](f4raw (&c)[4], uint32_t p) { c[0] = cp[p]; c[1] = cp[p + 1u]; c[2] = cp[p + 2u]; c[3] = cp[p + 3u]; };
-        auto ready = [&](const f4raw (&c)[4]) { asm volatile("" ::"s"(c[0].x), "s"(c[3].w)); };
-        auto group = [&](const f4raw (&c)[4], uint32_t p, uint32_t e) {
-            take(make_float4(c[0].x, c[0].y, c[0].z, c[0].w), p);
-            if (p + 1u < e) take(make_float4(c[1].x, c[1].y, c[1].z, c[1].w), p + 1u);
-            if (p + 2u < e) take(make_float4(c[2].x, c[2].y, c[2].z, c[2].w), p + 2u);
-            if (p + 3u < e) take(make_float4(c[3].x, c[3].y, c[3].z, c[3].w), p + 3u);
-        };
-        f4raw A[4], Bq[4];
-        uint32_t pA = 0, eA = 0, pB = 0, eB = 0;
-        bool haveA = nrounds > 0u && advance();           // (pc = ec = 0: the first call pops the first run)
-        if (haveA) { pA = pc; eA = ec; ld4(A, pA); }
-        while (haveA) {
-            ready(A);
-            const bool haveB = advance();
-            if (haveB) { pB = pc; eB = ec; ld4(Bq, pB); }
-            if (wave_any(cnt > kPend - 4)) flush();                    // room for four more in every lane
-            group(A, pA, eA);
-            if (!haveB) break;
-            ready(Bq);
-            haveA = advance();
-            if (haveA) { pA = pc; eA = ec; ld4(A, pA); }
-            if (wave_any(cnt > kPend - 4)) flush();
-            group(Bq, pB, eB);
-        }
-        flush();
-        // ---- who is finished: a lane whose ball - the smaller of the bound it came with and the (inflated) sixth distance it found, both
-        // distances six real points lie within - is inside the tile has seen everything in it
-        if (open) {
-            if (hf.pos[5] != kNoIdx) {
-                const float d5 = fmaxf(__uint_as_float(__float_as_uint(hf.d[5]) + 1u), 1.17549435e-38f);      // inclusive, as warm_bound6
-                bound = fminf(bound, fminf(fmaxf(d5, fminf(d5 * infl, cap)), radius_sq_f));
-            }
-            if (bound <= B) { open = false; lb_tile = B; }
-        }
-        if (!wave_any(open)) break;
-        if (pass == 1) return false;             // (cannot happen: pass 2's B is the largest bound left)
-        B = wave_max_f(open ? bound : 0.f);
-    }
-    if (wave_any(go && hf.pos[5] != kNoIdx && hf.d[4] == hf.d[5])) return false;      // the exact-key search decides such a set
-    if (go) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { st.pos[j] = hf.pos[j]; st.d2[j] = hf.d[j]; }
-        st.lb7 = fminf(hf.outside_min, fminf(hf.worst_d2(), lb_tile));
-        st.n_eval = seen; st.n_shell = 1;
-    }
-    return true;
-}
-#endif
-
 // search of one query inside a linearisation: bound (warm or cold), reach test, 6-NN, certificate
-// TILE (device only): a dense wave whose bounds are loose searches as one team over a shared candidate tile (tile_search6 above)
-template <bool SWEEP, int DEPTH = 2, bool TILE = false>
+template <bool SWEEP, int DEPTH = 2>
 DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, bool have_q, bool warm, const uint32_t (&oldpos)[6],
                              float qx, float qy, float qz, Set6 &st, uint32_t &cert) {
     float bound = a.radius_sq_f;
@@ -1619,24 +1397,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
 #pragma unroll
     for (int j = 0; j < 6; ++j) { st.pos[j] = kNoIdx; st.d2[j] = bound; }
     st.lb7 = bound; st.n_eval = 0; st.n_shell = 1;
-    bool done = false;               // uniform
-#if DCREG_ON_DEVICE
-    if constexpr (TILE) {
-        if (a.tile_mode != 0) {
-            // the rule (uniform): at least tile_min_lanes lanes search, and even the SMALLEST of their bounds reaches beyond tile_far cells -
-            // the wave as a whole is far from its surface, the regime in which a lane's own sweep costs thousands of instructions (one loose
-            // bound among tight ones is an outlier, which the tile's first pass deals with).  tile_mode 2 (tests): whenever the tile can be held
-            const uint32_t n_go = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(reach));
-            const float far2 = a.tile_far * (float)g.h;
-            const bool loose = a.tile_mode == 2 || wave_min_f(reach ? bound : __builtin_inff()) > far2 * far2;
-            if (n_go > 0u && (a.tile_mode == 2 || (n_go >= a.tile_min_lanes && loose)))
-                done = tile_search6(g, runs, reach, qx, qy, qz, bound, infl, cap, a.radius_sq_f, a.tile_max_rows, a.tile_max_pts, st);
-            if (done && a.search_count && (threadIdx.x & 63) == 0)      // (statistics: the third word next to the search counter)
-                atomicAdd(a.search_count + (size_t)(blockIdx.x & 63u) * 16 + 2, (unsigned long long)n_go);
-        }
-    }
-#endif
-    if (!done && reach) search6<SWEEP, DEPTH>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st, SWEEP && all_in_space);
+    if (reach) search6<SWEEP, DEPTH>(g, runs, qx, qy, qz, bound, a.max_ring, infl, cap, st, SWEEP && all_in_space);
     cert = make_cert(st, a);
 }
 
@@ -1745,6 +1506,9 @@ DCREG_DEVFN float team_bound(const GridDev &g, const LinArgs &a, const uint32_t 
 #endif
 constexpr int kTeamPre = DCREG_TEAM_PREFETCH;   // rows of a query whose first 64 points are requested together
 constexpr int kTeamMax = 7;            // queries of one wave the team serves (nine rows each: 63 lanes for the table phase)
+DCREG_DEVFN float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
+DCREG_DEVFN uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+DCREG_DEVFN float shfl_f(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)__float_as_uint(v))); }
 
 // team_mask: the lanes (at most kTeamMax) whose queries (qx, qy, qz, bound: valid in those lanes) are searched.  Returns the lanes
 // that were served; each of them holds its six positions (ascending; kNoIdx where fewer than six points lie inside the bound) and

@@ -46,8 +46,6 @@ typedef struct dcreg_launch_stats {
     int64_t points_searched;   /* ... of which went through the 6-NN search (the others' certificates held) */
     int64_t points_team;       /* ... of which were searched by a whole wave at a time (search.hpp team_search6: waves with a few
                                   lanes to search), the rest in lock-step; -1 like points_searched */
-    int64_t points_tile;       /* ... of which were searched over a shared candidate tile (search.hpp tile_search6: dense waves far from
-                                  their surface); -1 like points_searched */
 } dcreg_launch_stats;
 int dcreg_launch_stats_get(dcreg_ctx *, dcreg_launch_stats *, int reset);
 
@@ -109,10 +107,6 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *                        of a pose sums and publishes the pose's row); 0 = a k_finalize launch behind it, as for larger poses;
  *   "curve_x_scale"      next dcreg_set_source: the cells of the source's Hilbert-curve order are 1 / v times as long in x as in y and z
  *                        (v <= 1; default 1 = cubes): experiment of profiles/r04_ablation.md section 16;
- *   "tile_search"        0 / 1 (default) / 2: never / by the rule / whenever it can be held - a dense wave whose bounds are loose searches
- *                        as one team over a shared candidate tile (search.hpp tile_search6) instead of in lock-step; the rule:
- *                        "tile_min_lanes" (48) lanes of the wave search and some bound reaches beyond "tile_far" (2.0) cells; tiles of more
- *                        than "tile_max_rows" (576) row slots or "tile_max_pts" (768) candidates go back to the lock-step search;
  *   "far_loose"          a query that starts with no bound (first launch, or far from the target) probes the occupied cells within this
  *                        many cell sizes of the nearest occupied one for a start bound (default 1.5: profiles/r04_ablation.md section 11). */
 

@@ -118,18 +118,6 @@ def knn(index, q, k=5, max_radius=0.0):
     return idx, d2
 
 
-def tile_points(index, lo, hi, bound, n_target, max_slots=576):
-    """The candidate tile of search.hpp tile_search6 for the box [lo, hi] of queries and one squared bound, replayed on the host ->
-    (number of candidates or -1 where the device declines, uint8 count per original target index)"""
-    lo = np.ascontiguousarray(lo, np.float32).reshape(3); hi = np.ascontiguousarray(hi, np.float32).reshape(3)
-    mark = np.zeros(n_target, np.uint8)
-    L = lib()
-    L.emu_tile_points.restype = C.c_int64
-    L.emu_tile_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]
-    n = L.emu_tile_points(index.ptr, _ptr(lo), _ptr(hi), float(bound), int(max_slots), _ptr(mark))
-    return int(n), mark
-
-
 def ball_query(index, q, bound):
     """The row enumeration of the small-frame advance pass (kernels.hpp k_advance_team) for one query and squared bound, replayed on the
     host -> (n_inside or a negative code where the device would leave the query to k_lin, idx[7], d2[7]: the seven nearest below the bound)"""

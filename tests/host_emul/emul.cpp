@@ -282,7 +282,7 @@ int emu_linearize(void *idx, const float *src_xyz, const uint32_t *order, int64_
     while (k < 100000) { const double safe = (double)k * g.h * (1.0 - 1e-9); if (safe * safe * (1.0 - 1e-6) >= (double)a.radius_sq_f) break; ++k; }
     a.max_ring = k;
     a.warm = warm;
-    a.far_loose = 1.5f; a.tile_mode = 0; a.tile_min_lanes = 48; a.tile_far = 2.f; a.tile_max_rows = 576; a.tile_max_pts = 768;
+    a.far_loose = 1.5f;
     a.prune_infl = (float)((1.0 + p->cert_inflate) * (1.0 + p->cert_inflate));
     a.infl_max_d2 = (float)(4.0 * g.h * g.h);
     a.state = state; a.state_stride = (uint32_t)stride; a.euler = 0; a.dR = nullptr;
@@ -499,31 +499,6 @@ int64_t emu_ball_query(void *idx, const float *q, float bound, int32_t *out_idx,
         out_d2[j] = got ? list[(size_t)j].d2 : INFINITY;
     }
     return (int64_t)list.size();
-}
-
-// Scalar replay of the tile of search.hpp tile_search6 for a box of queries [lo, hi] (metres, float) and one squared bound B: the row slots
-// of tile_rows (centre-out), each cut by tile_row; returns the number of points of all runs and marks them in `mark` ([n_target] bytes,
-// by ORIGINAL index); -1: more than max_slots row slots (the device leaves such a wave to the lock-step search)
-int64_t emu_tile_points(void *idx, const float *lo, const float *hi, float B, int64_t max_slots, uint8_t *mark) {
-    EmuIndex *E = (EmuIndex *)idx;
-    const GridDev &g = E->g;
-    const double fx0 = ((double)lo[0] - g.ox) * g.inv_h, fx1 = ((double)hi[0] - g.ox) * g.inv_h;
-    const double fy0 = ((double)lo[1] - g.oy) * g.inv_h, fy1 = ((double)hi[1] - g.oy) * g.inv_h;
-    const double fz0 = ((double)lo[2] - g.oz) * g.inv_h, fz1 = ((double)hi[2] - g.oz) * g.inv_h;
-    const TileRows tr = tile_rows(g, fy0, fy1, fz0, fz1, B);
-    if (tr.nky > 4096 || tr.nkz > 4096) return -1;
-    const int64_t nslots = (int64_t)tr.nky * tr.nkz;
-    if (nslots > max_slots) return -1;
-    int64_t total = 0;
-    for (int64_t slot = 0; slot < nslots; ++slot) {
-        const int kz = (int)(slot / tr.nky), ky = (int)(slot - (int64_t)kz * tr.nky);
-        const int y = tr.ycen + tile_zig(ky), z = tr.zcen + tile_zig(kz);
-        if (!(y >= tr.ylo && y <= tr.yhi && z >= tr.zlo && z <= tr.zhi)) continue;
-        uint32_t s_ = 0, e_ = 0;
-        tile_row(g, fx0, fx1, fy0, fy1, fz0, fz1, B, y, z, s_, e_);
-        for (uint32_t p = s_; p < e_; ++p) { mark[__float_as_uint(g.pts[p].w)] += 1; ++total; }
-    }
-    return total;
 }
 
 // plane fit alone: Q = 5 neighbours (row-major 5x3); fast = 1 -> plane_fit_qr_fast

@@ -93,122 +93,3 @@ def test_small_host_frames_are_consumed_when_set_source_returns():
                 assert got["n_eff"] == want["n_eff"] and np.array_equal(got["H_upper"], want["H_upper"]) and np.array_equal(got["g"], want["g"])
     finally:
         ctx.close()
-
-
-# ---------------------------------------------------------------- the wave-cooperative tile search (search.hpp tile_search6)
-from oracle import pyoracle as po          # noqa: E402  (the checker)
-from test_gpu_parity import assert_lin_equal, assert_debug_equal          # noqa: E402
-
-TILE_SCENES = {
-    # name: target, radius, offsets (metres) of the source from the target - from aligned to a cell-dozen away
-    "corridor_300k": (lambda: h.scene_corridor(300_000, seed=5), 1.0, (0.0, 0.05, 0.3, 0.8)),
-    "cylinder_60k": (lambda: h.scene_cylinder(60_000, seed=8, noise=0.01), 1.0, (0.02, 0.4)),
-    "planes_r04": (lambda: h.scene_planes(80_000, seed=4), 0.4, (0.0, 0.15, 0.35)),
-    "fixture": (lambda: h.cylinder_cloud(), 1.0, (0.1, 0.6)),
-}
-
-
-@pytest.mark.parametrize("fast", [1, 0])
-@pytest.mark.parametrize("scene", list(TILE_SCENES))
-def test_tile_search_matches_the_oracle_point_by_point(scene, fast):
-    """Every dense wave searches over a shared candidate tile ("tile_search" = 2: whenever the tile can be held): neighbour indices, float
-    distances as bit patterns and gate flags against the oracle's kd-tree, at offsets from aligned to most of the search radius."""
-    gen, radius, offsets = TILE_SCENES[scene]
-    tgt = gen()
-    rng = np.random.default_rng(3)
-    src = (tgt[:: 2] + rng.normal(0, 0.005, tgt[::2].shape)).astype(np.float32)
-    tree = po.KdTree(tgt)
-    ctx = api.Context(0)
-    try:
-        ctx.set_option("fast_plane_fit", fast)
-        ctx.set_option("tile_search", 2); ctx.set_option("tile_max_pts", 1 << 20); ctx.set_option("count_searches", 1)
-        ctx.set_target(tgt, radius); ctx.set_source(src)
-        used = 0
-        for off in offsets:
-            T = h.pose6d_matrix(off * 0.7, -off * 0.5, off * 0.5, 0.002, -0.001, 0.004 * (1 + off))
-            ctx.launch_stats(reset=True)
-            gpu = ctx.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(radius, 1), debug=True)
-            used += ctx.launch_stats(reset=True)["points_tile"]
-            ref = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(radius, 1), debug=True)
-            assert_lin_equal(gpu, ref)
-            assert_debug_equal(gpu, ref)
-        assert used > len(src)            # the tile search did carry (most of) these launches
-    finally:
-        ctx.close()
-
-
-@pytest.mark.parametrize("scene", ["corridor_300k", "cylinder_60k", "lattice_dups", "planes_r04"])
-def test_tile_search_is_invisible(scene):
-    """Walks that mix micrometre steps, decimetre jumps and a metre jump: tile search forced, by the rule, and off give bitwise the same 31
-    sums at every step - whatever the states hold and whoever searched (history independence); ties (the lattice) fall back to the exact
-    keys of the lock-step search."""
-    if scene == "lattice_dups":
-        g = np.arange(0, 14, dtype=np.float32) * 0.3
-        tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
-        tgt, radius = np.concatenate([tgt, tgt[::7]]), 0.7
-        src = (tgt[::3] + np.float32(0.11)).astype(np.float32)
-    else:
-        gen, radius, _ = TILE_SCENES[scene]
-        tgt = gen()
-        src = (tgt[::2] + np.random.default_rng(31).normal(0, 0.004, tgt[::2].shape)).astype(np.float32)
-    prm = api.default_lin_params(radius, 1)
-    ctxs = {}
-    for name, opts in (("forced", {"tile_search": 2, "tile_max_pts": 1 << 20}), ("rule", {"tile_search": 1}), ("off", {"tile_search": 0}),
-                       ("forced_nocert", {"tile_search": 2, "use_certificates": 0})):
-        c = api.Context(0)
-        for k, v in opts.items():
-            c.set_option(k, v)
-        c.set_option("count_searches", 1)
-        c.set_target(tgt, radius); c.set_source(src)
-        ctxs[name] = c
-    T = np.eye(4)
-    steps = [0.0, 1e-6, 1e-3, 0.3, -0.25, 0.02, 0.6, -0.6, 1e-4, 0.1, 1.0, -1.1, 5e-3, 0.0]
-    for k, sz in enumerate(steps):
-        T = h.pose6d_matrix(sz * 0.6, -sz * 0.5, sz * 0.4, sz * 0.002, -sz * 0.001, sz * 0.004) @ T
-        outs = {name: c.linearize(T[:3, :3], T[:3, 3], prm) for name, c in ctxs.items()}
-        for name in ("forced", "rule", "forced_nocert"):
-            assert _same_sums(outs[name], outs["off"]), (scene, name, k)
-    st = {name: c.launch_stats(reset=True) for name, c in ctxs.items()}
-    assert st["off"]["points_tile"] == 0
-    if scene != "lattice_dups":
-        assert st["forced"]["points_tile"] > 0
-    if scene == "corridor_300k":
-        assert st["rule"]["points_tile"] > 0            # (the decimetre and metre jumps: dense waves far from their surface)
-    for c in ctxs.values():
-        c.close()
-
-
-def _same_sums(a, b):
-    return (a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
-            and a["sum_r2"] == b["sum_r2"] and a["sum_b2"] == b["sum_b2"])
-
-
-def test_tile_search_in_whole_pipelined_runs():
-    """Engine level: 30-iteration runs of a 400 k corridor pair from the bench's initial pose (gated, pipelined launches), tile search by the
-    rule / forced / off: every iteration's H, g, counts and pose bitwise the same; the rule used it in the first launches only."""
-    tgt = h.scene_corridor(400_000, seed=9)
-    src = (tgt + np.random.default_rng(10).normal(0, 0.01, tgt.shape)).astype(np.float32)
-    T0 = h.pose6d_matrix(0.05, -0.08, 0.03, h.deg2rad(0.2), h.deg2rad(-0.1), h.deg2rad(0.5))
-    cfg = api.default_config(search_radius=1.0, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=0.0,
-                             CONVERGENCE_THRESH_TRANS=0.0, use_weight_derivative=1, always_compute_schur=1)
-    logs, tiles = {}, {}
-    for name, opts in (("rule", {"tile_search": 1}), ("forced", {"tile_search": 2, "tile_max_pts": 1 << 20}), ("off", {"tile_search": 0})):
-        c = api.Context(0)
-        for k, v in opts.items():
-            c.set_option(k, v)
-        c.set_option("count_searches", 1)
-        c.set_target(tgt, 1.0); c.set_source(src)
-        runs = []
-        for rep in range(2):                       # the second run starts from the first one's converged state
-            res, lg = c.icp_run(T0, "Ours", cfg)
-            runs.append([(np.array(L.H_upper[:]), np.array(L.gradient[:]), L.effective_points, L.corr_pt_count, np.array(L.transform_matrix[:])) for L in lg[:res.iterations]])
-        logs[name] = runs
-        tiles[name] = c.launch_stats(reset=True)
-        c.close()
-    for name in ("rule", "forced"):
-        for rep in range(2):
-            assert len(logs[name][rep]) == len(logs["off"][rep]) == 30
-            for it, (x, y) in enumerate(zip(logs[name][rep], logs["off"][rep])):
-                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]), (name, rep, it)
-    assert tiles["off"]["points_tile"] == 0 and tiles["forced"]["points_tile"] >= tiles["rule"]["points_tile"] > 0
-    assert tiles["rule"]["points_tile"] < tiles["rule"]["points_searched"]
