@@ -109,6 +109,9 @@ def parse_args(argv=None):
     ap.add_argument("--concurrent-pairs", type=int, default=2,
                     help="after the main (one pair at a time) measurement, also time P independent scan pairs running "
                          "CONCURRENTLY on this GPU (one context + stream + host thread each); 0 = skip")
+    ap.add_argument("--prior-map-points", type=int, default=50_000_000,
+                    help="configs.c3_prior_map_50m: one registration of an 8 k-point frame against a seeded prior map of this many points "
+                         "(the regime of the reference's published timings); 0 = skip")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="backend option (dcreg_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
     return ap.parse_args(argv)
@@ -539,20 +542,27 @@ def converged_run(P, D, repeats=10, cold=False):
                 cfg.CONVERGENCE_THRESH_ROT, cfg.CONVERGENCE_THRESH_TRANS, P.w["run_len"])}
 
 
-def c3_registration(D, args, repeats=20):
-    """What the reference itself times (icp_test_runner.cpp:442-461; paper tables 6 / 7: Parking Lot 2.11 ms per registration on 1-10 k-point
+def c3_registration(D, args, repeats=20, prior_map_points=0):
+    """prior_map_points > 0: the same registration against a LARGE seeded prior map (scenes.scene_prior_map: the regime of the reference's
+    published timings, 1-10 k-point frames against 53-241 M-point maps) - map upload + index build reported beside it, once.
+    What the reference itself times (icp_test_runner.cpp:442-461; paper tables 6 / 7: Parking Lot 2.11 ms per registration on 1-10 k-point
     frames): ONE registration of an 8 k-point frame against the 200 k-point map from HOST buffers - dcreg_set_source (upload, curve
     sort) + run to convergence with the yaml's thresholds; the map and its index are resident (the reference's kd-tree of the map is
     built once as well).  The CPU oracle's run of the same pair beside it (8 OpenMP threads, kd-tree of the map built beforehand)."""
     import dcreg_amd
     from dcreg_amd import api, scenes as h
-    tgt, src = h.scene_parkinglot()
+    t_gen = time.perf_counter()
+    tgt, src = h.scene_prior_map(prior_map_points) if prior_map_points else h.scene_parkinglot()
+    t_gen = time.perf_counter() - t_gen
     gt, T0 = h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
     ctx = dcreg_amd.Context(D.local_rank)
     for kv in args.opt:
         k, v = kv.split("=", 1)
         ctx.set_option(k, float(v))
+    t_map = time.perf_counter()
     ctx.set_target(tgt, 0.5)
+    t_map = time.perf_counter() - t_map
+    info = ctx.index_info()
     cfg = api.default_config(search_radius=0.5, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=1e-5,
                              CONVERGENCE_THRESH_TRANS=1e-3, use_weight_derivative=0, always_compute_schur=1, gt_matrix=gt.reshape(16))
     t_src, t_tot, its = [], [], []
@@ -574,16 +584,26 @@ def c3_registration(D, args, repeats=20):
     ctx.set_option("record_launches", 0)
     T = np.eye(4); T[:3, :3] = np.array(res.R[:]).reshape(3, 3); T[:3, 3] = res.t[:]
     te, re_ = api.pose_error(gt, T)
+    # candidates evaluated per query by a cold search at the initial pose (debug dump, untimed): what the index costs at this map's scale
+    ctx.set_source(src)
+    dd = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(0.5, 0), debug=True)
+    ne = (dd["stats"] & 0xFFFF).astype(np.int64)
+    cand = {"mean": float(ne.mean()), "p50": float(np.percentile(ne, 50)), "p90": float(np.percentile(ne, 90)), "p99": float(np.percentile(ne, 99)),
+            "note": "target points whose distance a query's cold search at the initial pose evaluated (k_lin<1> dump)"}
     ctx.close()
     out = {"ms_total": 1e3 * float(np.mean(t_tot)), "ms_total_min": 1e3 * float(np.min(t_tot)), "ms_set_source": 1e3 * float(np.mean(t_src)),
            "ms_iterations": 1e3 * float(np.mean(t_tot) - np.mean(t_src)), "iterations": float(np.mean(its)), "converged": int(res.converged),
            "trans_error_vs_gt_m": float(te), "rot_error_vs_gt_deg": float(re_), "repeats": repeats,
-           "workload": "PK01 stand-in: %d-pt frame vs %d-pt map, radius 0.5, method %s, thresholds 1e-5 rad / 1e-3 m, init / gt poses of config/icp_pk01.yaml; "
-                       "frame from a host buffer every time (dcreg_set_source), map resident" % (len(src), len(tgt), args.method),
+           "workload": "%s: %d-pt frame vs %d-pt map, radius 0.5, method %s, thresholds 1e-5 rad / 1e-3 m, init / gt poses of config/icp_pk01.yaml; "
+                       "frame from a host buffer every time (dcreg_set_source), map resident" % (
+                           "seeded prior map (scenes.scene_prior_map)" if prior_map_points else "PK01 stand-in", len(src), len(tgt), args.method),
+           "candidates_per_query": cand,
+           "map": {"points": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells), "dims": [int(v) for v in info.dims],
+                   "s_set_target_from_host": t_map, "s_scene_generation": t_gen},
            "launch_structure": {"k_lin_alone": int((ser["advanced"] == 0).sum()), "k_advance_team_then_k_lin": int((ser["advanced"] == 2).sum()),
                                 "k_advance_then_k_lin": int((ser["advanced"] == 1).sum()), "searched_per_launch": [int(x) for x in ser["searched"]]},
            "reference_published_ms": 2.11, "reference_source": "paper table 6 / results/long_duration experiments/table3_4/*/dcreg/data_time.txt (Parking Lot, the authors' CPU; real data)"}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and len(tgt) <= 10_000_000:       # (the oracle's kd-tree of a 50 M-point map: minutes of build, 2 GB)
         from oracle import pyoracle as po
         tree = po.KdTree(tgt)
         ocfg = po.default_config(search_radius=0.5, max_iterations=30, kappa_target=10.0, std_reg_gamma=100.0, thresh_rot=1e-5, thresh_trans=1e-3,
@@ -760,6 +780,8 @@ def main(argv=None):
             Q.close()
         if n_gpus == 1:
             sub["c3_pk01_8k_registration"] = c3_registration(D, args)
+            if args.prior_map_points > 0:
+                sub["c3_prior_map_50m"] = c3_registration(D, args, repeats=20, prior_map_points=args.prior_map_points)
             usable = hostinfo.usable_cpus()
             sub["c5_montecarlo_5000"]["by_host_threads"] = c5_host_thread_sweep(D, args, sorted({2, 4, min(16, usable)}))
             api.set_host_threads(host_threads)

@@ -53,6 +53,15 @@ class LaunchStats(C.Structure):
                 ("points_team", C.c_int64)]
 
 
+class MethodStats(C.Structure):
+    _fields_ = [("total_runs", C.c_int64), ("converged_runs", C.c_int64), ("success_rate", C.c_double),
+                ("mean_trans_error", C.c_double), ("std_trans_error", C.c_double), ("min_trans_error", C.c_double), ("max_trans_error", C.c_double),
+                ("mean_rot_error", C.c_double), ("std_rot_error", C.c_double), ("min_rot_error", C.c_double), ("max_rot_error", C.c_double),
+                ("mean_time_ms", C.c_double), ("std_time_ms", C.c_double),
+                ("mean_iterations", C.c_double), ("mean_rmse", C.c_double), ("mean_fitness", C.c_double),
+                ("corr_num", C.c_int64), ("iterations_total", C.c_int64), ("ranks_seen", C.c_int), ("world", C.c_int)]
+
+
 class IndexInfo(C.Structure):
     _fields_ = [("cell", C.c_double), ("origin", C.c_double * 3), ("dims", C.c_int32 * 3),
                 ("n_cells", C.c_int64), ("n_target", C.c_int64), ("n_source", C.c_int64),
@@ -112,7 +121,7 @@ class TrialResult(C.Structure):
 _STRUCTS = {"dcreg_lin_params": LinParams, "dcreg_lin_out": LinOut, "dcreg_lin_debug": LinDebug,
             "dcreg_index_info": IndexInfo, "dcreg_config": Config, "dcreg_analysis": Analysis,
             "dcreg_iter_log": IterLog, "dcreg_icp_result": IcpResult, "dcreg_trial_result": TrialResult,
-            "dcreg_launch_stats": LaunchStats}
+            "dcreg_launch_stats": LaunchStats, "dcreg_method_stats": MethodStats}
 
 # every symbol include/dcreg.h and include/dcreg_debug.h declare
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_void_p)      # dcreg_reduce_fn
@@ -127,6 +136,7 @@ EXPORTS = [
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_icp_run_montecarlo", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
     "dcreg_set_host_threads", "dcreg_get_host_threads", "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
+    "dcreg_montecarlo_job", "dcreg_comm_allgather", "dcreg_comm_info", "dcreg_set_error_message",
 ]
 
 _lib = None
@@ -217,6 +227,12 @@ def load():
     L.dcreg_get_host_threads.argtypes = []
     L.dcreg_icp_run_montecarlo.argtypes = [vp, dp, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
                                            C.POINTER(Config), C.c_int, C.POINTER(TrialResult)]
+    L.dcreg_montecarlo_job.argtypes = [vp, dp, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(Config), C.c_int, dp,
+                                       C.POINTER(MethodStats)]
+    L.dcreg_comm_allgather.argtypes = [vp, dp, dp, C.c_int64]
+    L.dcreg_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dcreg_set_error_message.restype = None
+    L.dcreg_set_error_message.argtypes = [vp, C.c_char_p]
     L.dcreg_sizeof.restype = C.c_size_t
     L.dcreg_sizeof.argtypes = [C.c_char_p]
     L.dcreg_version.restype = C.c_char_p
@@ -657,6 +673,27 @@ class Context:
                                                      float(trans_amp), float(rot_amp_rad), DETECTION[det], HANDLING[hand], C.byref(cfg), int(slots), res),
                     "dcreg_icp_run_montecarlo")
         return [res[i] for i in range(int(n_trials))]
+
+    def montecarlo_job(self, base_xyzrpy, seed, n_trials, trans_amp, rot_amp_rad, method, cfg, slots=0, want_records=True):
+        """dcreg_montecarlo_job: the whole experiment as one C-ABI job over the ranks of this context's communicator (comm_init; none = one
+        rank): shard, run, ONE ncclAllGather, statistics - on every rank.  -> (records [n_trials, 64] float64 or None, stats dict)"""
+        det, hand = METHODS[method]
+        n = int(n_trials)
+        rec = np.zeros((max(n, 1), 64)) if want_records else None
+        st = MethodStats()
+        self._check(self._L.dcreg_montecarlo_job(self._h, _dp(_f64(base_xyzrpy, 6)), int(seed), n, float(trans_amp), float(rot_amp_rad), DETECTION[det],
+                                                 HANDLING[hand], C.byref(cfg), int(slots), _dp(rec) if want_records else None, C.byref(st)),
+                    "dcreg_montecarlo_job")
+        return (rec[:n] if want_records else None), {k: getattr(st, k) for k, _ in MethodStats._fields_}
+
+    def comm_allgather(self, row):
+        """dcreg_comm_allgather: this rank's doubles -> [world, len(row)] on every rank"""
+        rank, world = C.c_int(), C.c_int()
+        self._L.dcreg_comm_info(self._h, C.byref(rank), C.byref(world))
+        row = _f64(row).reshape(-1)
+        out = np.zeros((world.value, len(row)))
+        self._check(self._L.dcreg_comm_allgather(self._h, _dp(row), _dp(out), len(row)), "dcreg_comm_allgather")
+        return out
 
     def icp_run_trials(self, T0s, method, cfg):
         T0s = _f64(T0s).reshape(-1, 4, 4)

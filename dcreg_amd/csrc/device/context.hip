@@ -154,7 +154,12 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
     if (rc) return rc;
     for (int a = 0; a < 3; ++a) if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) { c->fail("target cloud has non-finite coordinates"); return DCREG_E_INVALID; }
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
-    const double max_cells = (double)((int64_t)1 << 27);
+    // The cell table is DENSE (one uint32 per x sub-cell of the bounding box): on a device with 288 GB of HBM a table of 2^30 entries (4 GB:
+    // a 700 m x 700 m x 12 m prior map at 0.25 m cells, two x sub-cells each) is cheaper than any indirection on the search's critical path.
+    // Rounds 1-5 capped it at 2^27 entries and enlarged the cell edge beyond that - a 50 M-point map then got 0.4 m cells without x
+    // sub-cells and three times the candidates per query.  The cap is an option ("max_table_entries", at most 2^31: table indices are
+    // 32-bit in the kernels); beyond it the cell edge still grows.
+    const double max_cells = (double)c->opt_max_table_entries;
     // the radius caps the cell edge (slightly above R so that one ring already covers the radius)
     const double h_cap = radius_hint > 0.0 ? radius_hint * 1.00001 : ext / std::cbrt((double)n) * 4.0;
     uint32_t occ = 0;
@@ -1156,6 +1161,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
 }
 
 const char *dcreg_last_error(const dcreg_ctx *c) { return c ? c->err : "null context"; }
+// (dcreg_debug.h) the host translation units above the device seam leave their error text here
+void dcreg_set_error_message(dcreg_ctx *c, const char *msg) { if (c && msg) c->fail("%s", msg); }
 
 int dcreg_set_stream(dcreg_ctx *c, void *s) {
     if (!c) return DCREG_E_INVALID;
@@ -1193,6 +1200,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
+    else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
     else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)

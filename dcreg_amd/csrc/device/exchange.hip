@@ -156,4 +156,39 @@ int dcreg_comm_allgather_sum(dcreg_ctx *c, double row[32]) {
     return DCREG_OK;
 }
 
+// count doubles of this rank -> recv[world * count], rank-major, on every rank: ONE ncclAllGather on the ctx's stream (the Monte-Carlo
+// experiment's statistics gather, engine.cpp dcreg_montecarlo_job).  Without a communicator: a job of one rank (recv = send).
+int dcreg_comm_allgather(dcreg_ctx *c, const double *send, double *recv, int64_t count) {
+    if (!c || !send || !recv || count < 0) return DCREG_E_INVALID;
+    if (!c->comm || c->comm_world <= 1) { std::memcpy(recv, send, sizeof(double) * (size_t)count); return DCREG_OK; }
+    if (count == 0) return DCREG_OK;
+    RcclApi &A = rccl();
+    if (hipSetDevice(c->device) != hipSuccess) { c->fail("hipSetDevice failed"); return DCREG_E_DEVICE; }
+    const size_t bytes = sizeof(double) * (size_t)count, all = bytes * (size_t)c->comm_world;
+    double *d_send = nullptr, *d_recv = nullptr;
+    if (hipMalloc((void **)&d_send, bytes) != hipSuccess || hipMalloc((void **)&d_recv, all) != hipSuccess) {
+        if (d_send) (void)hipFree(d_send);
+        c->fail("allocating %zu bytes for the gather failed", bytes + all);
+        return DCREG_E_NOMEM;
+    }
+    int rc = DCREG_OK;
+    hipError_t e = hipMemcpyAsync(d_send, send, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const ncclResult_t r = A.AllGather(d_send, d_recv, (size_t)count, ncclDouble, (ncclComm_t)c->comm, c->stream);
+        if (r != ncclSuccess) { c->fail("ncclAllGather failed: %s", A.GetErrorString(r)); rc = DCREG_E_DEVICE; }
+        else e = hipMemcpyAsync(recv, d_recv, all, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (rc == DCREG_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (rc == DCREG_OK && e != hipSuccess) { c->fail("gather failed: %s", hipGetErrorString(e)); rc = DCREG_E_DEVICE; }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_send); (void)hipFree(d_recv);
+    return rc;
+}
+int dcreg_comm_info(const dcreg_ctx *c, int *rank, int *world) {
+    if (!c) return DCREG_E_INVALID;
+    if (rank) *rank = c->comm ? c->comm_rank : 0;
+    if (world) *world = c->comm ? c->comm_world : 1;
+    return DCREG_OK;
+}
+
 }  // extern "C"

@@ -381,6 +381,84 @@ int dcreg_icp_run_montecarlo(dcreg_ctx *ctx, const double base_xyzrpy[6], uint64
     return run_trials_core(ctx, n_trials, R0.data(), t0.data(), detection, handling, cfg, results, slots);
 }
 
+// The experiment as one job over the ranks of the ctx's communicator (include/dcreg.h): shard, run, ONE gather, statistics on every rank.
+int dcreg_montecarlo_job(dcreg_ctx *ctx, const double base_xyzrpy[6], uint64_t seed, int64_t n_trials, double trans_amp, double rot_amp_rad,
+                         int detection, int handling, const dcreg_config *cfg, int slots, double *records, dcreg_method_stats *stats) {
+    if (!ctx || !base_xyzrpy || !cfg || n_trials < 0) return DCREG_E_INVALID;
+    int rank = 0, world = 1;
+    (void)dcreg_comm_info(ctx, &rank, &world);
+    constexpr int REC = DCREG_TRIAL_RECORD_DOUBLES;
+    const int64_t mine = n_trials > rank ? (n_trials - rank + world - 1) / world : 0;      // trials rank, rank + world, ...
+    const int64_t per = (n_trials + world - 1) / world;                                    // fixed-size blocks: padded with trial index -1
+    std::vector<dcreg_trial_result> res((size_t)std::max<int64_t>(mine, 1));
+    int rc = dcreg_icp_run_montecarlo(ctx, base_xyzrpy, seed, rank, world, mine, trans_amp, rot_amp_rad, detection, handling, cfg, slots, res.data());
+    // (a rank whose share failed still takes part in the collective - with an empty block - so that the others do not hang; it reports its error)
+    std::vector<double> blk((size_t)per * REC, 0.0);
+    for (int64_t j = 0; j < per; ++j) blk[(size_t)j * REC + 9] = -1.0;
+    if (rc == DCREG_OK) {
+        for (int64_t j = 0; j < mine; ++j) {
+            const dcreg_trial_result &t = res[(size_t)j];
+            double *r = &blk[(size_t)j * REC];
+            r[0] = t.converged; r[1] = t.iterations; r[2] = t.time_ms; r[3] = t.trans_error_m; r[4] = t.rot_error_deg; r[5] = t.final_rmse;
+            r[6] = t.final_fitness; r[7] = (double)t.corr_num; r[8] = t.status; r[9] = (double)(rank + j * world);
+            for (int k = 0; k < 16; ++k) r[10 + k] = t.final_transform[k];
+            for (int k = 0; k < 21; ++k) r[26 + k] = t.H_upper[k];
+            for (int k = 0; k < 6; ++k) r[47 + k] = t.degenerate_mask[k];
+        }
+    }
+    std::vector<double> all((size_t)per * REC * (size_t)world);
+    const int gc = dcreg_comm_allgather(ctx, blk.data(), all.data(), per * REC);
+    if (rc != DCREG_OK) return rc;
+    if (gc != DCREG_OK) return gc;
+    // order by trial: record k sits in block k % world at row k / world
+    std::vector<uint8_t> seen((size_t)world, 0);
+    std::vector<double> sorted((size_t)n_trials * REC);
+    for (int64_t k = 0; k < n_trials; ++k) {
+        const double *r = &all[((size_t)(k % world) * (size_t)per + (size_t)(k / world)) * REC];
+        if ((int64_t)r[9] != k) {
+            char msg[160];
+            std::snprintf(msg, sizeof(msg), "the gathered record of trial %lld is missing (index %lld in its place): a rank's share failed", (long long)k, (long long)r[9]);
+            dcreg_set_error_message(ctx, msg);
+            return DCREG_E_STATE;
+        }
+        std::memcpy(&sorted[(size_t)k * REC], r, sizeof(double) * REC);
+        seen[(size_t)(k % world)] = 1;
+    }
+    if (records) std::memcpy(records, sorted.data(), sizeof(double) * sorted.size());
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        dcreg_method_stats &s = *stats;
+        s.total_runs = n_trials; s.world = world;
+        for (int r = 0; r < world; ++r) s.ranks_seen += seen[(size_t)r];
+        if (n_trials > 0) {
+            const double n = (double)n_trials;
+            double st = 0, sr = 0, sm = 0, si = 0, srm = 0, sf = 0;
+            s.min_trans_error = s.min_rot_error = std::numeric_limits<double>::infinity();
+            s.max_trans_error = s.max_rot_error = -std::numeric_limits<double>::infinity();
+            for (int64_t k = 0; k < n_trials; ++k) {
+                const double *r = &sorted[(size_t)k * REC];
+                s.converged_runs += r[0] != 0.0;
+                st += r[3]; sr += r[4]; sm += r[2]; si += r[1]; srm += r[5]; sf += r[6];
+                s.corr_num += (int64_t)r[7]; s.iterations_total += (int64_t)r[1];
+                s.min_trans_error = std::min(s.min_trans_error, r[3]); s.max_trans_error = std::max(s.max_trans_error, r[3]);
+                s.min_rot_error = std::min(s.min_rot_error, r[4]); s.max_rot_error = std::max(s.max_rot_error, r[4]);
+            }
+            s.success_rate = (double)s.converged_runs / n;
+            s.mean_trans_error = st / n; s.mean_rot_error = sr / n; s.mean_time_ms = sm / n;
+            s.mean_iterations = si / n; s.mean_rmse = srm / n; s.mean_fitness = sf / n;
+            double vt = 0, vr = 0, vm = 0;
+            for (int64_t k = 0; k < n_trials; ++k) {
+                const double *r = &sorted[(size_t)k * REC];
+                vt += (r[3] - s.mean_trans_error) * (r[3] - s.mean_trans_error);
+                vr += (r[4] - s.mean_rot_error) * (r[4] - s.mean_rot_error);
+                vm += (r[2] - s.mean_time_ms) * (r[2] - s.mean_time_ms);
+            }
+            s.std_trans_error = std::sqrt(vt / n); s.std_rot_error = std::sqrt(vr / n); s.std_time_ms = std::sqrt(vm / n);   // population std (:660-662)
+        }
+    }
+    return DCREG_OK;
+}
+
 // Second engine: TestRunner::Point2PlaneICP (icp_test_runner.cpp:2064-2830), Pose6D state, the Jacobian of :2299-2346 (LOAM's brackets,
 // the reference's coefficient order; include/dcreg.h enum dcreg_parameterization).
 int dcreg_icp_run_euler(dcreg_ctx *ctx, const double pose6d[6], int detection, int handling, const dcreg_config *cfg,
@@ -540,6 +618,7 @@ size_t dcreg_sizeof(const char *name) {
     if (!std::strcmp(name, "dcreg_icp_result")) return sizeof(dcreg_icp_result);
     if (!std::strcmp(name, "dcreg_trial_result")) return sizeof(dcreg_trial_result);
     if (!std::strcmp(name, "dcreg_launch_stats")) return sizeof(dcreg_launch_stats);
+    if (!std::strcmp(name, "dcreg_method_stats")) return sizeof(dcreg_method_stats);
     return 0;
 }
 

@@ -172,6 +172,66 @@ def scene_parkinglot(n_map=200_000, n_frame=8_000, seed=7, extent=45.0, frame_ra
     return tgt, body.astype(np.float32)
 
 
+def scene_prior_map(n_map=50_000_000, n_frame=8_000, seed=11, extent=350.0, frame_range=30.0, noise=0.02):
+    """A LARGE prior map around the PK01 ground-truth position and one LiDAR frame cut out of it - the regime the reference publishes its
+    timings in (1 - 10 k-point frames against 53 - 241 M-point prior maps: README tables 6 / 7, results/long_duration experiments/table3_4).
+    Map: 2 * extent metres square - tilted, gently undulating ground (~ 93 % of the points), building facades (vertical planes 8 m high,
+    ~ 5 %), poles (~ 2 %); at the defaults ~ 100 points per square metre of ground.  Built in float32 blocks (a 50 M-point map is 600 MB;
+    no global shuffle - the index sorts the points anyway).  -> (map [n_map,3] float32 in the map frame, frame [n_frame,3] float32 in the
+    sensor frame); poses = PK01_GT / PK01_INIT."""
+    rng = np.random.default_rng(seed)
+    T_gt = pose6d_matrix(**PK01_GT)
+    c = T_gt[:3, 3].astype(np.float32)
+    n_wall, n_pole = n_map // 20, n_map // 50
+    n_ground = n_map - n_wall - n_pole
+    tgt = np.empty((n_map, 3), np.float32)
+    e = np.float32(extent)
+
+    def height(x, y):           # ground height above c.z - 1.8 at offsets (x, y) from the sensor's footprint
+        return np.float32(0.01) * x - np.float32(0.005) * y + np.float32(0.15) * np.sin(x * np.float32(0.05)) * np.cos(y * np.float32(0.04))
+
+    blk = 1 << 22
+    for i0 in range(0, n_ground, blk):
+        m = min(blk, n_ground - i0)
+        gx = (rng.random(m, dtype=np.float32) * 2 - 1) * e
+        gy = (rng.random(m, dtype=np.float32) * 2 - 1) * e
+        tgt[i0:i0 + m, 0] = c[0] + gx
+        tgt[i0:i0 + m, 1] = c[1] + gy
+        tgt[i0:i0 + m, 2] = c[2] - np.float32(1.8) + height(gx, gy) + rng.standard_normal(m, dtype=np.float32) * np.float32(0.01)
+    # facades: 64 vertical planes, 20 - 60 m long, 8 m high, random position / heading (a dozen of them within the frame's range)
+    nf = 64
+    fc = ((rng.random((nf, 2), dtype=np.float32) * 2 - 1) * e * np.float32(0.9))
+    fc[:12] = (rng.random((12, 2), dtype=np.float32) * 2 - 1) * np.float32(frame_range * 0.9)
+    fh = rng.random(nf, dtype=np.float32) * np.float32(np.pi)
+    fl = np.float32(20.0) + rng.random(nf, dtype=np.float32) * np.float32(40.0)
+    j = rng.integers(0, nf, n_wall)
+    sw = (rng.random(n_wall, dtype=np.float32) - np.float32(0.5)) * fl[j]
+    wx, wy = fc[j, 0] + sw * np.cos(fh[j]), fc[j, 1] + sw * np.sin(fh[j])
+    o = n_ground
+    tgt[o:o + n_wall, 0] = c[0] + wx
+    tgt[o:o + n_wall, 1] = c[1] + wy
+    tgt[o:o + n_wall, 2] = c[2] - np.float32(1.8) + height(wx, wy) + rng.random(n_wall, dtype=np.float32) * np.float32(8.0)
+    # poles: 400 thin vertical cylinders (two dozen within the frame's range)
+    npc = 400
+    pc = (rng.random((npc, 2), dtype=np.float32) * 2 - 1) * e * np.float32(0.95)
+    pc[:24] = (rng.random((24, 2), dtype=np.float32) * 2 - 1) * np.float32(frame_range * 0.9)
+    k = rng.integers(0, npc, n_pole)
+    ang = rng.random(n_pole, dtype=np.float32) * np.float32(2 * np.pi)
+    o += n_wall
+    tgt[o:o + n_pole, 0] = c[0] + pc[k, 0] + np.float32(0.15) * np.cos(ang)
+    tgt[o:o + n_pole, 1] = c[1] + pc[k, 1] + np.float32(0.15) * np.sin(ang)
+    tgt[o:o + n_pole, 2] = c[2] - np.float32(1.8) + height(pc[k, 0], pc[k, 1]) + rng.random(n_pole, dtype=np.float32) * np.float32(4.0)
+    tgt[n_ground:] += rng.standard_normal((n_wall + n_pole, 3), dtype=np.float32) * np.float32(0.005)
+    # one frame: map points within range of the sensor, in the sensor frame, with range noise
+    dx, dy = tgt[:, 0] - c[0], tgt[:, 1] - c[1]
+    near = np.flatnonzero(dx * dx + dy * dy < np.float32(frame_range * frame_range))
+    sel = rng.choice(near, size=min(n_frame, len(near)), replace=False)
+    Rg, tg = T_gt[:3, :3], T_gt[:3, 3]
+    body = (tgt[sel].astype(np.float64) - tg) @ Rg          # R^T (p - t)
+    body += rng.normal(0, noise, body.shape)
+    return tgt, body.astype(np.float32)
+
+
 def write_pcd_xyzi(path, xyz):
     """Binary PCD v0.7, fields x y z intensity (float32), like pcl::io::savePCDFileBinary<PointXYZI>."""
     xyz = np.asarray(xyz, np.float32).reshape(-1, 3)

@@ -128,7 +128,10 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *                   search from the points around the nearest occupied cell (next dcreg_set_target);
  *   "cell", "cell_factor", "x_subdiv", "gap_field": the grid index (cell edge in metres, 0 = auto = cell_factor x the estimated
  *                   5th-neighbour distance; x sub-cells per cell 1..16, default 8; 1 = build the empty-space distance field) at the
- *                   next dcreg_set_target.
+ *                   next dcreg_set_target;
+ *   "max_table_entries" default 2^30 (at most 2^31): entries of the dense cell table - one uint32 per x sub-cell of the target's
+ *                   bounding box; a map whose cells at the wanted edge would need more gets fewer x sub-cells first and a larger cell
+ *                   edge after that (next dcreg_set_target).
  * Profiling / experiment knobs are listed in dcreg_debug.h. */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
@@ -339,6 +342,33 @@ int dcreg_trial_pose(const double base_xyzrpy[6], uint64_t seed, int64_t k, doub
 int dcreg_icp_run_montecarlo(dcreg_ctx *, const double base_xyzrpy[6], uint64_t seed, int64_t first_trial, int64_t trial_stride,
                              int64_t n_trials, double trans_amp, double rot_amp_rad, int detection, int handling,
                              const dcreg_config *, int slots, dcreg_trial_result *results);
+
+/* The Monte-Carlo experiment (BASELINE configs[4]; runMethod's num_runs loop + updateStatistics / finalizeStatistics,
+ * icp_test_runner.cpp:331-390, 604-664) as ONE job over the ranks of the ctx's communicator (dcreg_comm_init; without one: a job of one
+ * rank): this rank runs trials k = rank, rank + world, ... (dcreg_icp_run_montecarlo), the fixed-size trial records of all ranks are
+ * gathered with ONE ncclAllGather (RCCL over xGMI) on the ctx's stream, and EVERY rank receives all n_trials records ordered by trial
+ * and the method's statistics - no host-side collective, no Python.  A record is DCREG_TRIAL_RECORD_DOUBLES doubles:
+ *   [0] converged [1] iterations [2] time_ms [3] trans_error_m [4] rot_error_deg [5] final_rmse [6] final_fitness [7] corr_num
+ *   [8] status [9] trial index [10..25] final transform, row-major [26..46] last Hessian, upper triangle [47..52] degenerate mask.
+ * records: [n_trials * DCREG_TRIAL_RECORD_DOUBLES] or NULL; stats may be NULL. */
+#define DCREG_TRIAL_RECORD_DOUBLES 64
+typedef struct dcreg_method_stats {        /* MethodStatistics, utils.hpp:305-330 */
+    int64_t total_runs, converged_runs;
+    double success_rate;
+    double mean_trans_error, std_trans_error, min_trans_error, max_trans_error;     /* population std (:660-662) */
+    double mean_rot_error, std_rot_error, min_rot_error, max_rot_error;
+    double mean_time_ms, std_time_ms;
+    double mean_iterations, mean_rmse, mean_fitness;
+    int64_t corr_num;              /* correspondences of all final iterations */
+    int64_t iterations_total;      /* ICP iterations of all trials */
+    int ranks_seen;                /* ranks that contributed at least one record (= the communicator's size when every rank did) */
+    int world;
+} dcreg_method_stats;
+int dcreg_montecarlo_job(dcreg_ctx *, const double base_xyzrpy[6], uint64_t seed, int64_t n_trials, double trans_amp, double rot_amp_rad,
+                         int detection, int handling, const dcreg_config *, int slots, double *records, dcreg_method_stats *stats);
+/* the gather on its own: count doubles of this rank -> recv[world * count], rank-major, on every rank; rank / size of the communicator */
+int dcreg_comm_allgather(dcreg_ctx *, const double *send, double *recv, int64_t count);
+int dcreg_comm_info(const dcreg_ctx *, int *rank, int *world);
 
 /* host threads the batched engines may use for the per-trial 6x6 steps (OpenMP; the reference hard-codes 8, :1714).  Launchers
  * that pin OMP_NUM_THREADS=1 (torch.distributed.run) should set this to the CPUs the rank really owns. */

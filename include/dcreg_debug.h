@@ -110,6 +110,9 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "far_loose"          a query that starts with no bound (first launch, or far from the target) probes the occupied cells within this
  *                        many cell sizes of the nearest occupied one for a start bound (default 1.5: profiles/r04_ablation.md section 11). */
 
+/* internal: the host-only translation units above the device seam (engine.cpp) store their error text where dcreg_last_error finds it */
+void dcreg_set_error_message(dcreg_ctx *, const char *msg);
+
 #ifdef __cplusplus
 }
 #endif

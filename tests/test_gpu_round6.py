@@ -93,3 +93,48 @@ def test_small_host_frames_are_consumed_when_set_source_returns():
                 assert got["n_eff"] == want["n_eff"] and np.array_equal(got["H_upper"], want["H_upper"]) and np.array_equal(got["g"], want["g"])
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------- the reference's published regime: a small frame against a large prior map
+from oracle import pyoracle as po                                                          # noqa: E402  (the checker)
+from test_gpu_parity import assert_lin_equal, assert_debug_equal                           # noqa: E402
+from test_gpu_configs import assert_runs_equal, assert_cov_equal, cfg_pair                 # noqa: E402
+
+
+@pytest.mark.timeout(1200)
+def test_registration_against_a_5m_point_prior_map_matches_the_oracle():
+    """8 k-point frame against a 5 M-point seeded prior map (scenes.scene_prior_map: the largest map the oracle's kd-tree handles inside the
+    test timeout; bench.py's c3_prior_map_50m runs the 50 M-point one), R = 0.5, Ours, the yaml's poses and thresholds: neighbour lists, float
+    distances and gate flags of the first linearisation bit for bit; the whole run iteration by iteration; with the dense cell table capped at
+    2^22 entries (the cell edge grows, x sub-cells go: rounds 1-5's behaviour at scale) every iteration's sums are bitwise the same."""
+    tgt, src = h.scene_prior_map(5_000_000, extent=110.0)
+    gt, T0 = h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
+    tree = po.KdTree(tgt)
+    cfg, ocfg = cfg_pair(0.5, 30, 0, 1e-5, 1e-3, gt.reshape(16))
+    runs = {}
+    for name, entries in (("dense", 0), ("capped", 1 << 22)):
+        ctx = api.Context(0)
+        try:
+            if entries:
+                ctx.set_option("max_table_entries", entries)
+            ctx.set_target(tgt, 0.5)
+            ctx.set_source(src)
+            info = ctx.index_info()
+            if name == "dense":
+                gpu = ctx.linearize(T0[:3, :3], T0[:3, 3], api.default_lin_params(0.5, 0), debug=True)
+                ref = po.linearize(tree, src, T0[:3, :3], T0[:3, 3], po.default_lin_params(0.5, 0), debug=True)
+                assert ref["n_eff"] > 3000
+                assert_lin_equal(gpu, ref)
+                assert_debug_equal(gpu, ref)
+                ctx.set_source(src)
+            res, logs = ctx.icp_run(T0, "Ours", cfg)
+            runs[name] = (info.cell, int(info.n_cells), res, [(tuple(L.H_upper[:]), tuple(L.gradient[:]), L.effective_points, L.corr_pt_count) for L in logs])
+            if name == "dense":
+                ores, ologs = po.icp_run(tree, src, T0, "Ours", ocfg)
+                assert_runs_equal(res, logs, ores, ologs)
+                assert_cov_equal(res, ores)
+                assert res.converged == 1 and logs[-1].trans_error_vs_gt < 0.01
+        finally:
+            ctx.close()
+    assert runs["capped"][0] > 1.5 * runs["dense"][0] and runs["capped"][1] * 4 < runs["dense"][1]          # the cap did coarsen the grid ...
+    assert runs["capped"][3] == runs["dense"][3]                                                           # ... and changed no bit of any sum
