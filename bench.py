@@ -256,6 +256,7 @@ class Pair:
             self.mc_base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
             self.mc_rank, self.mc_world = D.rank, D.world
             self.mc_stats, self.mc_ranks_seen, self.D = None, 0, D
+            self.mc_comm, self.mc_native = False, False
 
     def _restart(self):
         self.pos = 0
@@ -300,6 +301,20 @@ class Pair:
         it inside the caller's timed region.  mc_iters counts the ICP iterations of ALL trials (strong scaling: the job is fixed)."""
         from dcreg_amd import montecarlo as mcm
         D = self.D
+        # the product path: ONE C-ABI call per experiment (dcreg_montecarlo_job: shard, run, ncclAllGather of the records on the ctx's
+        # stream, statistics on every rank) - whenever the ranks can form an RCCL communicator, i.e. always except in the gloo test hook
+        if self.mc_world == 1 or D.backend == "nccl":
+            if self.mc_world > 1 and not self.mc_comm:
+                from dcreg_amd import pointshard
+                pointshard.init_native_exchange(self.ctx, D.dist, D.cdev)
+                self.mc_comm = True
+            for _ in range(k):
+                _, st = self.ctx.montecarlo_job(self.mc_base, MC_SEED, MC_TRIALS, 0.5, np.deg2rad(2.0), self.method, self.cfg, slots=MC_SLOTS, want_records=False)
+                self.mc_iters += int(st["iterations_total"])
+                self.mc_ranks_seen = int(st["ranks_seen"])
+                self.mc_native = True
+                self.mc_stats = {kk: (int(v) if isinstance(v, int) else float(v)) for kk, v in st.items() if kk not in ("ranks_seen", "world", "iterations_total")}
+            return
         for _ in range(k):
             mine = mcm.shard_indices(MC_TRIALS, self.mc_rank, self.mc_world)
             res = self.ctx.icp_run_montecarlo(self.mc_base, MC_SEED, self.mc_rank, self.mc_world, len(mine), 0.5, np.deg2rad(2.0), self.method, self.cfg, slots=MC_SLOTS)
@@ -459,7 +474,9 @@ def summarize(name, P, D, m, steps, n_gpus):
         rec["scaling"] = "strong"
         rec["rccl_ranks_seen"] = P.mc_ranks_seen
         rec["montecarlo"] = {"trials": MC_TRIALS, "trials_per_rank": "k = rank mod %d" % n_gpus, "slots_in_flight": MC_SLOTS, "seed": MC_SEED,
-                             "record_gather": "one all_gather of %d-double trial records inside the timed region" % 64,
+                             "record_gather": ("dcreg_montecarlo_job: one ncclAllGather of the 64-double trial records on the context's stream, inside the "
+                                               "C-ABI call and the timed region" if P.mc_native else
+                                               "one torch.distributed all_gather of the 64-double trial records inside the timed region (gloo test hook)"),
                              "statistics": P.mc_stats}
     return rec
 
@@ -823,6 +840,12 @@ def main(argv=None):
         print(json.dumps(result), flush=True)
     P.close()
     D.close()
+    # a job of N ranks whose experiment did not gather records from N ranks is not a measurement of N GPUs: say so with the exit code
+    seen = None
+    if D.rank == 0:
+        seen = main_rec.get("rccl_ranks_seen") if P.mc else (sub.get("c5_montecarlo_5000") or {}).get("rccl_ranks_seen")
+    if seen is not None and seen != n_gpus:
+        sys.exit("bench.py: the Monte-Carlo experiment gathered records from %d rank(s), the job has %d" % (seen, n_gpus))
 
 
 def _cpu_time_runs(po, tree, src, T_init, w, method, threads, budget_s):

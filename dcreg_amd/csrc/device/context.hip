@@ -1198,28 +1198,19 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "x_subdiv") { int sx = 1; while (sx < 16 && (double)(sx * 2) <= v) sx *= 2; c->opt_x_subdiv = sx; }
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
-    else if (k == "fused_batches") c->opt_fused_batches = v != 0.0;   // batches of one-chunk poses finish in the kernel (0: k_finalize)
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
-    else if (k == "far_loose") c->opt_far_loose = v > 0.0 ? v : 1.5;      // cells beyond the nearest occupied cell from which a start bound is probed
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)
     else if (k == "team_stamps") c->opt_team_stamps = v != 0.0;   // timing probe of the small-frame pass (dcreg_team_pass_stamps)
     else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible
-    else if (k == "team_pass_max_points") c->opt_team_pass_max_points = v;
-    else if (k == "team_pass_min_frac") c->opt_team_pass_min_frac = v;
-    else if (k == "team_pass_min_cell_pts") c->opt_team_pass_min_cell_pts = v;
-    else if (k == "advance_lo") c->opt_advance_lo = v;           // ... rule: the last launch searched between these fractions of its points
-    else if (k == "advance_hi") c->opt_advance_hi = v;
     else if (k == "advance_min_blocks") c->opt_advance_min_blocks = (int)v;   // ... and the cloud has at least this many query blocks
     else if (k == "team_search") c->opt_team_max = (int)v;        // lanes a sparse wave serves cooperatively (0 = off, default 7)
     else if (k == "spin") c->opt_spin = v != 0.0;
-    else if (k == "direct_rows") c->opt_direct_rows = v != 0.0;   // launches of <= 64 blocks: block rows straight to the host
     else if (k == "far_bound") c->opt_far_bound = v != 0.0;       // next dcreg_set_target: start bound of far queries from the nearest occupied cell
     else if (k == "dispatch_order") { c->opt_dispatch_order = v != 0.0; c->order_valid = false; }   // heavy query groups first (kernels.hpp k_group_cost)
     else if (k == "keep_source_order") c->opt_keep_source_order = v != 0.0;   // next dcreg_set_source: no Hilbert sort
     else if (k == "gap_field") c->opt_gap_field = v != 0.0;      // takes effect at the next dcreg_set_target
-    else if (k == "xcd_chunk") c->opt_xcd_chunk = (int)v;   // 0 = one contiguous run of query blocks per XCD, c = chunks of c blocks round-robin
     else { c->fail("unknown option '%s'", key); return DCREG_E_INVALID; }
     return DCREG_OK;
 }

@@ -100,12 +100,8 @@ __device__ __forceinline__ int gram_entry_of_slot(int slot) {
     return tab[slot];
 }
 
-// the searches of k_lin sweep the occupied rows of their ball (search.hpp knn_shells); -DDCREG_RING_WALK: the ring walk (experiments)
-#if defined(DCREG_RING_WALK)
-constexpr bool kLinSweep = false;
-#else
+// the searches of k_lin sweep the occupied rows of their ball (search.hpp knn_shells<.., true>); the ring walk is what dcreg_knn runs
 constexpr bool kLinSweep = true;
-#endif
 
 // XCD-aware block remap: hardware places block b on XCD b % 8 (as that XCD's (b / 8)-th block).
 //   chunk == 0: every XCD gets ONE contiguous run of query blocks, so spatially adjacent (Hilbert-ordered) queries share
@@ -159,10 +155,7 @@ struct DebugDev {
 // result is deterministic.  Batched launches (many poses, few blocks
 // each) use k_finalize instead: a ticket per block costs more there than the extra launch (measured, profiles/r01_search_ablation.md
 // addendum 5).
-#if !defined(DCREG_CHUNK)
-#define DCREG_CHUNK 64
-#endif
-constexpr int kChunk = DCREG_CHUNK;
+constexpr int kChunk = 64;
 // counters that many blocks hit with atomics live one per 128-byte line: atomics on ONE line are served one after the other (~11 ns
 // each), whatever word they address - 3907 ticket arrivals on two lines were 10 us of a 46 us kernel
 constexpr int kCounterStride = 32;      // uint32 words
@@ -427,20 +420,14 @@ __device__ __forceinline__ void block_publish(const double *gm0, int gm_stride, 
     }
 }
 
-#if !defined(DCREG_LIN_DEPTH)
-#define DCREG_LIN_DEPTH 2
-#endif
-constexpr int kLinDepth = DCREG_LIN_DEPTH;        // register sets of k_lin's candidate pipeline (search.hpp knn_search DEPTH)
+constexpr int kLinDepth = 2;                      // register sets of k_lin's candidate pipeline (search.hpp knn_search DEPTH)
 // points per block of the advance pass (k_advance below): kAdvTile / kLinBlock query blocks of k_lin
-#if !defined(DCREG_ADV_TILE)
-#define DCREG_ADV_TILE 1536
-#endif
-constexpr int kAdvTile = DCREG_ADV_TILE;
+constexpr int kAdvTile = 1536;
 static_assert(kAdvTile % kLinBlock == 0 && kAdvTile <= 65536, "a tile is a whole number of query blocks; list entries are 16-bit offsets");
 
 // ---------------------------------------------------------------- k_lin
 template <int MODE, bool FUSED, bool FAST, bool GATE = false>
-static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+static __global__ __launch_bounds__(kLinBlock, kLinOcc) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag, GateArgs gt) {
@@ -671,13 +658,10 @@ static __global__ __launch_bounds__(kLinBlock, DCREG_LIN_OCC) void k_lin(const f
 // changes a result (history independence), so the sums are bitwise those of a launch without the pass.  The host decides per launch
 // (context.hip: the fraction of points the last completed launch searched; clouds whose query blocks exceed what the device holds).
 // A point whose new certificate has no slack at all (exact distance ties) is searched again by k_lin - correct, merely slower.
-#if !defined(DCREG_ADV_DEPTH)
-#define DCREG_ADV_DEPTH 4
-#endif
-constexpr int kAdvDepth = DCREG_ADV_DEPTH;        // trips in flight in the pass's searches (search.hpp knn_search DEPTH); > 2: the kernel takes
+constexpr int kAdvDepth = 4;                      // trips in flight in the pass's searches (search.hpp knn_search DEPTH); > 2: the kernel takes
                                                   // the registers of two waves per SIMD - its dense waves are few and each a chain of round trips
 template <bool FAST>
-static __global__ __launch_bounds__(kLinBlock, (DCREG_ADV_DEPTH > 2 ? 2 : DCREG_LIN_OCC)) void k_advance(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
+static __global__ __launch_bounds__(kLinBlock, (kAdvDepth > 2 ? 2 : kLinOcc)) void k_advance(const float4 *__restrict__ src, uint32_t n_src, GridDev g, PoseArg pose1,
                                                                               const PoseArg *__restrict__ poses, LinArgs a,
                                                                               uint32_t *__restrict__ counts, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off
@@ -827,10 +811,7 @@ static __global__ __launch_bounds__(kLinBlock, (DCREG_ADV_DEPTH > 2 ? 2 : DCREG_
 // A frame of 8 k points is ~2000 waves spread over the device.  k_lin then finds the certificates fresh and runs the stored-plane
 // path.  A query the team cannot serve (more layers, rows, candidates or points inside its bound than the lists hold) is left alone:
 // k_lin searches it itself.  Results never depend on who searched (history independence).
-#if !defined(DCREG_TEAM_TILE)
-#define DCREG_TEAM_TILE 4
-#endif
-constexpr int kTeamTile = DCREG_TEAM_TILE;        // points per block (one wave)
+constexpr int kTeamTile = 4;                      // points per block (one wave)
 constexpr int kTeamG = 16;                        // lanes per query
 constexpr int kTeamRows = 64;                     // rows of a ball the group handles (four per lane)
 constexpr int kTeamCand = 8;                      // candidates per lane

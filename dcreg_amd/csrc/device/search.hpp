@@ -41,13 +41,8 @@ inline float med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(
 #endif
 
 constexpr int kBlock = 256;          // 4 waves: the utility kernels
-#if !defined(DCREG_LIN_OCC)
-#define DCREG_LIN_OCC 4            // waves per SIMD the linearisation kernel is compiled for (register budget 512 / that)
-#endif
-#if !defined(DCREG_LIN_BLOCK)
-#define DCREG_LIN_BLOCK 256
-#endif
-constexpr int kLinBlock = DCREG_LIN_BLOCK;   // threads per block of the linearisation kernel: one partial row per kLinBlock source points
+constexpr int kLinOcc = 4;           // waves per SIMD the linearisation kernel is compiled for (register budget 512 / that)
+constexpr int kLinBlock = 256;       // threads per block of the linearisation kernel: one partial row per kLinBlock source points
 constexpr int kSlots = 32;           // doubles per partial row
 constexpr uint32_t kNoIdx = 0xFFFFFFFFu;
 
@@ -200,11 +195,7 @@ struct HeapExact {
 template <int K_>
 struct HeapFast {
     static constexpr int K = K_;
-#if defined(DCREG_NO_DEFER)
-    static constexpr bool kDeferred = false;
-#else
     static constexpr bool kDeferred = true;
-#endif
     // a point that was never offered to push() (filtered out by a bound >= the K-th best) stays outside at distance d2
     DCREG_DEVFN void note_outside(float d2) { outside_min = fminf(outside_min, d2); }
     float d[K];
@@ -383,16 +374,13 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
 // Surface data leaves most of the 9 (y,z) rows empty, so the list is short (~3 runs) and a run switch in the
 // divergent candidate loop costs one ds_read instead of a 9-way register select.
 //
-// Deferred insertion (DCREG_DEFER, the default): while the runs are scanned a candidate is only FILTERED against the lane's
+// Deferred insertion: while the runs are scanned a candidate is only FILTERED against the lane's
 // bound (one compare instead of the 21-instruction sorted insertion) and, if it passes, appended to the lane's pending list;
 // the list is inserted into the heap when some lane of the wave is about to run out of room, and at the end.  With a warm
 // bound ~6 of a query's ~34 candidates pass, so the insertion network runs ~10 times per wave instead of ~63 (it runs for
 // every lane whenever ANY lane has a candidate, which is always).  The pushes reach the heap in scan order, so the result -
 // neighbour set, order among ties, the exact-tie flag - is the one the immediate insertion gives (search.hpp knn_search).
-#if !defined(DCREG_PEND)
-#define DCREG_PEND 7
-#endif
-constexpr int kPend = DCREG_PEND;
+constexpr int kPend = 7;
 static_assert(kPend >= 4, "a trip parks up to four candidates: the pending list must hold them");
 constexpr int kWave = 64;
 struct PendEntry { uint32_t d2_bits, pos; };
@@ -432,10 +420,7 @@ DCREG_DEVFN void push_point(H &hp, float qx, float qy, float qz, const float4 &c
 // (NB: trips whose loads are requested together - a scan that nothing else overlaps, like the start-bound probe of a far query, pays one
 //  memory round trip per NB trips instead of one per trip; the sorted array is padded for the widest batch, kPtsPad)
 constexpr int kPtsPad = 16;
-#if !defined(DCREG_PROBE_BATCH)
-#define DCREG_PROBE_BATCH 2
-#endif
-constexpr int kProbeBatch = DCREG_PROBE_BATCH;   // lin_search6's start-bound probe (at most 48 points)
+constexpr int kProbeBatch = 2;       // lin_search6's start-bound probe (at most 48 points)
 template <class H, int NB>
 DCREG_DEVFN void scan_run(const GridDev &g, uint32_t s, uint32_t e, float qx, float qy, float qz, H &hp) {
     static_assert(4 * NB <= kPtsPad, "slots past the end of the array read its padding");
@@ -1373,11 +1358,7 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
         if (wave_any(far)) {
             // (only the sixth smallest DISTANCE of the probed points is wanted - no positions, no tie bookkeeping: a sorted six of floats
             //  kept by the median trick of HeapFast::push, six instructions per point instead of the 25 of the full insertion network)
-#if defined(DCREG_PROBE_FULLHEAP)
-            HeapFast<6> hb;            // (the A/B of profiles/r05_ablation.md)
-#else
             Top6 hb;
-#endif
             hb.init(bound);
             uint32_t s_ = 0, e_ = 0;
             if (far) {
@@ -1501,10 +1482,7 @@ DCREG_DEVFN float team_bound(const GridDev &g, const LinArgs &a, const uint32_t 
 }
 
 #if DCREG_ON_DEVICE
-#if !defined(DCREG_TEAM_PREFETCH)
-#define DCREG_TEAM_PREFETCH 4
-#endif
-constexpr int kTeamPre = DCREG_TEAM_PREFETCH;   // rows of a query whose first 64 points are requested together
+constexpr int kTeamPre = 4;            // rows of a query whose first 64 points are requested together
 constexpr int kTeamMax = 7;            // queries of one wave the team serves (nine rows each: 63 lanes for the table phase)
 DCREG_DEVFN float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
 DCREG_DEVFN uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }

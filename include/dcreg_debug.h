@@ -83,32 +83,26 @@ int dcreg_kdtree_info(const dcreg_ctx *, int32_t *depth, int32_t *leaf_size, dou
 int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_floats, int k, double max_radius, int index, int repeats,
                     int32_t *idx, float *d2, double *kernel_ms);
 
-/* experiment knobs of dcreg_set_option (defaults are what the product runs with):
+/* test and measurement knobs of dcreg_set_option (defaults are what the product runs with; none changes a result):
  *   "time_kernels"       see dcreg_kernel_time;
- *   "xcd_chunk"          query-block -> XCD mapping: 0 = one contiguous run of query blocks per XCD, c = runs of c blocks dealt
- *                        round-robin (default 16);
- *   "keep_source_order"  1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert-curve sort;
- *   "use_certificates"   0 = search every point in every launch (the old neighbours still bound the searches), 1 = default;
- *   "direct_rows"        1 (default) = a single-pose launch of at most 64 blocks publishes its block rows straight to pinned memory and
- *                        the host adds them (in the device's association); 0 = chunk rows as for larger launches;
  *   "count_searches"     see dcreg_launch_stats;
  *   "record_launches"    see dcreg_launch_series;
+ *   "use_certificates"   0 = search every point in every launch (the old neighbours still bound the searches), 1 = default;
+ *   "keep_source_order"  1 = the next dcreg_set_source keeps the caller's point order instead of the Hilbert-curve sort;
  *   "advance"            the advance pass in front of single-pose launches: 0 = never, 1 (default) = when the last completed launch searched
- *                        between "advance_lo" (0.01) and "advance_hi" (0.45) of its points and the cloud has at least "advance_min_blocks"
- *                        (2048) query blocks, 2 = whenever the launch can take it (warm state, certificates in use): tests;
+ *                        between 1 % and 45 % of its points and the cloud has at least "advance_min_blocks" (2048) query blocks, 2 = whenever
+ *                        the launch can take it (warm state, certificates in use): tests;
  *   "team_pass"          the small-frame advance pass (sixteen lanes per query) in front of single-pose launches: 0 = never, 1 (default) =
- *                        for clouds of at most "team_pass_max_points" (16384) points when the last completed launch searched at least
- *                        "team_pass_min_frac" (0.5) of them and the map holds at least "team_pass_min_cell_pts" (3) points per occupied
- *                        cell, 2 = whenever the launch can take it; "team_stamps": see dcreg_team_pass_stamps;
+ *                        for clouds of at most 16384 points when the last completed launch searched at least half of them and the map holds
+ *                        at least 3 points per occupied cell, 2 = whenever the launch can take it; "team_stamps": see dcreg_team_pass_stamps;
  *   "gate_in_kernel"     1 (default) = a pipelined launch of at most 64 query blocks waits for its pose in its first kernel (one kernel boundary
  *                        less); 0 = behind the one-wave gate kernel, like larger launches;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
- *   "fused_batches"      1 (default) = a batched launch whose poses have at most 64 query blocks each finishes inside the kernel (the last block
- *                        of a pose sums and publishes the pose's row); 0 = a k_finalize launch behind it, as for larger poses;
  *   "curve_x_scale"      next dcreg_set_source: the cells of the source's Hilbert-curve order are 1 / v times as long in x as in y and z
- *                        (v <= 1; default 1 = cubes): experiment of profiles/r04_ablation.md section 16;
- *   "far_loose"          a query that starts with no bound (first launch, or far from the target) probes the occupied cells within this
- *                        many cell sizes of the nearest occupied one for a start bound (default 1.5: profiles/r04_ablation.md section 11). */
+ *                        (v <= 1; default 1 = cubes).
+ * Settled and no longer options (rounds 3-5, profiles/r0?_ablation.md): query blocks are dealt to the XCDs in runs of 16;
+ * launches of at most 64 query blocks publish their block rows straight to pinned memory; batched launches of one-chunk poses finish inside
+ * the kernel; a start bound counts as loose 1.5 cells beyond the nearest occupied cell; the windows of the two advance passes as above. */
 
 /* internal: the host-only translation units above the device seam (engine.cpp) store their error text where dcreg_last_error finds it */
 void dcreg_set_error_message(dcreg_ctx *, const char *msg);

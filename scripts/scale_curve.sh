@@ -2,7 +2,9 @@
 # The scaling curve of BASELINE.json's metric on one node, without touching code: python bench.py --gpus N for N = 1 2 4 8 (as many as the
 # node has), one JSON line each under gpurun_out/scale/, then a table - C4 weak scaling (one 1 M x 1 M pair per GPU: `value`) and C5 strong
 # scaling (the 5000-trial Monte-Carlo experiment sharded k = rank mod N, records gathered over RCCL: configs.c5_montecarlo_5000) with the
-# number of ranks RCCL actually carried (rccl_ranks_seen).  usage: scripts/scale_curve.sh [steps] [warmup]
+# number of ranks RCCL actually carried (rccl_ranks_seen).  Besides the table: ONE compact JSON line per N on stdout ({"scale_curve": ...}) and
+# gpurun_out/scale/curve.jsonl.  bench.py itself exits non-zero when the experiment gathered records from fewer ranks than the job has.
+# usage: scripts/scale_curve.sh [steps] [warmup]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/scale; mkdir -p $O
 STEPS=${1:-20}; WARMUP=${2:-5}
 cd $R
@@ -25,6 +27,12 @@ for n in (1, 2, 4, 8):
         continue
     c5 = (d.get("configs") or {}).get("c5_montecarlo_5000") or {}
     rows.append((n, d["value"], d["ms_per_step"], d["roofline"]["frac"], c5.get("value"), c5.get("ms_per_step"), c5.get("rccl_ranks_seen")))
+with open(os.path.join(o, "curve.jsonl"), "w") as out:
+    for n, v4, ms4, fr, v5, ms5, seen in rows:
+        line = json.dumps({"scale_curve": "dcreg-mi355x", "n_gpus": n, "c4_weak_iterations_per_s": v4, "c4_ms_per_step": ms4, "c4_hbm_frac_rank0": fr,
+                           "c5_strong_iterations_per_s": v5, "c5_ms_per_experiment": ms5, "rccl_ranks_seen": seen,
+                           "c4_efficiency_vs_1gpu": v4 / (n * rows[0][1] / rows[0][0]), "c5_speedup_vs_first": (v5 / rows[0][4]) if v5 and rows[0][4] else None})
+        print(line); out.write(line + "\n")
 if rows:
     b4, b5 = rows[0][1], rows[0][4]
     print("| GPUs | C4 weak: it/s (all GPUs) | ms/step | HBM frac (rank 0) | vs N x 1-GPU | C5 strong: it/s | ms / experiment | speed-up | RCCL ranks seen |")

@@ -138,3 +138,34 @@ def test_registration_against_a_5m_point_prior_map_matches_the_oracle():
             ctx.close()
     assert runs["capped"][0] > 1.5 * runs["dense"][0] and runs["capped"][1] * 4 < runs["dense"][1]          # the cap did coarsen the grid ...
     assert runs["capped"][3] == runs["dense"][3]                                                           # ... and changed no bit of any sum
+
+
+def test_the_montecarlo_job_of_one_rank_equals_the_python_driver():
+    """dcreg_montecarlo_job (shard, run, gather over the ctx's communicator, statistics - one C-ABI call) with no communicator is a job of
+    one rank: its records are bitwise those of dcreg_icp_run_montecarlo packed by dcreg_amd/montecarlo.py, its statistics
+    icp_test_runner.cpp:604-664's; with a communicator of one rank (RCCL brought up) the same."""
+    from dcreg_amd import montecarlo as mcm, pointshard
+    pts = h.cylinder_cloud()
+    cfg = api.default_config(search_radius=1.0, max_iterations=30, CONVERGENCE_THRESH_TRANS=1e-3, CONVERGENCE_THRESH_ROT=1e-5, KAPPA_TARGET=10.0,
+                             STD_REG_GAMMA=100.0, use_weight_derivative=1, always_compute_schur=1)
+    base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+    ctx = api.Context(0)
+    try:
+        ctx.set_target(pts, 1.0); ctx.set_source(pts)
+        n = 300
+        want, wstats = mcm.run_montecarlo_native(ctx, "Ours", cfg, base, n, 2024, 0.5, np.deg2rad(2.0), slots=64)
+        for with_comm in (False, True):
+            if with_comm:
+                pointshard.init_native_exchange(ctx)
+            rec, st = ctx.montecarlo_job(base, 2024, n, 0.5, np.deg2rad(2.0), "Ours", cfg, slots=64)
+            cols = [c for c in range(64) if c != mcm.R_TIME]                      # (wall time of a trial: not reproducible)
+            assert np.array_equal(rec[:, cols], want[:, cols])
+            assert st["total_runs"] == n == wstats["total_runs"] and st["converged_runs"] == wstats["converged_runs"] and st["ranks_seen"] == st["world"] == 1
+            assert st["iterations_total"] == int(want[:, mcm.R_ITERS].sum()) and st["corr_num"] == wstats["corr_num"]
+            for k in ("success_rate", "mean_trans_error", "std_trans_error", "min_trans_error", "max_trans_error", "mean_rot_error", "std_rot_error",
+                      "mean_iterations", "mean_rmse", "mean_fitness"):
+                assert np.isclose(st[k], wstats[k], rtol=1e-12, atol=1e-300), k
+            got = ctx.comm_allgather(np.arange(5.0))
+            assert got.shape == (1, 5) and np.array_equal(got[0], np.arange(5.0))
+    finally:
+        ctx.close()
