@@ -1408,6 +1408,29 @@ static __global__ void k_gap_init(const uint32_t *__restrict__ cell_start, int64
         owner[c] = occ ? (uint32_t)c : kNoIdx;
     }
 }
+// The owners the start-bound probe of lin_search6 uses come from a second field of the same kind whose seeds are the DENSE cells only: cells
+// whose three-cell x-run - the very run the probe scans - holds at least min_pts points.  (Round 6: with every occupied cell as a seed the
+// nearest seed of a query 0.8 m below a ceiling was a cell holding the noise tail of that ceiling, one cell layer in front of it - a handful
+// of points, no bound to be had from them; such queries started from the search radius: 350 candidates each, their waves what a run's first
+// launch lasted.  profiles/r06_ablation.md section 3.)  gap2 / owner2 are scratch of the index build; k_owner_merge keeps the dense owner
+// where there is one within the rings and the plain one elsewhere.
+static __global__ void k_gap_init_dense(const uint32_t *__restrict__ cell_start, int nx, int64_t n_cells, int sx, uint32_t min_pts, uint8_t *__restrict__ gap,
+                                        uint32_t *__restrict__ owner) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cells) {
+        const int x = (int)(c % nx);
+        const int64_t row = c - x;
+        const bool own = cell_start[(c + 1) * sx] > cell_start[c * sx];
+        const uint32_t run = cell_start[(row + min(x + 2, nx)) * sx] - cell_start[(row + max(x - 1, 0)) * sx];
+        const bool dense = own && run >= min_pts;
+        gap[c] = dense ? 0 : 255;
+        owner[c] = dense ? (uint32_t)c : kNoIdx;
+    }
+}
+static __global__ void k_owner_merge(uint32_t *__restrict__ owner, const uint32_t *__restrict__ dense_owner, int64_t n_cells) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cells && dense_owner[c] != kNoIdx) owner[c] = dense_owner[c];
+}
 // (a cell of ring r takes, of the owners of its neighbours of ring r - 1, the one nearest to itself - vector propagation, so the owner
 // stays near the foot of the perpendicular instead of drifting along the diagonal; rings r - 1 are final when ring r is written, and
 // a launch only writes cells that are still 255: no cell is read and written in the same launch with a value that matters)
@@ -1454,6 +1477,28 @@ static __global__ void k_ymask(const uint32_t *__restrict__ cell_start, int nx, 
         if (cell_start[row + (int64_t)xe * sx] > cell_start[row + (int64_t)xa * sx]) m |= 1u << b;
     }
     ymask[w] = m;
+}
+
+// the boxes of the row segments (GridDev::rowbox): one thread per (z, y, x block) scans the points of the block's 16 cells
+static __global__ void k_rowbox(const uint32_t *__restrict__ cell_start, const float4 *__restrict__ pts, GridDev g, uint32_t *__restrict__ rowbox) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (int64_t)g.nz * g.ny * g.nxb) return;
+    const int xb = (int)(w % g.nxb), y = (int)((w / g.nxb) % g.ny), z = (int)(w / ((int64_t)g.nxb * g.ny));
+    const int xa = xb * 16, xe = min(xa + 16, g.nx);
+    const int64_t row = ((int64_t)z * g.ny + y) * ((int64_t)g.nx * g.sx);
+    const uint32_t s = cell_start[row + (int64_t)xa * g.sx], e = cell_start[row + (int64_t)xe * g.sx];
+    uint32_t ylo = 255u, yhi = 0u, zlo = 255u, zhi = 0u;
+    for (uint32_t p = s; p < e; ++p) {
+        const float4 c = pts[p];
+        // position inside the cell's cross-section, in the arithmetic the cells were assigned with (k_cell_keys); a point the clamp put into a
+        // border cell from outside it makes the box the whole cross-section
+        const double ty = ((double)c.y - g.oy) * g.inv_h - (double)y, tz = ((double)c.z - g.oz) * g.inv_h - (double)z;
+        const bool odd = !(ty >= 0.0 && ty <= 1.0 && tz >= 0.0 && tz <= 1.0);
+        const uint32_t ly = odd ? 0u : (uint32_t)floor(ty * 255.0), hy = odd ? 255u : (uint32_t)min(ceil(ty * 255.0), 255.0);
+        const uint32_t lz = odd ? 0u : (uint32_t)floor(tz * 255.0), hz = odd ? 255u : (uint32_t)min(ceil(tz * 255.0), 255.0);
+        ylo = min(ylo, ly); yhi = max(yhi, hy); zlo = min(zlo, lz); zhi = max(zhi, hz);
+    }
+    rowbox[w] = ylo | (yhi << 8) | (zlo << 16) | (zhi << 24);
 }
 
 // reductions for dcreg_p2p_error: sum sqrt(d2), sum d2 [dist<thr], count  (deterministic two-stage)

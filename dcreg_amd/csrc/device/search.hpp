@@ -62,6 +62,12 @@ struct GridDev {
     const uint32_t *ymask;        // [nz][nxb][nyw] row occupancy: bit (y & 31) of word ((z * nxb + (x >> 4)) * nyw + (y >> 5)) is set iff
     int nxb, nyw;                 //   one of the 16 cells (x', y, z), x' >> 4 == x >> 4, holds a point.  The bounded searches of the
                                   //   linearisation sweep the occupied rows of their ball through these words (knn_shells<.., true>)
+    const uint32_t *rowbox;       // [nz][ny][nxb] or null: where INSIDE their cells' cross-section the points of a row segment (row (y, z), the 16
+                                  //   cells of x block xb) lie: bytes y-low, y-high, z-low, z-high in 1/255 of the cell edge, rounded outward.
+                                  //   A query d metres from a surface reaches a cap of radius sqrt(2 d t) of a slab of thickness t around it:
+                                  //   with t = the cell edge (all the slab test knows) that is 0.45 m at d = 0.86 m, h = 0.116 m - 350
+                                  //   candidates where the ball holds 20; with the segment's own extent (a floor, a wall: millimetres) the
+                                  //   row's x-run shrinks to what the ball really cuts out of the surface (row_box_gaps; round 6)
 };
 
 struct PoseArg {
@@ -363,6 +369,15 @@ DCREG_DEVFN float sqrt_approx(float x) {
 #else
     return sqrtf(x);
 #endif
+}
+
+// distance (cells, >= 0) along one axis from a query to the points of a row segment whose extent inside the row's cell layer is [lo, hi] / 255
+// of the cell edge (GridDev::rowbox; rounded outward when built): dc = the layer's cell index minus the query's, fr = the query's position
+// inside its own cell (cells).  Conservative: one more 255th on either side and 1e-4 of a cell.
+DCREG_DEVFN float row_box_gap(int dc, float fr, uint32_t lo, uint32_t hi) {
+    const float a = (float)dc + ((float)lo - 1.f) * (1.f / 255.f) - fr;          // the segment's low side, relative to the query
+    const float b = (float)dc + ((float)hi + 1.f) * (1.f / 255.f) - fr;          // ... and its high side
+    return fmaxf(fmaxf(a, -b) - 1e-4f, 0.f);
 }
 
 struct RunList;
@@ -739,13 +754,40 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
             auto sweep_row = [&](int y, int z, float gz) {
                 DCREG_STAT(rows);
                 const float gy = slab(y, cy, fry);
-                const float dyz = (gy * gy + gz * gz) * 0.99999f;
+                float dyz = (gy * gy + gz * gz) * 0.99999f;
                 const float w = hp.worst_d2();
                 if (dyz > w) return;
-                const float xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
-                const int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);           // sub-cell offsets from cxs
-                const int x0 = max(cxs + dlo, 0), x1 = min(cxs + dhi, nxf - 1) + 1;
+                float xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
+                int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);           // sub-cell offsets from cxs
+                int x0 = max(cxs + dlo, 0), x1 = min(cxs + dhi, nxf - 1) + 1;
                 if (x1 <= x0) return;
+                if (g.rowbox) {
+                    // the slab test took the points anywhere in the row's h x h cross-section; the boxes of the x blocks the run spans say where they
+                    // are: the distance to THAT (never smaller than the slab's) cuts the run again - or drops the row
+                    const int b0 = (x0 / sx) >> 4, b1 = ((x1 - 1) / sx) >> 4;
+                    if (b1 - b0 < 4) {
+                        const uint32_t *bw = g.rowbox + ((int64_t)z * ny + y) * nxb + b0;
+                        uint32_t ylo = 255u, yhi = 0u, zlo_ = 255u, zhi_ = 0u;
+                        for (int b = b0; b <= b1; ++b) {
+                            const uint32_t v = bw[b - b0];
+                            DCREG_STAT(table_loads);
+                            if ((v & 0xFFu) <= ((v >> 8) & 0xFFu)) {        // (an empty block holds lo > hi)
+                                ylo = min(ylo, v & 0xFFu); yhi = max(yhi, (v >> 8) & 0xFFu); zlo_ = min(zlo_, (v >> 16) & 0xFFu); zhi_ = max(zhi_, v >> 24);
+                            }
+                        }
+                        if (ylo > yhi) return;                               // no point in any of the blocks the run spans
+                        const float gy2 = row_box_gap(y - cy, fry, ylo, yhi) * hf, gz2 = row_box_gap(z - cz, frz, zlo_, zhi_) * hf;
+                        const float dyz2 = (gy2 * gy2 + gz2 * gz2) * 0.99999f;
+                        if (dyz2 > dyz) {
+                            dyz = dyz2;
+                            if (dyz > w) return;
+                            xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
+                            dlo = (int)floorf(uf - xr_c); dhi = (int)floorf(uf + xr_c);
+                            x0 = max(cxs + dlo, 0); x1 = min(cxs + dhi, nxf - 1) + 1;
+                            if (x1 <= x0) return;
+                        }
+                    }
+                }
                 const int64_t row = ((int64_t)z * ny + y) * nxf;
                 if (abs(y - cy) <= 1 && abs(z - cz) <= 1) {
                     const int l1 = min(x1, cxs - sx), r0 = max(x0, cxs + 2 * sx);
@@ -1344,14 +1386,26 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
         const float loose0 = a.far_loose * (float)g.h;
         // (a bound within 1.5 cells is tight wherever the query sits: the usual case once a trajectory converges - no field byte is
         // loaded for it, and a wave of such queries skips the block)
-        const bool maybe = reach && bound > loose0 * loose0 && fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz;
+        // (round 6: a query OUTSIDE the grid's box - a source displaced beyond the map's extent, the far end of a misaligned corridor - takes the
+        //  grid cell nearest to it: its owner is as real a starting point.  Such queries used to start from the search radius itself: 400
+        //  candidates per lane where the others of the launch evaluate 70, and their waves - the slowest of the launch by a factor of three - were
+        //  what the first launch of a run lasted, profiles/r06_ablation.md section 3)
+        const bool maybe = reach && bound > loose0 * loose0;
         if (wave_any(maybe)) {
             if (maybe) {
-                const int64_t cell = ((int64_t)(int)fz * g.ny + (int)fy) * g.nx + (int)fx;
-                const int f = (int)g.gap[cell];
-                in_space = f >= 2;
+                const int ix = clampi((int)floor(fx), 0, g.nx - 1), iy = clampi((int)floor(fy), 0, g.ny - 1), iz = clampi((int)floor(fz), 0, g.nz - 1);
+                // how far outside the box the query lies (cells, the largest axis, rounded up; 0 inside)
+                const double outd = fmax(fmax(fmax(-fx, fx - (double)g.nx), fmax(-fy, fy - (double)g.ny)), fmax(fmax(-fz, fz - (double)g.nz), 0.0));
+                const int out = (int)ceil(fmin(outd, 1.0e6));
+                const int64_t cell = ((int64_t)iz * g.ny + iy) * g.nx + ix;
+                const int f0 = (int)g.gap[cell];
+                const int f = f0 + out;
+                in_space = f >= 2 && (out == 0 || out >= 2);        // (a query less than two cells outside: its block may still touch occupied cells)
                 const float loose = ((float)f + a.far_loose) * (float)g.h;
-                if (f != 255 && bound > loose * loose) { oc = g.owner[cell]; far = oc != kNoIdx; }
+                // (a bound that is still the search radius itself - nothing known about this query - is loose whatever the field says: seven
+                //  and more cells from its surface "1.5 cells beyond the nearest occupied cell" lies past the radius, and such queries went
+                //  unprobed: a cap of half a metre around the foot of their perpendicular, 450 candidates)
+                if (f0 != 255 && (bound > loose * loose || bound >= a.radius_sq_f)) { oc = g.owner[cell]; far = oc != kNoIdx; }
             }
             all_in_space = !wave_any(reach && !in_space);
         }
@@ -1369,6 +1423,30 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
                 e_ = min(e_, s_ + 48u);
             }
             scan_run<decltype(hb), kProbeBatch>(g, s_, e_, qx, qy, qz, hb);
+            // (round 6) The run along x holds fewer than six points where the surface the query faces is PERPENDICULAR to x - the end wall of a
+            // corridor: three cells of the run, one of them on the wall.  Such queries kept the search radius as their bound (400 candidates
+            // each; their waves were the slowest of a run's first launch by a factor of three): the runs of the four (y,z) rows around the
+            // owner's are probed as well, while some lane of the wave still lacks its six points.
+            bool more = far && !(hb.d[5] < bound);
+            if (wave_any(more)) {
+                uint32_t ox = 0, oy = 0, oz = 0;
+                if (more) { ox = oc % (uint32_t)g.nx; const uint32_t r_ = oc / (uint32_t)g.nx; oy = r_ % (uint32_t)g.ny; oz = r_ / (uint32_t)g.ny; }
+#pragma unroll 1
+                for (int k = 0; k < 4 && wave_any(more); ++k) {
+                    uint32_t s2 = 0, e2 = 0;
+                    if (more) {
+                        const int yy = (int)oy + (k == 0 ? -1 : (k == 1 ? 1 : 0)), zz = (int)oz + (k == 2 ? -1 : (k == 3 ? 1 : 0));
+                        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                            const uint32_t row2 = ((uint32_t)zz * (uint32_t)g.ny + (uint32_t)yy) * (uint32_t)g.nx * (uint32_t)g.sx;
+                            s2 = g.cell_start[row2 + (ox > 0u ? ox - 1u : 0u) * (uint32_t)g.sx];
+                            e2 = g.cell_start[row2 + min(ox + 2u, (uint32_t)g.nx) * (uint32_t)g.sx];
+                            e2 = min(e2, s2 + 48u);
+                        }
+                    }
+                    scan_run<decltype(hb), kProbeBatch>(g, s2, e2, qx, qy, qz, hb);
+                    more = far && !(hb.d[5] < bound);
+                }
+            }
             // (six points closer than the bound: d[5] < bound, and only then does the new bound differ from the old one)
             if (far) bound = fminf(bound, fmaxf(__uint_as_float(__float_as_uint(hb.d[5]) + 1u), 1.17549435e-38f));   // inclusive, as warm_bound6
         }

@@ -64,3 +64,8 @@ for w in order:
 for cap_q in (99.9, 99.0, 95.0):
     cap = np.percentile(tot, cap_q)
     print("waves capped at the p%.1f wave (%d cycles): sum / 4096 = %.1f us" % (cap_q, cap, np.minimum(tot, cap).sum() / 4096.0 / 2400.0))
+# the lanes of the slowest wave: is a lane's work explained by how far it is from its surface?
+w = order[0]
+print("lanes of wave %d: (d1 cm, d5 cm, candidates)" % w)
+print(" ".join("(%.0f,%.0f,%d)" % (d1_w[w][l] * 100, d5_w[w][l] * 100 if np.isfinite(d5_w[w][l]) else -1, ne_w[w][l]) for l in range(64)))
+# candidates against the ideal: target points inside the ball of the TRUE 6th-neighbour distance (what an oracle bound would scan at least)

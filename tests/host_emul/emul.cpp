@@ -21,6 +21,7 @@ struct EmuIndex {
     std::vector<uint8_t> gap;
     std::vector<uint32_t> owner;
     std::vector<uint32_t> ymask;
+    std::vector<uint32_t> rowbox;
     bool sweep = true;
     bool team = false;                  // replay team_search6's algorithm for the queries it would take (tight warm bound)
     int64_t team_served = 0;
@@ -151,29 +152,46 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
         while (rings < 12 && (double)rings * g.h < (radius_hint > 0.0 ? radius_hint : 4.0 * g.h)) ++rings;
         if (rings >= 2) {
             const int nx = g.nx, ny = g.ny, nz = g.nz;
+            // one field: seeds -> `rings` dilation passes (as k_gap_dilate: a cell takes the nearest of the owners of its neighbours of the ring before)
+            auto dilate = [&](std::vector<uint8_t> &gap, std::vector<uint32_t> &owner) {
+                for (int r = 1; r <= rings; ++r) {
+                    std::vector<uint8_t> nxt = gap;
+                    for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
+                        const int64_t c = ((int64_t)z * ny + y) * nx + x;
+                        if (gap[(size_t)c] != 255) continue;
+                        bool hit = false;
+                        int64_t best = INT64_MAX;
+                        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                            const int xx = x + dx, yy = y + dy, zz = z + dz;
+                            if (xx < 0 || yy < 0 || zz < 0 || xx >= nx || yy >= ny || zz >= nz) continue;
+                            const size_t nb = (size_t)(((int64_t)zz * ny + yy) * nx + xx);
+                            if (gap[nb] != (uint8_t)(r - 1)) continue;
+                            const uint32_t o = owner[nb];
+                            const int64_t ox = o % (uint32_t)nx, oy = (o / (uint32_t)nx) % (uint32_t)ny, oz = o / ((uint32_t)nx * (uint32_t)ny);
+                            const int64_t d = (ox - x) * (ox - x) + (oy - y) * (oy - y) + (oz - z) * (oz - z);
+                            if (d < best) { best = d; owner[(size_t)c] = o; hit = true; }
+                        }
+                        if (hit) nxt[(size_t)c] = (uint8_t)r;
+                    }
+                    gap.swap(nxt);
+                }
+            };
             E->gap.assign((size_t)E->n_cells, 255);
             E->owner.assign((size_t)E->n_cells, kNoIdx);
             for (int64_t c = 0; c < E->n_cells; ++c) if (E->cell_start[(size_t)(c + 1) * g.sx] > E->cell_start[(size_t)c * g.sx]) { E->gap[(size_t)c] = 0; E->owner[(size_t)c] = (uint32_t)c; }
-            for (int r = 1; r <= rings; ++r) {
-                std::vector<uint8_t> nxt = E->gap;
-                for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
-                    const int64_t c = ((int64_t)z * ny + y) * nx + x;
-                    if (E->gap[(size_t)c] != 255) continue;
-                    bool hit = false;
-                    int64_t best = INT64_MAX;
-                    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
-                        const int xx = x + dx, yy = y + dy, zz = z + dz;
-                        if (xx < 0 || yy < 0 || zz < 0 || xx >= nx || yy >= ny || zz >= nz) continue;
-                        const size_t nb = (size_t)(((int64_t)zz * ny + yy) * nx + xx);
-                        if (E->gap[nb] != (uint8_t)(r - 1)) continue;
-                        const uint32_t o = E->owner[nb];              // (as k_gap_dilate: the nearest of the neighbours' owners)
-                        const int64_t ox = o % (uint32_t)nx, oy = (o / (uint32_t)nx) % (uint32_t)ny, oz = o / ((uint32_t)nx * (uint32_t)ny);
-                        const int64_t d = (ox - x) * (ox - x) + (oy - y) * (oy - y) + (oz - z) * (oz - z);
-                        if (d < best) { best = d; E->owner[(size_t)c] = o; hit = true; }
-                    }
-                    if (hit) nxt[(size_t)c] = (uint8_t)r;
+            dilate(E->gap, E->owner);
+            {   // the probe's owners: the nearest DENSE cell where there is one within the rings (kernels.hpp k_gap_init_dense / k_owner_merge)
+                std::vector<uint8_t> gap2((size_t)E->n_cells, 255);
+                std::vector<uint32_t> own2((size_t)E->n_cells, kNoIdx);
+                for (int64_t c = 0; c < E->n_cells; ++c) {
+                    const int x = (int)(c % nx);
+                    const int64_t row = c - x;
+                    const bool own = E->cell_start[(size_t)(c + 1) * g.sx] > E->cell_start[(size_t)c * g.sx];
+                    const uint32_t run = E->cell_start[(size_t)(row + std::min(x + 2, nx)) * g.sx] - E->cell_start[(size_t)(row + std::max(x - 1, 0)) * g.sx];
+                    if (own && run >= 6u) { gap2[(size_t)c] = 0; own2[(size_t)c] = (uint32_t)c; }
                 }
-                E->gap.swap(nxt);
+                dilate(gap2, own2);
+                for (int64_t c = 0; c < E->n_cells; ++c) if (own2[(size_t)c] != kNoIdx) E->owner[(size_t)c] = own2[(size_t)c];
             }
             g.gap = E->gap.data(); g.gap_cap = rings; g.owner = E->owner.data();
         }
@@ -190,6 +208,25 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
                 E->ymask[((size_t)z * g.nxb + xb) * g.nyw + (y >> 5)] |= 1u << (y & 31);
         }
         g.ymask = E->ymask.data();
+        // the boxes of the row segments, as k_rowbox
+        E->rowbox.assign((size_t)nz * ny * g.nxb, 0u);
+        for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int xb = 0; xb < g.nxb; ++xb) {
+            const int xa = xb * 16, xe = std::min(xa + 16, nx);
+            const int64_t row = ((int64_t)z * ny + y) * ((int64_t)nx * g.sx);
+            const uint32_t s_ = E->cell_start[(size_t)(row + (int64_t)xa * g.sx)], e_ = E->cell_start[(size_t)(row + (int64_t)xe * g.sx)];
+            uint32_t ylo = 255u, yhi = 0u, zlo = 255u, zhi = 0u;
+            for (uint32_t p = s_; p < e_; ++p) {
+                const float4 c = E->pts[p];
+                const double ty = ((double)c.y - g.oy) * g.inv_h - (double)y, tz = ((double)c.z - g.oz) * g.inv_h - (double)z;
+                const bool odd = !(ty >= 0.0 && ty <= 1.0 && tz >= 0.0 && tz <= 1.0);
+                const uint32_t ly = odd ? 0u : (uint32_t)std::floor(ty * 255.0), hy = odd ? 255u : (uint32_t)std::min(std::ceil(ty * 255.0), 255.0);
+                const uint32_t lz = odd ? 0u : (uint32_t)std::floor(tz * 255.0), hz = odd ? 255u : (uint32_t)std::min(std::ceil(tz * 255.0), 255.0);
+                ylo = std::min(ylo, ly); yhi = std::max(yhi, hy); zlo = std::min(zlo, lz); zhi = std::max(zhi, hz);
+            }
+            E->rowbox[((size_t)z * ny + y) * g.nxb + xb] = ylo | (yhi << 8) | (zlo << 16) | (zhi << 24);
+        }
+        g.rowbox = E->rowbox.data();
+
     }
     return E;
 }
