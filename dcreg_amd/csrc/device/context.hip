@@ -240,16 +240,9 @@ static int build_row_words(dcreg_ctx *c) {
     const int64_t n_words = (int64_t)g.nz * g.nxb * g.nyw;
     if (ensure(c, c->d_ymask, c->ymask_cap, (size_t)n_words)) return DCREG_E_NOMEM;
     hipLaunchKernelGGL(k_ymask, dim3(blocks_for(n_words, 256)), dim3(256), 0, c->stream, c->d_cell_start, g.nx, g.ny, g.nz, g.sx, g.nxb, g.nyw, c->d_ymask);
-    g.rowbox = nullptr;
-    if (c->opt_row_boxes) {          // where inside their cells the points of every row segment lie (search.hpp GridDev::rowbox)
-        const int64_t n_box = (int64_t)g.nz * g.ny * g.nxb;
-        if (ensure(c, c->d_rowbox, c->rowbox_cap, (size_t)n_box)) return DCREG_E_NOMEM;
-        hipLaunchKernelGGL(k_rowbox, dim3(blocks_for(n_box, 256)), dim3(256), 0, c->stream, c->d_cell_start, c->d_tgt, g, c->d_rowbox);
-    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     g.ymask = c->d_ymask;
-    if (c->opt_row_boxes) g.rowbox = c->d_rowbox;
     return DCREG_OK;
 }
 
@@ -1171,7 +1164,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     kdtree_free(c->kd); c->kd = nullptr;
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
-                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_rowbox, c->d_owner,
+                    c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner,
                     c->d_adv_counts, c->d_team_stamps};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
@@ -1227,7 +1220,6 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "small_source_kernel") c->opt_small_source_kernel = v != 0.0;      // (tests: 0 = the radix-sort path for small frames too)
-    else if (k == "row_boxes") c->opt_row_boxes = v != 0.0;     // next dcreg_set_target: 0 = the row sweep prunes on the cells' slabs alone (tests, A/B)
     else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)

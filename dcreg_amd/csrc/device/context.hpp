@@ -154,8 +154,6 @@ struct dcreg_ctx {
     bool opt_far_bound = true;     // far queries with a loose bound start from the points around the nearest occupied cell (search.hpp lin_search6)
     uint32_t *d_owner = nullptr; size_t owner_cap = 0;
     uint32_t *d_ymask = nullptr; size_t ymask_cap = 0;
-    uint32_t *d_rowbox = nullptr; size_t rowbox_cap = 0;     // GridDev::rowbox
-    bool opt_row_boxes = true;
     bool opt_keep_source_order = false;   // experiments only
     // heavy groups first (kernels.hpp k_group_cost): the dispatch order of the query-block groups, estimated once per cloud pair
     bool opt_dispatch_order = true;

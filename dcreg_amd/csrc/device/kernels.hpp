@@ -1479,28 +1479,6 @@ static __global__ void k_ymask(const uint32_t *__restrict__ cell_start, int nx, 
     ymask[w] = m;
 }
 
-// the boxes of the row segments (GridDev::rowbox): one thread per (z, y, x block) scans the points of the block's 16 cells
-static __global__ void k_rowbox(const uint32_t *__restrict__ cell_start, const float4 *__restrict__ pts, GridDev g, uint32_t *__restrict__ rowbox) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= (int64_t)g.nz * g.ny * g.nxb) return;
-    const int xb = (int)(w % g.nxb), y = (int)((w / g.nxb) % g.ny), z = (int)(w / ((int64_t)g.nxb * g.ny));
-    const int xa = xb * 16, xe = min(xa + 16, g.nx);
-    const int64_t row = ((int64_t)z * g.ny + y) * ((int64_t)g.nx * g.sx);
-    const uint32_t s = cell_start[row + (int64_t)xa * g.sx], e = cell_start[row + (int64_t)xe * g.sx];
-    uint32_t ylo = 255u, yhi = 0u, zlo = 255u, zhi = 0u;
-    for (uint32_t p = s; p < e; ++p) {
-        const float4 c = pts[p];
-        // position inside the cell's cross-section, in the arithmetic the cells were assigned with (k_cell_keys); a point the clamp put into a
-        // border cell from outside it makes the box the whole cross-section
-        const double ty = ((double)c.y - g.oy) * g.inv_h - (double)y, tz = ((double)c.z - g.oz) * g.inv_h - (double)z;
-        const bool odd = !(ty >= 0.0 && ty <= 1.0 && tz >= 0.0 && tz <= 1.0);
-        const uint32_t ly = odd ? 0u : (uint32_t)floor(ty * 255.0), hy = odd ? 255u : (uint32_t)min(ceil(ty * 255.0), 255.0);
-        const uint32_t lz = odd ? 0u : (uint32_t)floor(tz * 255.0), hz = odd ? 255u : (uint32_t)min(ceil(tz * 255.0), 255.0);
-        ylo = min(ylo, ly); yhi = max(yhi, hy); zlo = min(zlo, lz); zhi = max(zhi, hz);
-    }
-    rowbox[w] = ylo | (yhi << 8) | (zlo << 16) | (zhi << 24);
-}
-
 // reductions for dcreg_p2p_error: sum sqrt(d2), sum d2 [dist<thr], count  (deterministic two-stage)
 static __global__ __launch_bounds__(kBlock) void k_p2p_partial(const float *__restrict__ d2, int64_t n, double thr, double *__restrict__ part) {
     __shared__ double tile[kBlock / 64][4];

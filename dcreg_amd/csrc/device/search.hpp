@@ -62,12 +62,6 @@ struct GridDev {
     const uint32_t *ymask;        // [nz][nxb][nyw] row occupancy: bit (y & 31) of word ((z * nxb + (x >> 4)) * nyw + (y >> 5)) is set iff
     int nxb, nyw;                 //   one of the 16 cells (x', y, z), x' >> 4 == x >> 4, holds a point.  The bounded searches of the
                                   //   linearisation sweep the occupied rows of their ball through these words (knn_shells<.., true>)
-    const uint32_t *rowbox;       // [nz][ny][nxb] or null: where INSIDE their cells' cross-section the points of a row segment (row (y, z), the 16
-                                  //   cells of x block xb) lie: bytes y-low, y-high, z-low, z-high in 1/255 of the cell edge, rounded outward.
-                                  //   A query d metres from a surface reaches a cap of radius sqrt(2 d t) of a slab of thickness t around it:
-                                  //   with t = the cell edge (all the slab test knows) that is 0.45 m at d = 0.86 m, h = 0.116 m - 350
-                                  //   candidates where the ball holds 20; with the segment's own extent (a floor, a wall: millimetres) the
-                                  //   row's x-run shrinks to what the ball really cuts out of the surface (row_box_gaps; round 6)
 };
 
 struct PoseArg {
@@ -369,15 +363,6 @@ DCREG_DEVFN float sqrt_approx(float x) {
 #else
     return sqrtf(x);
 #endif
-}
-
-// distance (cells, >= 0) along one axis from a query to the points of a row segment whose extent inside the row's cell layer is [lo, hi] / 255
-// of the cell edge (GridDev::rowbox; rounded outward when built): dc = the layer's cell index minus the query's, fr = the query's position
-// inside its own cell (cells).  Conservative: one more 255th on either side and 1e-4 of a cell.
-DCREG_DEVFN float row_box_gap(int dc, float fr, uint32_t lo, uint32_t hi) {
-    const float a = (float)dc + ((float)lo - 1.f) * (1.f / 255.f) - fr;          // the segment's low side, relative to the query
-    const float b = (float)dc + ((float)hi + 1.f) * (1.f / 255.f) - fr;          // ... and its high side
-    return fmaxf(fmaxf(a, -b) - 1e-4f, 0.f);
 }
 
 struct RunList;
@@ -754,40 +739,13 @@ DCREG_DEVFN void knn_shells(const GridDev &g, RunList &rl, float qx, float qy, f
             auto sweep_row = [&](int y, int z, float gz) {
                 DCREG_STAT(rows);
                 const float gy = slab(y, cy, fry);
-                float dyz = (gy * gy + gz * gz) * 0.99999f;
+                const float dyz = (gy * gy + gz * gz) * 0.99999f;
                 const float w = hp.worst_d2();
                 if (dyz > w) return;
-                float xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
-                int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);           // sub-cell offsets from cxs
-                int x0 = max(cxs + dlo, 0), x1 = min(cxs + dhi, nxf - 1) + 1;
+                const float xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
+                const int dlo = (int)floorf(uf - xr_c), dhi = (int)floorf(uf + xr_c);           // sub-cell offsets from cxs
+                const int x0 = max(cxs + dlo, 0), x1 = min(cxs + dhi, nxf - 1) + 1;
                 if (x1 <= x0) return;
-                if (g.rowbox) {
-                    // the slab test took the points anywhere in the row's h x h cross-section; the boxes of the x blocks the run spans say where they
-                    // are: the distance to THAT (never smaller than the slab's) cuts the run again - or drops the row
-                    const int b0 = (x0 / sx) >> 4, b1 = ((x1 - 1) / sx) >> 4;
-                    if (b1 - b0 < 4) {
-                        const uint32_t *bw = g.rowbox + ((int64_t)z * ny + y) * nxb + b0;
-                        uint32_t ylo = 255u, yhi = 0u, zlo_ = 255u, zhi_ = 0u;
-                        for (int b = b0; b <= b1; ++b) {
-                            const uint32_t v = bw[b - b0];
-                            DCREG_STAT(table_loads);
-                            if ((v & 0xFFu) <= ((v >> 8) & 0xFFu)) {        // (an empty block holds lo > hi)
-                                ylo = min(ylo, v & 0xFFu); yhi = max(yhi, (v >> 8) & 0xFFu); zlo_ = min(zlo_, (v >> 16) & 0xFFu); zhi_ = max(zhi_, v >> 24);
-                            }
-                        }
-                        if (ylo > yhi) return;                               // no point in any of the blocks the run spans
-                        const float gy2 = row_box_gap(y - cy, fry, ylo, yhi) * hf, gz2 = row_box_gap(z - cz, frz, zlo_, zhi_) * hf;
-                        const float dyz2 = (gy2 * gy2 + gz2 * gz2) * 0.99999f;
-                        if (dyz2 > dyz) {
-                            dyz = dyz2;
-                            if (dyz > w) return;
-                            xr_c = fminf((sqrt_approx(w - dyz) * 1.00001f) * inv_hfs + 1e-4f, 1.0e6f);
-                            dlo = (int)floorf(uf - xr_c); dhi = (int)floorf(uf + xr_c);
-                            x0 = max(cxs + dlo, 0); x1 = min(cxs + dhi, nxf - 1) + 1;
-                            if (x1 <= x0) return;
-                        }
-                    }
-                }
                 const int64_t row = ((int64_t)z * ny + y) * nxf;
                 if (abs(y - cy) <= 1 && abs(z - cz) <= 1) {
                     const int l1 = min(x1, cxs - sx), r0 = max(x0, cxs + 2 * sx);

@@ -21,7 +21,6 @@ struct EmuIndex {
     std::vector<uint8_t> gap;
     std::vector<uint32_t> owner;
     std::vector<uint32_t> ymask;
-    std::vector<uint32_t> rowbox;
     bool sweep = true;
     bool team = false;                  // replay team_search6's algorithm for the queries it would take (tight warm bound)
     int64_t team_served = 0;
@@ -208,24 +207,6 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
                 E->ymask[((size_t)z * g.nxb + xb) * g.nyw + (y >> 5)] |= 1u << (y & 31);
         }
         g.ymask = E->ymask.data();
-        // the boxes of the row segments, as k_rowbox
-        E->rowbox.assign((size_t)nz * ny * g.nxb, 0u);
-        for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int xb = 0; xb < g.nxb; ++xb) {
-            const int xa = xb * 16, xe = std::min(xa + 16, nx);
-            const int64_t row = ((int64_t)z * ny + y) * ((int64_t)nx * g.sx);
-            const uint32_t s_ = E->cell_start[(size_t)(row + (int64_t)xa * g.sx)], e_ = E->cell_start[(size_t)(row + (int64_t)xe * g.sx)];
-            uint32_t ylo = 255u, yhi = 0u, zlo = 255u, zhi = 0u;
-            for (uint32_t p = s_; p < e_; ++p) {
-                const float4 c = E->pts[p];
-                const double ty = ((double)c.y - g.oy) * g.inv_h - (double)y, tz = ((double)c.z - g.oz) * g.inv_h - (double)z;
-                const bool odd = !(ty >= 0.0 && ty <= 1.0 && tz >= 0.0 && tz <= 1.0);
-                const uint32_t ly = odd ? 0u : (uint32_t)std::floor(ty * 255.0), hy = odd ? 255u : (uint32_t)std::min(std::ceil(ty * 255.0), 255.0);
-                const uint32_t lz = odd ? 0u : (uint32_t)std::floor(tz * 255.0), hz = odd ? 255u : (uint32_t)std::min(std::ceil(tz * 255.0), 255.0);
-                ylo = std::min(ylo, ly); yhi = std::max(yhi, hy); zlo = std::min(zlo, lz); zhi = std::max(zhi, hz);
-            }
-            E->rowbox[((size_t)z * ny + y) * g.nxb + xb] = ylo | (yhi << 8) | (zlo << 16) | (zhi << 24);
-        }
-        g.rowbox = E->rowbox.data();
 
     }
     return E;

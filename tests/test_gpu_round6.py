@@ -194,3 +194,4 @@ def test_one_workgroup_orders_a_small_frame_like_the_radix_sort(n):
     a, b = outs
     assert a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
     assert a["sum_r2"] == b["sum_r2"] and a["sum_b2"] == b["sum_b2"]
+
