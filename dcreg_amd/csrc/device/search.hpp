@@ -458,13 +458,12 @@ DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, ui
         cnt = 0;
         lim = hp.worst_d2();
     };
-    for (uint32_t p = s; p < e; p += 4) {
+    // Two register sets, the loads of the next trip requested before the present one is consumed (round 6): a far query's rows are a few
+    // trips each and nothing else of the wave overlaps them - one memory round trip per trip was most of what the slowest waves of a run's
+    // first launches lasted (profiles/r06_ablation.md section 3).  Same candidates in the same order.
+    auto take4 = [&](const float4 (&c)[4], uint32_t p) {
         DCREG_STAT(trips);
         if (wave_any(cnt > kPend - 4)) flush();
-        float4 c[4];
-        const float4 *cp4 = g.pts + p;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = cp4[u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float d2 = dist2_nofma(qx, qy, qz, c[u]);
@@ -474,6 +473,21 @@ DCREG_DEVFN void scan_run_deferred(const GridDev &g, RunList &rl, uint32_t s, ui
             if (pass) { rl.pend[cnt][tid] = PendEntry{__float_as_uint(d2), p + u}; ++cnt; }
             if (NOTE) om = fminf(om, (valid && !pass) ? d2 : __builtin_inff());
         }
+    };
+    auto load4 = [&](float4 (&c)[4], uint32_t p) {
+        const float4 *cp4 = g.pts + p;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = cp4[u];
+    };
+    float4 ca[4], cb[4];
+    if (s < e) load4(ca, s);
+    for (uint32_t p = s; p < e; p += 8) {
+        const bool second = p + 4 < e;
+        if (second) load4(cb, p + 4);
+        take4(ca, p);
+        if (!second) break;
+        if (p + 8 < e) load4(ca, p + 8);
+        take4(cb, p + 4);
     }
     flush();
     if (NOTE) hp.note_outside(om);
