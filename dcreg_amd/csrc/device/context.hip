@@ -353,15 +353,12 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         // their input order (the sort is stable)
         int levels = 4;
         while (levels < 21 && ((int64_t)1 << (3 * (levels - 4))) < n) ++levels;
-        if (n <= kSmallSrcMax && c->opt_small_source_kernel) {       // one workgroup, one launch (kernels.hpp k_small_source): the same order
-            hipLaunchKernelGGL(k_small_source, dim3(1), dim3(kSmallSrcThreads), 0, c->stream, c->d_src_raw, (uint32_t)n, mn[0], mn[1], mn[2], inv_q,
-                               c->opt_curve_x_scale, 63 - 3 * levels, c->d_src);
-        } else {
-            hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->opt_curve_x_scale, c->d_mkeys, c->d_vals);
-            rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n, 63 - 3 * levels);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
-        }
+        // (round 6: ONE workgroup ordering a frame of <= 8192 points in LDS - keys, bitonic sort, gather, a single launch - was built and
+        //  measured: 35 us of host time instead of 39, and 120 us of DEVICE time in front of the first linearisation instead of 15; removed)
+        hipLaunchKernelGGL(k_curve_keys, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, n, mn[0], mn[1], mn[2], inv_q, c->opt_curve_x_scale, c->d_mkeys, c->d_vals);
+        rc = sort_pairs_u64(c, c->d_mkeys, c->d_mkeys2, c->d_vals, c->d_vals2, (size_t)n, 63 - 3 * levels);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather4, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->d_src_raw, c->d_vals2, n, c->d_src);
     }
     // A small frame from a host buffer went through the context's pinned block (upload_cloud): the caller's buffer is consumed, whatever
     // kind of memory it is, and nothing has to be waited for - the first linearisation queues behind the sort, and a device fault surfaces
@@ -1219,7 +1216,6 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
-    else if (k == "small_source_kernel") c->opt_small_source_kernel = v != 0.0;      // (tests: 0 = the radix-sort path for small frames too)
     else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)

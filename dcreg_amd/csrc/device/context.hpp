@@ -174,7 +174,6 @@ struct dcreg_ctx {
     bool last_pose_valid = false;
     bool opt_fused_batches = true; // batched launches of one-chunk poses sum and publish per pose inside k_lin (kernels.hpp FinArgs::chunks_per_pose)
     double opt_curve_x_scale = 1.0;  // kernels.hpp k_curve_keys: < 1 stretches the patches of the source's curve order along x
-    bool opt_small_source_kernel = true;                // frames of at most 8192 points are ordered by one workgroup (kernels.hpp k_small_source)
     int64_t opt_max_table_entries = (int64_t)1 << 30;   // entries of the dense cell table (x sub-cells of the bounding box) before the cell edge grows
     double opt_far_loose = 1.5;    // search.hpp lin_search6: when a start bound is loose enough to be worth a probe (cells)
     // the advance pass (kernels.hpp k_advance): 0 never, 1 by the rule below, 2 whenever a launch can take it (tests)

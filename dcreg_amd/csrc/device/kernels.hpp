@@ -1289,35 +1289,6 @@ static __global__ void k_curve_keys(const float4 *__restrict__ p, int64_t n, dou
     vals[i] = (uint32_t)i;
 }
 
-// A small frame (the registration path: a few thousand points from a host buffer) ordered along the curve by ONE workgroup: keys, a
-// bitonic sort of (key prefix, input index) in LDS, the gather - one launch instead of the key kernel, the radix sort's passes and the
-// gather kernel (each a launch of a few microseconds of host and device time on a path that lasts well under a millisecond).  The order
-// is the stable radix sort's: the key's bits from lo_bit up, ties in input order.
-constexpr int kSmallSrcMax = 8192, kSmallSrcThreads = 1024;
-static __global__ __launch_bounds__(kSmallSrcThreads) void k_small_source(const float4 *__restrict__ raw, uint32_t n, double ox, double oy, double oz, double inv_q,
-                                                                          double x_scale, int lo_bit, float4 *__restrict__ out) {
-    __shared__ uint64_t key[kSmallSrcMax];            // 64 KB
-    uint32_t np2 = 64;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t i = threadIdx.x; i < np2; i += kSmallSrcThreads)
-        key[i] = i < n ? (((curve_key(raw[i], ox, oy, oz, inv_q, x_scale) >> lo_bit) << 13) | (uint64_t)i) : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += kSmallSrcThreads) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const uint64_t a = key[i], b = key[x];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { key[i] = b; key[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += kSmallSrcThreads) out[i] = raw[(uint32_t)key[i] & (uint32_t)(kSmallSrcMax - 1)];
-}
-
 static __global__ void k_gather4(const float4 *__restrict__ in, const uint32_t *__restrict__ order, int64_t n, float4 *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -1399,7 +1399,10 @@ DCREG_DEVFN void lin_search6(const GridDev &g, RunList &runs, const LinArgs &a, 
             // corridor: three cells of the run, one of them on the wall.  Such queries kept the search radius as their bound (400 candidates
             // each; their waves were the slowest of a run's first launch by a factor of three): the runs of the four (y,z) rows around the
             // owner's are probed as well, while some lane of the wave still lacks its six points.
-            bool more = far && !(hb.d[5] < bound);
+            // (only where the run itself was short: a run of six and more points none of which is inside the bound says the query has no
+            //  six neighbours within reach here - an OUT point of a sparse map -, and four more scans per launch were a fifth of a small
+            //  frame's registration)
+            bool more = far && e_ - s_ < 6u && !(hb.d[5] < bound);
             if (wave_any(more)) {
                 uint32_t ox = 0, oy = 0, oz = 0;
                 if (more) { ox = oc % (uint32_t)g.nx; const uint32_t r_ = oc / (uint32_t)g.nx; oy = r_ % (uint32_t)g.ny; oz = r_ / (uint32_t)g.ny; }

@@ -98,8 +98,6 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "gate_in_kernel"     1 (default) = a pipelined launch of at most 64 query blocks waits for its pose in its first kernel (one kernel boundary
  *                        less); 0 = behind the one-wave gate kernel, like larger launches;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);
- *   "small_source_kernel" 1 (default) = a frame of at most 8192 points is ordered along the curve by one workgroup in one launch; 0 = by the
- *                        key kernel + radix sort + gather of larger clouds (the same order: tests);
  *   "curve_x_scale"      next dcreg_set_source: the cells of the source's Hilbert-curve order are 1 / v times as long in x as in y and z
  *                        (v <= 1; default 1 = cubes).
  * Settled and no longer options (rounds 3-5, profiles/r0?_ablation.md): query blocks are dealt to the XCDs in runs of 16;

@@ -169,29 +169,3 @@ def test_the_montecarlo_job_of_one_rank_equals_the_python_driver():
             assert got.shape == (1, 5) and np.array_equal(got[0], np.arange(5.0))
     finally:
         ctx.close()
-
-
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097, 8000, 8192, 8193])
-def test_one_workgroup_orders_a_small_frame_like_the_radix_sort(n):
-    """Frames of at most 8192 points are ordered along the Hilbert curve by ONE workgroup (kernels.hpp k_small_source: keys, bitonic sort of
-    (key prefix, input index) in LDS, gather) instead of key kernel + radix sort + gather: the same order, hence bitwise the same sums (the
-    sums are taken in processing order) - with duplicated points (equal keys: the tie goes to the input order) in the frame."""
-    tgt = h.scene_cylinder(40_000, seed=6, noise=0.01)
-    rng = np.random.default_rng(n)
-    frame = tgt[rng.integers(0, len(tgt), n)].copy()          # (sampling with replacement: duplicates)
-    frame += rng.normal(0, 0.004, frame.shape).astype(np.float32) * (rng.random((n, 1)) < 0.7)
-    prm = api.default_lin_params(1.0, 1)
-    T = h.pose6d_matrix(0.01, -0.02, 0.01, 0.001, 0.002, -0.003)
-    outs = []
-    for small in (1, 0):
-        ctx = api.Context(0)
-        try:
-            ctx.set_option("small_source_kernel", small)
-            ctx.set_target(tgt, 1.0); ctx.set_source(frame)
-            outs.append(ctx.linearize(T[:3, :3], T[:3, 3], prm))
-        finally:
-            ctx.close()
-    a, b = outs
-    assert a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
-    assert a["sum_r2"] == b["sum_r2"] and a["sum_b2"] == b["sum_b2"]
-
