@@ -525,7 +525,7 @@ static int estimate_dispatch_order(dcreg_ctx *c, const double *R9, const double 
     for (uint32_t k = 0; k < ng; ++k) { sum += est[k]; mx = std::max(mx, (double)est[k]); }
     c->order_uneven = mx * ng > 1.3 * sum;                       // some group costs well above the mean
     std::memcpy(c->est_R, R9, sizeof(c->est_R)); std::memcpy(c->est_t, t3, sizeof(c->est_t));
-    c->order_valid = true; c->est_launch = c->n_launches;
+    c->order_valid = true; c->est_launch = (int64_t)c->seq;
     return DCREG_OK;
 }
 
@@ -625,7 +625,11 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (wanted && !gated) {
             // the estimate holds for poses near the one it was made at (within a cell for every point)
             bool stale = !c->order_valid;
-            if (!stale && c->n_launches - c->est_launch >= 16) {       // (a loop of ungated launches does not re-estimate at every step)
+            // (counted in c->seq, the launch number that is never reset: round 6 found this test dead - it compared with n_launches, which
+            //  dcreg_launch_stats_get(reset) zeroes, so that after one reset of the statistics the order of the moment was kept for good; with
+            //  `bench.py --steps 20 --warmup 5` that was the order estimated at an ALIGNED pose, i.e. none: 355 / 314 / 260 us for the first
+            //  launches of every later run instead of 264 / 216 / 205)
+            if (!stale && (int64_t)c->seq - c->est_launch >= 16) {       // (a loop of ungated launches does not re-estimate at every step)
                 double dr = 0.0, dt = 0.0;
                 for (int k = 0; k < 9; ++k) dr += (R9[k] - c->est_R[k]) * (R9[k] - c->est_R[k]);
                 for (int k = 0; k < 3; ++k) dt += (t3[k] - c->est_t[k]) * (t3[k] - c->est_t[k]);

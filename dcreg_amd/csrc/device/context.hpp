@@ -164,7 +164,7 @@ struct dcreg_ctx {
     bool order_valid = false;       // group_order is the estimate for est_R / est_t; order_uneven: its costs differ enough to matter
     bool order_uneven = false;
     double est_R[9] = {}, est_t[3] = {};
-    int64_t est_launch = 0;         // n_launches when the estimate was made
+    int64_t est_launch = 0;         // the launch number (seq) at which the estimate was made
     double hint_misalign = 1e300;   // dcreg_hint_misalignment
     // "nothing known" (a negative hint: what the engines say at the start of a run) is resolved at the next launch whose pose is known up
     // front: a pose within half a cell of the last linearised one continues that trajectory - the last hint still describes it (a run
