@@ -153,12 +153,23 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
             const int nx = g.nx, ny = g.ny, nz = g.nz;
             // one field: seeds -> `rings` dilation passes (as k_gap_dilate: a cell takes the nearest of the owners of its neighbours of the ring before)
             auto dilate = [&](std::vector<uint8_t> &gap, std::vector<uint32_t> &owner) {
-                for (int r = 1; r <= rings; ++r) {
-                    std::vector<uint8_t> nxt = gap;
-                    for (int z = 0; z < nz; ++z) for (int y = 0; y < ny; ++y) for (int x = 0; x < nx; ++x) {
-                        const int64_t c = ((int64_t)z * ny + y) * nx + x;
-                        if (gap[(size_t)c] != 255) continue;
-                        bool hit = false;
+                // (only the cells next to the ring before can join a ring: they are collected from that ring's cells instead of scanning the grid)
+                std::vector<int64_t> front, cand;
+                for (int64_t c = 0; c < E->n_cells; ++c) if (gap[(size_t)c] == 0) front.push_back(c);
+                std::vector<uint8_t> mark((size_t)E->n_cells, 0);
+                for (int r = 1; r <= rings && !front.empty(); ++r) {
+                    cand.clear();
+                    for (int64_t f : front) {
+                        const int x = (int)(f % nx), y = (int)((f / nx) % ny), z = (int)(f / ((int64_t)nx * ny));
+                        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                            const int xx = x + dx, yy = y + dy, zz = z + dz;
+                            if (xx < 0 || yy < 0 || zz < 0 || xx >= nx || yy >= ny || zz >= nz) continue;
+                            const int64_t nb = ((int64_t)zz * ny + yy) * nx + xx;
+                            if (gap[(size_t)nb] == 255 && !mark[(size_t)nb]) { mark[(size_t)nb] = 1; cand.push_back(nb); }
+                        }
+                    }
+                    for (int64_t c : cand) {
+                        const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((int64_t)nx * ny));
                         int64_t best = INT64_MAX;
                         for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
                             const int xx = x + dx, yy = y + dy, zz = z + dz;
@@ -168,11 +179,11 @@ void *emu_index_build(const float *xyz, int64_t n, double radius_hint, double op
                             const uint32_t o = owner[nb];
                             const int64_t ox = o % (uint32_t)nx, oy = (o / (uint32_t)nx) % (uint32_t)ny, oz = o / ((uint32_t)nx * (uint32_t)ny);
                             const int64_t d = (ox - x) * (ox - x) + (oy - y) * (oy - y) + (oz - z) * (oz - z);
-                            if (d < best) { best = d; owner[(size_t)c] = o; hit = true; }
+                            if (d < best) { best = d; owner[(size_t)c] = o; }
                         }
-                        if (hit) nxt[(size_t)c] = (uint8_t)r;
                     }
-                    gap.swap(nxt);
+                    for (int64_t c : cand) gap[(size_t)c] = (uint8_t)r;       // (after all of the ring's owners are chosen: a ring only reads the ring before)
+                    front.swap(cand);
                 }
             };
             E->gap.assign((size_t)E->n_cells, 255);
