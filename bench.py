@@ -513,6 +513,7 @@ def regime_probe(P, runs=6):
         out[name] = {"launches": int(sel.sum()), "mean_us": mean_us, "min_us": float(us.min()), "max_us": float(us.max()),
                      "share_of_kernel_time": float(us.sum() / (1e3 * ms.sum())),
                      "launches_with_advance_pass": int((ser["advanced"][ok][sel] == 1).sum()), "launches_with_team_pass": int((ser["advanced"][ok][sel] == 2).sum()),
+                     "launches_in_one_wave_blocks": int(ser["one_wave"][ok][sel].sum()),
                      "mean_searched_frac": float(frac_s[sel].mean()), "mean_refitted_frac": float(refit[sel].mean()),
                      "achieved_GBps": algo / (mean_us * 1e-6) / 1e9, "frac": algo / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
     # the first four launches of a run, by position (the launches 0.87 m off the surface)

@@ -556,7 +556,8 @@ class Context:
 
     def launch_series(self, reset=True, cap=1 << 20):
         """dcreg_launch_series (dcreg_debug.h; option "record_launches"): per completed launch its HIP-event time (ms, -1 = untimed),
-        points searched, points refitted and points linearised -> dict of arrays"""
+        points searched, points refitted and points linearised, which pass ran in front (dcreg_launch_series_passes: 0 / 1 / 2) and
+        whether the linearisation kernel ran in one-wave blocks -> dict of arrays"""
         lp = C.POINTER(C.c_int64)
         n = self._L.dcreg_launch_series(self._h, None, None, None, None, 0, 0)
         if n < 0:
@@ -568,7 +569,7 @@ class Context:
         if hasattr(self._L, "dcreg_launch_series_passes"):
             self._L.dcreg_launch_series_passes(self._h, adv.ctypes.data_as(C.POINTER(C.c_uint8)), n)
         self._L.dcreg_launch_series(self._h, _dp(ms), se.ctypes.data_as(lp), rf.ctypes.data_as(lp), pt.ctypes.data_as(lp), n, int(reset))
-        return {"ms": ms, "searched": se, "refitted": rf, "points": pt, "advanced": adv}
+        return {"ms": ms, "searched": se, "refitted": rf, "points": pt, "advanced": adv & 3, "one_wave": (adv >> 2) & 1}
 
     def team_pass_stamps(self):
         """dcreg_team_pass_stamps (option "team_stamps"): [n_blocks, 8] shader-clock words of the last launch that ran the small-frame pass"""

@@ -569,14 +569,14 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     key.radius_sq = a.radius_sq; key.max_thick_sq = a.max_thick_sq; key.min_norm = a.min_norm;
     key.radius_sq_f = a.radius_sq_f; key.cert_r_out = a.cert_r_out; key.cert_r_in = a.cert_r_in; key.fast_plane = c->opt_fast_plane ? 1 : 0;
     const uint32_t nbx = blocks_for(c->n_src, kLinBlock);
-    if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
+    if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots * (kLinBlock / kWave))) return DCREG_E_NOMEM;      // (a row per block, or per tile: k_lin's one-wave instantiation)
     // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
     const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
     // ... and so do batches whose poses are one chunk each (the Monte-Carlo batches: 30 blocks per pose): the last block of a pose sums
     // the pose's rows - block_sum_rows, as k_finalize would - and publishes the pose's result row
     const bool fused = (n_poses == 1) || (n_chunks == 1 && c->opt_fused_batches);
     // a launch of one chunk's worth of blocks: the blocks publish their rows themselves and the host adds them (kernels.hpp FinArgs)
-    const bool direct = fused && n_poses == 1 && nbx <= (uint32_t)kChunk && c->opt_direct_rows;
+    const bool direct = fused && n_poses == 1 && nbx <= (uint32_t)kChunk && c->opt_direct_rows && c->opt_one_wave < 2;     // (one_wave = 2: tile rows even there - tests)
     const size_t n_rows = direct ? (size_t)nbx : (fused ? (size_t)n_chunks * (size_t)n_poses : (size_t)n_poses);      // result rows the host waits for
     if (fused) {   // tickets: zero when (re)allocated, afterwards every completed launch leaves them zero
         const size_t had = S.tickets_cap;
@@ -753,6 +753,16 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
                                          per_cell >= c->opt_team_pass_min_cell_pts);
     }
     if (team) adv = false;
+    // the one-wave instantiation of k_lin (kernels.hpp): fused single-pose launches of many blocks in which most waves search
+    bool one_wave = false;
+    if (n_poses == 1 && fused && !direct && !dbg_host && !stamps_only && !team) {
+        // by the rule: a launch of many blocks whose searches are long - the queries more than a cell and a half from the surface (the
+        // engines' hint, as for the dispatch order above; unknown at the start of a run = far) - and most of whose points search
+        const bool known = c->last_searched >= 0 && c->last_points == n;
+        const bool most = !uses_state || one.fresh != 0u || !a.use_cert || (known && (double)c->last_searched >= c->opt_one_wave_min_frac * (double)n);
+        one_wave = c->opt_one_wave >= 2 || (c->opt_one_wave == 1 && nbx >= (uint32_t)c->opt_one_wave_min_blocks && !adv && most &&
+                                            c->hint_misalign > c->opt_one_wave_min_cells * c->grid.h);
+    }
     const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
     if (adv || team) {      // the passes' counts, per query block of k_lin: zero between launches (k_lin takes them and zeroes them again)
         const size_t had = c->adv_counts_cap;
@@ -864,6 +874,12 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         } else
         if (stamps_only) { if (fast) DCREG_LAUNCH_LIN(2, true, true); else DCREG_LAUNCH_LIN(2, true, false); }     // (the probe writes the shared state: same fit as the plain launches)
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
+        else if (one_wave) {               // one-wave blocks: a grid of tiles
+            const dim3 tiles(nbx * (kLinBlock / kWave), 1u);
+            if (fast) hipLaunchKernelGGL((k_lin<0, true, true, false, true>), tiles, dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a, S.d_partials, nbx, fin, dd, abort_flag, gt);
+            else hipLaunchKernelGGL((k_lin<0, true, false, false, true>), tiles, dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a, S.d_partials, nbx, fin, dd, abort_flag, gt);
+            hipLaunchKernelGGL(k_sum_tiles, dim3(n_chunks), dim3(kLinBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq, abort_flag);
+        }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
         else { if (fast) DCREG_LAUNCH_LIN(0, false, true); else DCREG_LAUNCH_LIN(0, false, false); }
 #undef DCREG_LAUNCH_LIN
@@ -902,7 +918,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     S.pending = true; S.n_poses = n_poses; S.n_chunks = n_chunks; S.n_rows = n_rows; S.fused = fused; S.direct = direct; S.timed = timed;
     S.seq = seq; S.sync = dbg_host != nullptr;
     S.stamps_only = stamps_only;
-    S.advanced = adv ? 1 : (team ? 2 : 0);
+    S.advanced = (adv ? 1 : (team ? 2 : 0)) | (one_wave ? 4 : 0);
     S.coded = a.count_scale != 0.0;        // how THIS launch's count slots are to be read (the source may be replaced while it is pending)
     if (gated) {
         c->gate_slot = slot;
@@ -1222,6 +1238,10 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
     else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
+    else if (k == "one_wave") c->opt_one_wave = (int)v;                  // k_lin in one-wave blocks: 0 never, 1 by the rule (launches of many blocks in which most waves search), 2 wherever possible
+    else if (k == "one_wave_min_frac") c->opt_one_wave_min_frac = v;
+    else if (k == "one_wave_min_cells") c->opt_one_wave_min_cells = v;
+    else if (k == "one_wave_min_blocks") c->opt_one_wave_min_blocks = (int)v;
     else if (k == "gate_in_kernel") c->opt_gate_in_kernel = v != 0.0;     // pipelined launches of at most 64 query blocks wait for their pose in their first kernel (1, default) or behind k_gate (0)
     else if (k == "team_stamps") c->opt_team_stamps = v != 0.0;   // timing probe of the small-frame pass (dcreg_team_pass_stamps)
     else if (k == "team_pass") c->opt_team_pass = (int)v;        // the small-frame advance pass: 0 never, 1 (default) by the host's rule, 2 whenever possible

@@ -36,7 +36,7 @@ struct LinSlot {
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // "time_kernels": the events of this slot's launch (the two slots alternate in a pipelined run)
     bool stamps_only = false;
-    int advanced = 0;              // an advance pass ran in front of the launch in flight: 1 = k_advance, 2 = k_advance_team (kernels.hpp)
+    int advanced = 0;              // an advance pass ran in front of the launch in flight: 1 = k_advance, 2 = k_advance_team (kernels.hpp); + 4: k_lin ran in one-wave blocks
     bool coded = false;            // the launch in flight reports searched / refitted counts above its count slots (LinArgs::count_scale)
 };
 
@@ -115,6 +115,10 @@ struct dcreg_ctx {
     uint32_t *d_gate_abort = nullptr;
     dcreg::GateDev *d_gate_dev = nullptr;  // device copy of the gate record: launches gated in their first kernel (kernels.hpp gate_wait)
     bool opt_gate_in_kernel = true;
+    int opt_one_wave = 1;                 // k_lin<.., ONE> (one-wave blocks): 0 never, 1 by the rule, 2 wherever possible
+    double opt_one_wave_min_frac = 0.5;
+    double opt_one_wave_min_cells = 1.5;
+    int opt_one_wave_min_blocks = 1024;
     unsigned long long gate_seq = 0;       // number of the gated launch last queued
     int gate_slot = -1;                    // slot of the gated launch that still waits for its pose (-1: none)
     bool gate_uses_state = false;          // what the queued launch was built with: it reads / writes the ctx's own state,

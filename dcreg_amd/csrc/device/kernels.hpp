@@ -226,6 +226,47 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
     return tot;
 }
 
+// k_lin's one-wave instantiation leaves a row per 64-point TILE (four per query block) and no ticket: k_sum_tiles, queued behind it, adds
+// them - one block per chunk of kChunk query blocks.  Block row r = ((0 + tile 4r) + tile 4r+1) + ... exactly as block_publish adds the
+// four waves' values, then the rows as block_sum_rows adds them: the same additions in the same order, bit for bit.  (In the kernel
+// itself the sum would be the last arrival's, ONE wave with a kilobyte per lane to load: four dependent rounds of loads, 3 us each -
+// measured; here it is one round behind a kernel boundary.)
+static __global__ __launch_bounds__(kLinBlock) void k_sum_tiles(const double *__restrict__ tile_rows, uint32_t n_blocks_x, double *__restrict__ out,
+                                                                unsigned long long seq, const uint32_t *__restrict__ abort_flag) {
+    if (abort_flag && *abort_flag != 0u) return;       // the launch was called off: k_lin wrote no rows, nothing is published
+    __shared__ double sm[kLinBlock / 32][kSlots];
+    constexpr int G = kLinBlock / 32, T = kLinBlock / 64;
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t count = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
+    const double *rows = tile_rows + (size_t)chunk * kChunk * T * kSlots;
+    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    double x[kChunk / G][T];
+#pragma unroll
+    for (int u = 0; u < kChunk / G; ++u) {
+        const uint32_t r = (uint32_t)grp + (uint32_t)G * u;
+#pragma unroll
+        for (int w = 0; w < T; ++w) x[u][w] = r < count ? rows[((size_t)r * T + w) * kSlots + j] : 0.0;
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < kChunk / G; ++u) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < T; ++w) v += x[u][w];
+        t += v;
+    }
+    sm[grp][j] = t;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double tot = 0.0;
+        if (threadIdx.x < 31) {
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) tot += sm[gi][threadIdx.x];
+        }
+        publish_row(out + (size_t)chunk * kSlots, tot, seq);
+    }
+}
+
 // ---------------------------------------------------------------- the gate of a pipelined launch
 // An ICP loop alternates one linearisation and a 3 us host step, and every launch costs ~4 us of host time plus ~2 us until the
 // device starts: idle time for a device that has nothing else queued.  A GATED linearisation is queued while its predecessor still
@@ -426,21 +467,32 @@ constexpr int kAdvTile = 1536;
 static_assert(kAdvTile % kLinBlock == 0 && kAdvTile <= 65536, "a tile is a whole number of query blocks; list entries are 16-bit offsets");
 
 // ---------------------------------------------------------------- k_lin
-template <int MODE, bool FUSED, bool FAST, bool GATE = false>
-static __global__ __launch_bounds__(kLinBlock, kLinOcc) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
+// ONE: blocks of one wave (64 points; four of them cover a query block).  A four-wave block holds its wave slots until its slowest wave
+// is through; one-wave blocks give a slot back when its wave ends - worth 6-9 % of a launch whose searches are long (queries a cell and
+// more from the surface), and a loss where they are short (four times the blocks to dispatch: profiles/r06_ablation.md section 5).  Each
+// block leaves the row of its TILE; k_sum_tiles, queued behind, adds the tile rows in the order block_publish and block_sum_rows add the
+// waves' values and the block rows: the 31 sums are bitwise those of the four-wave launch.
+template <int MODE, bool FUSED, bool FAST, bool GATE = false, bool ONE = false>
+static __global__ __launch_bounds__(ONE ? kWave : kLinBlock, kLinOcc) void k_lin(const float4 *__restrict__ src, uint32_t n_src, GridDev g,
                                                           PoseArg pose1, const PoseArg *__restrict__ poses, LinArgs a,
                                                           double *__restrict__ partials, uint32_t n_blocks_x, FinArgs fin,
                                                           DebugDev dbg, const uint32_t *__restrict__ abort_flag, GateArgs gt) {
     if (abort_flag && *abort_flag != 0u) return;       // a gated launch the host called off (uniform: every block returns)
-    __shared__ double red[kLinBlock / 32][kSlots];
-    __shared__ double cnt[kLinBlock / 64][2];
+    static_assert(!ONE || (MODE == 0 && FUSED && !GATE), "the one-wave instantiation is the fused product launch behind k_gate");
+    constexpr int kWavesHere = ONE ? 1 : kLinBlock / kWave;
+    __shared__ double red[ONE ? 1 : kLinBlock / 32][kSlots];      // (ONE: the Gram matrix lives in the wave's RunList, behind the staging area)
+    __shared__ double cnt[kWavesHere][2];
     __shared__ int s_role;
-    __shared__ RunList runs[kLinBlock / kWave];
+    __shared__ RunList runs[kWavesHere];
+    static_assert(sizeof(RunList) >= sizeof(double) * (kWave * kRowStride + 64), "the one-wave block's reduction lives in its RunList");
     const double *const gm0 = &red[0][0];            // the waves' 8x8 Gram matrices (wave w at gm0 + 64 w); later the scratch of the chunk sum
     constexpr int gm_stride = 64;
     const int wave = threadIdx.x >> 6;
     const uint32_t pose_id = blockIdx.y;
-    uint32_t vb = xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
+    // (ONE: the blocks of the grid are tiles, four per query block; XCD runs and group order as for the query blocks they belong to)
+    const uint32_t vbt = ONE ? xcd_remap(blockIdx.x, n_blocks_x * (kLinBlock / kWave), a.xcd_chunk * (kLinBlock / kWave)) : 0u;
+    uint32_t vb = ONE ? vbt / (kLinBlock / kWave) : xcd_remap(blockIdx.x, n_blocks_x, a.xcd_chunk);
+    const uint32_t tile = ONE ? vbt % (kLinBlock / kWave) : (uint32_t)wave;    // the wave's tile of its query block
     if (a.n_groups) {       // heavy groups first (k_group_cost).  The groups cover the END of the block range: the blocks no group covers
                             // are the first ones - dispatched first, whatever they cost
         const uint32_t lead = n_blocks_x - a.n_groups * a.group_blocks;
@@ -449,7 +501,7 @@ static __global__ __launch_bounds__(kLinBlock, kLinOcc) void k_lin(const float4 
             vb = lead + (uint32_t)a.group_order[slot] * a.group_blocks + (vb - lead) % a.group_blocks;
         }
     }
-    const uint32_t i = vb * kLinBlock + threadIdx.x;
+    const uint32_t i = ONE ? vb * kLinBlock + tile * kWave + threadIdx.x : vb * kLinBlock + threadIdx.x;
     auto stamp = [&](int k, unsigned long long v) {       // MODE 2 only (timing probe): one store by lane 0, nothing kept in registers
         if constexpr (MODE == 2) {
             if ((threadIdx.x & 63) == 0 && dbg.stamps) dbg.stamps[((size_t)vb * (kLinBlock / 64) + wave) * 8 + k] = v;
@@ -497,9 +549,9 @@ static __global__ __launch_bounds__(kLinBlock, kLinOcc) void k_lin(const float4 
     uint32_t stats = 0;
     uint32_t w_search = 0, w_refit = 0;             // lanes of this wave that were searched / only refitted (uniform)
     uint32_t adv_s = 0, adv_r = 0;                  // ... and what the advance pass in front of this launch did for this block's points
-    if (a.adv_counts && wave == 0) {                // (taken and zeroed again: the passes only ever add to zeroes)
+    if (a.adv_counts && tile == 0u) {                // (taken and zeroed again: the passes only ever add to zeroes)
         adv_s = a.adv_counts[(size_t)vb * kCounterStride]; adv_r = a.adv_counts[(size_t)vb * kCounterStride + 1];
-        if (threadIdx.x == 0) { a.adv_counts[(size_t)vb * kCounterStride] = 0u; a.adv_counts[(size_t)vb * kCounterStride + 1] = 0u; }
+        if ((threadIdx.x & 63u) == 0u) { a.adv_counts[(size_t)vb * kCounterStride] = 0u; a.adv_counts[(size_t)vb * kCounterStride + 1] = 0u; }
     }
     KnnResult<5> nn;
     Fit fit;
@@ -638,11 +690,24 @@ static __global__ __launch_bounds__(kLinBlock, kLinOcc) void k_lin(const float4 
         if (dbg.stats) dbg.stats[oi] = stats;
     }
     // (the wave's RunList is free now: it stages the rows)
+    if constexpr (ONE) {
+        double *const gm = runs[0].stage + kWave * kRowStride;                              // behind the staging area
+        wave_rows_to_lds(row, flag, runs[0].stage, gm, cnt, a.count_scale * (double)(w_search + adv_s), a.count_scale * (double)(w_refit + adv_r));
+        __syncthreads();
+        constexpr uint32_t T = kLinBlock / kWave;
+        if (threadIdx.x < kSlots) {                        // the tile's row; k_sum_tiles (behind this kernel) adds the rows
+            double t = 0.0;
+            if (threadIdx.x < 29) t = gm[gram_entry_of_slot(threadIdx.x)];
+            else if (threadIdx.x < 31) t = cnt[0][threadIdx.x - 29];
+            partials[((size_t)vb * T + tile) * kSlots + threadIdx.x] = t;
+        }
+    } else {
     wave_rows_to_lds(row, flag, runs[wave].stage, &red[0][0] + wave * gm_stride, cnt, a.count_scale * (double)(w_search + adv_s),
                      a.count_scale * (double)(w_refit + adv_r));
     if constexpr (MODE == 2) stamp(5, __builtin_readcyclecounter());
     __syncthreads();
     block_publish<FUSED>(gm0, gm_stride, red, cnt, &s_role, partials + (size_t)pose_id * n_blocks_x * kSlots, vb, n_blocks_x, fin, pose_id);
+    }
 }
 
 // ---------------------------------------------------------------- the advance pass: searches and refits in dense waves

@@ -59,7 +59,8 @@ int dcreg_launch_series(dcreg_ctx *, double *ms, int64_t *searched, int64_t *ref
 /* ... and, for the same log (call it BEFORE the resetting dcreg_launch_series): 1 where the advance pass (kernels.hpp k_advance: the
  * searches and refits of a launch in dense waves, in front of the linearisation kernel) ran, 2 where its small-frame form did
  * (k_advance_team: sixteen lanes per query), 0 where neither did; the duration and the counts of such a launch cover both kernels.
- * Returns the number of entries logged. */
+ * Bit 2 (+ 4): the linearisation kernel ran in one-wave blocks with k_sum_tiles behind it (option "one_wave"; its duration covers
+ * both).  Returns the number of entries logged. */
 int dcreg_launch_series_passes(dcreg_ctx *, uint8_t *advanced, int64_t cap);
 
 /* Timing probe of the small-frame advance pass (option "team_stamps" = 1): of the LAST launch that ran the pass, per block (one wave,
@@ -95,6 +96,10 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "team_pass"          the small-frame advance pass (sixteen lanes per query) in front of single-pose launches: 0 = never, 1 (default) =
  *                        for clouds of at most 16384 points when the last completed launch searched at least half of them and the map holds
  *                        at least 3 points per occupied cell, 2 = whenever the launch can take it; "team_stamps": see dcreg_team_pass_stamps;
+ *   "one_wave"           the linearisation kernel in one-wave blocks (a tile row per wave, k_sum_tiles behind it): 0 = never, 1 (default) =
+ *                        single-pose launches of at least "one_wave_min_blocks" (1024) query blocks most of whose points are expected to
+ *                        search ("one_wave_min_frac", 0.5) while the misalignment hint is above "one_wave_min_cells" (1.5) cells - the
+ *                        first launches of a run; 2 = every fused single-pose launch, small ones included: tests;
  *   "gate_in_kernel"     1 (default) = a pipelined launch of at most 64 query blocks waits for its pose in its first kernel (one kernel boundary
  *                        less); 0 = behind the one-wave gate kernel, like larger launches;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);

@@ -169,3 +169,81 @@ def test_the_montecarlo_job_of_one_rank_equals_the_python_driver():
             assert got.shape == (1, 5) and np.array_equal(got[0], np.arange(5.0))
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------- k_lin in one-wave blocks (kernels.hpp k_lin<.., ONE>, k_sum_tiles)
+def _same_sums(a, b):
+    return (a["n_eff"] == b["n_eff"] and a["n_pt"] == b["n_pt"] and np.array_equal(a["H_upper"], b["H_upper"]) and np.array_equal(a["g"], b["g"])
+            and a["sum_r2"] == b["sum_r2"] and a["sum_b2"] == b["sum_b2"])
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("scene", ["fixture", "lattice_dups", "planes_dense", "corridor_300k"])
+def test_one_wave_blocks_are_invisible(scene, fast):
+    """Walks that mix micrometre steps, centimetre steps and a jump (the scenes of round 5's pass tests: ties, duplicates, OUT points,
+    dense cells; 30 to 1172 query blocks, i.e. ragged last chunks): with the linearisation kernel forced into one-wave blocks on every
+    launch ("one_wave" = 2: a row per 64-point tile, k_sum_tiles behind the kernel), with and without certificates, and with the advance
+    pass in front of it, the 31 sums are those of the four-wave launch bit for bit; the series reports which launches ran that way."""
+    from test_gpu_round5 import _scene
+    rng = np.random.default_rng(31)
+    tgt, src, radius = _scene(scene, rng)
+    prm = api.default_lin_params(radius, 1)
+    ctxs = {}
+    for name, opts in (("one", {"one_wave": 2, "advance": 0, "team_pass": 0}), ("one_all", {"one_wave": 2, "use_certificates": 0, "team_pass": 0}),
+                       ("one_adv", {"one_wave": 2, "advance": 2, "team_pass": 0}),     # (launches behind the small-frame pass keep their four-wave blocks)
+                       ("plain", {"one_wave": 0})):
+        c = api.Context(0)
+        c.set_option("fast_plane_fit", fast)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_option("record_launches", 1)
+        c.set_target(tgt, radius); c.set_source(src)
+        ctxs[name] = c
+    T = np.eye(4)
+    steps = [0.0, 1e-6, 1e-4, 3e-4, 1e-3, -1e-3, 2e-3, 1e-5, 4e-3, 6e-3, -6e-3, 1e-2, 1e-4, 3e-2, 0.2, 1e-3, 5e-4, 0.0]
+    for k, sz in enumerate(steps):
+        T = h.pose6d_matrix(sz * 0.6, -sz * 0.3, sz * 0.2, sz * 0.002, -sz * 0.001, sz * 0.004) @ T
+        outs = {name: c.linearize(T[:3, :3], T[:3, 3], prm) for name, c in ctxs.items()}
+        for name in ("one", "one_all", "one_adv"):
+            assert _same_sums(outs[name], outs["plain"]), (scene, fast, k, name)
+    ser = {name: c.launch_series(reset=True) for name, c in ctxs.items()}
+    assert ser["one"]["one_wave"].all() and ser["one_all"]["one_wave"].all() and ser["one_adv"]["one_wave"].all() and not ser["plain"]["one_wave"].any()
+    assert (ser["one_adv"]["advanced"][1:] == 1).all()
+    for c in ctxs.values():
+        c.close()
+
+
+def test_one_wave_blocks_by_the_rule_in_whole_runs():
+    """Engine level, 400 k corridor pair 0.35 m off (the pipelined engine: every launch but the first behind a gate; the run with the
+    thresholds on calls its last queued launch off - k_lin and k_sum_tiles both return): the rule picks one-wave blocks for the first
+    launches of a run (misalignment hint above 1.5 cells, most points searching) and four-wave blocks later; iteration by iteration H, g,
+    counts and pose are bitwise those of runs with one-wave blocks everywhere and nowhere, and a second run from what the first left gives
+    the same again."""
+    tgt = h.scene_corridor(400_000, seed=9)
+    src = (tgt + np.random.default_rng(10).normal(0, 0.01, tgt.shape)).astype(np.float32)
+    T0 = h.pose6d_matrix(0.15, -0.2, 0.1, h.deg2rad(0.3), h.deg2rad(-0.2), h.deg2rad(0.6))
+    logs, picked = {}, {}
+    for name, ow in (("rule", 1), ("forced", 2), ("off", 0)):
+        c = api.Context(0)
+        c.set_option("one_wave", ow)
+        c.set_option("record_launches", 1)
+        c.set_target(tgt, 1.0); c.set_source(src)
+        runs = []
+        for rep, thr in enumerate((0.0, 0.0, None)):                  # two fixed-length runs, then one with the reference's thresholds on
+            kw = {} if thr is None else {"CONVERGENCE_THRESH_ROT": 0.0, "CONVERGENCE_THRESH_TRANS": 0.0}
+            cfg = api.default_config(search_radius=1.0, max_iterations=25, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, use_weight_derivative=1,
+                                     always_compute_schur=1, **kw)
+            res, lg = c.icp_run(T0, "Ours", cfg)
+            runs.append([(np.array(L.H_upper[:]), np.array(L.gradient[:]), L.effective_points, L.corr_pt_count, np.array(L.transform_matrix[:])) for L in lg[:res.iterations]])
+        logs[name] = runs
+        picked[name] = c.launch_series(reset=True)["one_wave"]
+        c.close()
+    for name in ("rule", "forced"):
+        for rep in range(3):
+            assert len(logs[name][rep]) == len(logs["off"][rep]) and len(logs["off"][rep]) >= 5
+            for it, (x, y) in enumerate(zip(logs[name][rep], logs["off"][rep])):
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3] and np.array_equal(x[4], y[4]), (name, rep, it)
+    assert picked["off"].sum() == 0 and picked["forced"].all()
+    n_rule = int(picked["rule"].sum())
+    assert 3 <= n_rule <= 2 * len(picked["rule"]) // 3, picked["rule"]
+    assert picked["rule"][0] == 1 and picked["rule"][24] == 0           # the first launch of the first run, its last one
