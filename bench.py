@@ -397,7 +397,8 @@ def roofline_blocks(name, n_queries_per_launch, kern_us, kern_source=None):
     hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("source"),
            "kernel": "k_lin (certificate test, exact 6-NN search where needed, plane fit, point-to-plane row, J^T J / J^T r reduction) + the advance pass "
-                     "the host puts in front of it in some launches (k_advance / k_advance_team: the searches and refits in dense waves / by teams of 16 lanes); "
+                     "the host puts in front of it in some launches (k_advance / k_advance_team: the searches and refits in dense waves / by teams of 16 lanes) "
+                     "and k_sum_tiles behind the one-wave launches (the first launches of a run); "
                      "kernel_us_avg brackets all kernels of a linearisation",
            "kernel_us_avg": kern_us, "kernel_us_source": kern_source, "points_per_launch": n_queries_per_launch, "algorithmic_bytes_per_launch": algo}
     out = {"roofline": hbm}

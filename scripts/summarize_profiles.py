@@ -28,10 +28,11 @@ def check_kernels(names):
         sys.exit("summarize_profiles: the trace holds dcreg kernels this tree's library does not export (stale profile?): %s" % ", ".join(bad))
 
 ALL_LIN = "dcreg::k_lin (all instantiations)"
-# one linearisation = one k_lin dispatch + the advance pass that may run in front of it (k_advance / k_advance_team): per-linearisation
+# one linearisation = one k_lin dispatch + the advance pass that may run in front of it (k_advance / k_advance_team) + k_sum_tiles behind a
+# one-wave launch: per-linearisation
 # figures are the totals over all of those kernels divided by the number of k_lin dispatches
 LIN = "one linearisation (k_lin + advance passes)"
-def is_lin(name): return "k_lin" in name or "k_advance" in name
+def is_lin(name): return "k_lin" in name or "k_advance" in name or "k_sum_tiles" in name      # (k_sum_tiles: behind k_lin's one-wave launches)
 
 out = {"tag": tag, "workload": wl}
 md = ["# %s — rocprofv3 summary, workload %s" % (tag, wl), "",
