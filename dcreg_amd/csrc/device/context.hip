@@ -569,7 +569,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     key.radius_sq = a.radius_sq; key.max_thick_sq = a.max_thick_sq; key.min_norm = a.min_norm;
     key.radius_sq_f = a.radius_sq_f; key.cert_r_out = a.cert_r_out; key.cert_r_in = a.cert_r_in; key.fast_plane = c->opt_fast_plane ? 1 : 0;
     const uint32_t nbx = blocks_for(c->n_src, kLinBlock);
-    if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots * (kLinBlock / kWave))) return DCREG_E_NOMEM;      // (a row per block, or per tile: k_lin's one-wave instantiation)
+    if (ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots)) return DCREG_E_NOMEM;
     // one pose: the kernels finish the reduction themselves (chunk rows -> pinned memory); many poses: k_finalize
     const uint32_t n_chunks = (nbx + kChunk - 1) / kChunk;
     // ... and so do batches whose poses are one chunk each (the Monte-Carlo batches: 30 blocks per pose): the last block of a pose sums
@@ -763,6 +763,8 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         one_wave = c->opt_one_wave >= 2 || (c->opt_one_wave == 1 && nbx >= (uint32_t)c->opt_one_wave_min_blocks && !adv && most &&
                                             c->hint_misalign > c->opt_one_wave_min_cells * c->grid.h);
     }
+    // (a row per TILE then: grown here, before any kernel of this launch is queued)
+    if (one_wave && ensure(c, S.d_partials, S.partials_cap, (size_t)nbx * kSlots * (kLinBlock / kWave))) return DCREG_E_NOMEM;
     const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
     if (adv || team) {      // the passes' counts, per query block of k_lin: zero between launches (k_lin takes them and zeroes them again)
         const size_t had = c->adv_counts_cap;
