@@ -1,6 +1,7 @@
 """Randomised hunt for the advance passes (GPU box): random scenes, sizes, radii, cell sizes (balls of one to a dozen cells: the teams' row
 lists, layer masks and overflow paths all occur), walks that mix tiny steps and jumps.  At every step the 31 sums of a context with the dense
-pass forced, one with the team pass forced and one without passes must agree BIT FOR BIT, and with the oracle to 1e-8.
+pass forced, one with the team pass forced, one whose linearisation kernel runs in one-wave blocks (round 6) and one without any of it
+must agree BIT FOR BIT, and with the oracle to 1e-8.
 usage: fuzz_passes.py [n_cases] [seed]"""
 import os, sys
 import numpy as np
@@ -24,7 +25,9 @@ def same(a, b):
 
 def run(n_cases, seed, verbose=True):
     rng = np.random.default_rng(seed)
-    ctxs = {"dense": dcreg_amd.Context(0), "team": dcreg_amd.Context(0), "plain": dcreg_amd.Context(0)}
+    ctxs = {"dense": dcreg_amd.Context(0), "team": dcreg_amd.Context(0), "plain": dcreg_amd.Context(0), "one": dcreg_amd.Context(0)}
+    ctxs["one"].set_option("advance", 0); ctxs["one"].set_option("team_pass", 0); ctxs["one"].set_option("one_wave", 2)
+    ctxs["plain"].set_option("one_wave", 0)
     ctxs["dense"].set_option("advance", 2); ctxs["dense"].set_option("team_pass", 0)
     ctxs["team"].set_option("advance", 0); ctxs["team"].set_option("team_pass", 2)
     ctxs["plain"].set_option("advance", 0); ctxs["plain"].set_option("team_pass", 0)
@@ -58,7 +61,7 @@ def run(n_cases, seed, verbose=True):
             amp = float(rng.choice([1e-5, 0.002, 0.02, 0.3]))
             T = h.pose6d_matrix(*(rng.normal(0, amp, 3)), *(rng.normal(0, amp * 0.05, 3))) @ T
             outs = {k: c.linearize(T[:3, :3], T[:3, 3], api.default_lin_params(radius, wd)) for k, c in ctxs.items()}
-            good = same(outs["dense"], outs["plain"]) and same(outs["team"], outs["plain"])
+            good = same(outs["dense"], outs["plain"]) and same(outs["team"], outs["plain"]) and same(outs["one"], outs["plain"])
             if good and step in (0, 5):
                 r = po.linearize(tree, src, T[:3, :3], T[:3, 3], po.default_lin_params(radius, wd))
                 good = outs["plain"]["n_eff"] == r["n_eff"] and outs["plain"]["n_pt"] == r["n_pt"]
