@@ -180,8 +180,9 @@ int dcreg_linearize_batch_end(dcreg_ctx *, int slot, dcreg_lin_out *outs);
 /* Scheduling hint, never needed for correctness: how far (metres, roughly) the source points are expected to lie from the map at the
  * poses of the next single-pose linearisations - e.g. the RMS residual of the last iteration.  While it is above half a grid cell
  * (and the context's own cost estimate of the cloud pair is uneven) the query blocks of a launch are handed out heaviest group first
- * instead of in index order (longest processing time first: a launch ends when its slowest block does).  The 31 sums do not depend
- * on it.  Default: +infinity (no knowledge: assume misaligned).  dcreg_icp_run* call it themselves. */
+ * instead of in index order (longest processing time first: a launch ends when its slowest block does); while it is above a cell and
+ * a half, launches of large clouds most of whose points search run the linearisation kernel in one-wave blocks (kernels.hpp
+ * k_lin<.., ONE>: worth a tenth of such a launch, a few microseconds lost on others).  The 31 sums do not depend on it.  Default: +infinity (no knowledge: assume misaligned).  dcreg_icp_run* call it themselves. */
 int dcreg_hint_misalignment(dcreg_ctx *, double metres);
 int dcreg_reserve_warm_states(dcreg_ctx *, int64_t n_states);
 int dcreg_reset_warm_state(dcreg_ctx *, int64_t state_id);
