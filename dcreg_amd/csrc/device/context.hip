@@ -755,6 +755,9 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (team) adv = false;
     // the one-wave instantiation of k_lin (kernels.hpp): fused single-pose launches of many blocks in which most waves search
     bool one_wave = false;
+    if (n_poses > 1) {      // batched launches of one-chunk poses (the Monte-Carlo batches): trials at every stage of their runs side by side
+        one_wave = fused && !dbg_host && (c->opt_one_wave >= 2 || (c->opt_one_wave_batches && (uint64_t)n_poses * nbx >= (uint64_t)c->opt_one_wave_min_blocks));
+    } else
     if (n_poses == 1 && fused && !direct && !dbg_host && !stamps_only && !team) {
         // by the rule: a launch of many blocks whose searches are long - the queries more than a cell and a half from the surface (the
         // engines' hint, as for the dispatch order above; unknown at the start of a run = far) - and most of whose points search
@@ -764,7 +767,7 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
                                             c->hint_misalign > c->opt_one_wave_min_cells * c->grid.h);
     }
     // (a row per TILE then: grown here, before any kernel of this launch is queued)
-    if (one_wave && ensure(c, S.d_partials, S.partials_cap, (size_t)nbx * kSlots * (kLinBlock / kWave))) return DCREG_E_NOMEM;
+    if (one_wave && ensure(c, S.d_partials, S.partials_cap, (size_t)n_poses * nbx * kSlots * (kLinBlock / kWave))) return DCREG_E_NOMEM;
     const uint32_t n_tiles = team ? blocks_for(n, kTeamTile) : blocks_for(n, kAdvTile);
     if (adv || team) {      // the passes' counts, per query block of k_lin: zero between launches (k_lin takes them and zeroes them again)
         const size_t had = c->adv_counts_cap;
@@ -877,10 +880,10 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
         if (stamps_only) { if (fast) DCREG_LAUNCH_LIN(2, true, true); else DCREG_LAUNCH_LIN(2, true, false); }     // (the probe writes the shared state: same fit as the plain launches)
         else if (dbg_host) { if (fast) DCREG_LAUNCH_LIN(1, true, true); else DCREG_LAUNCH_LIN(1, true, false); }
         else if (one_wave) {               // one-wave blocks: a grid of tiles
-            const dim3 tiles(nbx * (kLinBlock / kWave), 1u);
+            const dim3 tiles(nbx * (kLinBlock / kWave), (unsigned)n_poses);
             if (fast) hipLaunchKernelGGL((k_lin<0, true, true, false, true>), tiles, dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a, S.d_partials, nbx, fin, dd, abort_flag, gt);
             else hipLaunchKernelGGL((k_lin<0, true, false, false, true>), tiles, dim3(kWave), 0, c->stream, c->d_src, (uint32_t)n, c->grid, one, lin_poses, a, S.d_partials, nbx, fin, dd, abort_flag, gt);
-            hipLaunchKernelGGL(k_sum_tiles, dim3(n_chunks), dim3(kLinBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq, abort_flag);
+            hipLaunchKernelGGL(k_sum_tiles, dim3(n_chunks, (unsigned)n_poses), dim3(kLinBlock), 0, c->stream, S.d_partials, nbx, S.d_out, seq, abort_flag);
         }
         else if (fused) { if (fast) DCREG_LAUNCH_LIN(0, true, true); else DCREG_LAUNCH_LIN(0, true, false); }
         else { if (fast) DCREG_LAUNCH_LIN(0, false, true); else DCREG_LAUNCH_LIN(0, false, false); }
@@ -1241,6 +1244,7 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "one_wave") c->opt_one_wave = (int)v;                  // k_lin in one-wave blocks: 0 never, 1 by the rule (launches of many blocks in which most waves search), 2 wherever possible
+    else if (k == "one_wave_batches") c->opt_one_wave_batches = v != 0.0;
     else if (k == "one_wave_min_frac") c->opt_one_wave_min_frac = v;
     else if (k == "one_wave_min_cells") c->opt_one_wave_min_cells = v;
     else if (k == "one_wave_min_blocks") c->opt_one_wave_min_blocks = (int)v;

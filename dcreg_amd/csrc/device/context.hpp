@@ -116,6 +116,7 @@ struct dcreg_ctx {
     dcreg::GateDev *d_gate_dev = nullptr;  // device copy of the gate record: launches gated in their first kernel (kernels.hpp gate_wait)
     bool opt_gate_in_kernel = true;
     int opt_one_wave = 1;                 // k_lin<.., ONE> (one-wave blocks): 0 never, 1 by the rule, 2 wherever possible
+    bool opt_one_wave_batches = true;     // ... for batched launches of one-chunk poses with at least opt_one_wave_min_blocks blocks in all
     double opt_one_wave_min_frac = 0.5;
     double opt_one_wave_min_cells = 1.5;
     int opt_one_wave_min_blocks = 1024;

@@ -231,6 +231,7 @@ __device__ __forceinline__ double block_sum_rows(const double *rows, uint32_t co
 // four waves' values, then the rows as block_sum_rows adds them: the same additions in the same order, bit for bit.  (In the kernel
 // itself the sum would be the last arrival's, ONE wave with a kilobyte per lane to load: four dependent rounds of loads, 3 us each -
 // measured; here it is one round behind a kernel boundary.)
+// Grid: (chunks of a pose, poses) - batched launches of one-chunk poses (the Monte-Carlo batches) get their pose rows this way.
 static __global__ __launch_bounds__(kLinBlock) void k_sum_tiles(const double *__restrict__ tile_rows, uint32_t n_blocks_x, double *__restrict__ out,
                                                                 unsigned long long seq, const uint32_t *__restrict__ abort_flag) {
     if (abort_flag && *abort_flag != 0u) return;       // the launch was called off: k_lin wrote no rows, nothing is published
@@ -238,7 +239,7 @@ static __global__ __launch_bounds__(kLinBlock) void k_sum_tiles(const double *__
     constexpr int G = kLinBlock / 32, T = kLinBlock / 64;
     const uint32_t chunk = blockIdx.x;
     const uint32_t count = min((uint32_t)kChunk, n_blocks_x - chunk * kChunk);
-    const double *rows = tile_rows + (size_t)chunk * kChunk * T * kSlots;
+    const double *rows = tile_rows + ((size_t)blockIdx.y * n_blocks_x + (size_t)chunk * kChunk) * T * kSlots;
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double x[kChunk / G][T];
 #pragma unroll
@@ -263,7 +264,7 @@ static __global__ __launch_bounds__(kLinBlock) void k_sum_tiles(const double *__
 #pragma unroll
             for (int gi = 0; gi < G; ++gi) tot += sm[gi][threadIdx.x];
         }
-        publish_row(out + (size_t)chunk * kSlots, tot, seq);
+        publish_row(out + ((size_t)blockIdx.y * gridDim.x + chunk) * kSlots, tot, seq);
     }
 }
 
@@ -699,7 +700,7 @@ static __global__ __launch_bounds__(ONE ? kWave : kLinBlock, kLinOcc) void k_lin
             double t = 0.0;
             if (threadIdx.x < 29) t = gm[gram_entry_of_slot(threadIdx.x)];
             else if (threadIdx.x < 31) t = cnt[0][threadIdx.x - 29];
-            partials[((size_t)vb * T + tile) * kSlots + threadIdx.x] = t;
+            partials[(((size_t)pose_id * n_blocks_x + vb) * T + tile) * kSlots + threadIdx.x] = t;
         }
     } else {
     wave_rows_to_lds(row, flag, runs[wave].stage, &red[0][0] + wave * gm_stride, cnt, a.count_scale * (double)(w_search + adv_s),

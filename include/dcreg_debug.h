@@ -99,7 +99,9 @@ int dcreg_knn_timed(dcreg_ctx *, const float *q_xyz, int64_t n, int64_t stride_f
  *   "one_wave"           the linearisation kernel in one-wave blocks (a tile row per wave, k_sum_tiles behind it): 0 = never, 1 (default) =
  *                        single-pose launches of at least "one_wave_min_blocks" (1024) query blocks most of whose points are expected to
  *                        search ("one_wave_min_frac", 0.5) while the misalignment hint is above "one_wave_min_cells" (1.5) cells - the
- *                        first launches of a run; 2 = every fused single-pose launch, small ones included: tests;
+ *                        first launches of a run; 2 = every fused launch, small ones included: tests; "one_wave_batches" (1): batched
+ *                        launches of one-chunk poses (the Monte-Carlo batches: trials at every stage of their runs side by side) with
+ *                        at least "one_wave_min_blocks" query blocks in all run that way too (+ 6 % on the experiment);
  *   "gate_in_kernel"     1 (default) = a pipelined launch of at most 64 query blocks waits for its pose in its first kernel (one kernel boundary
  *                        less); 0 = behind the one-wave gate kernel, like larger launches;
  *   "team_search"        lanes a wave serves one query at a time with all 64 lanes instead of searching in lock-step (0 = never, 7 = default);

@@ -247,3 +247,29 @@ def test_one_wave_blocks_by_the_rule_in_whole_runs():
     n_rule = int(picked["rule"].sum())
     assert 3 <= n_rule <= 2 * len(picked["rule"]) // 3, picked["rule"]
     assert picked["rule"][0] == 1 and picked["rule"][24] == 0           # the first launch of the first run, its last one
+
+
+def test_montecarlo_batches_in_one_wave_blocks_give_the_same_records():
+    """The Monte-Carlo experiment (batched launches of 30-block poses, trials at every stage of their runs side by side) with the batches'
+    linearisation kernel in one-wave blocks ("one_wave_batches" = 1, the default: a tile row per wave, k_sum_tiles with one block per pose
+    behind it), in four-wave blocks (0), and with one-wave blocks forced for batches too small for the rule (12 slots, "one_wave" = 2):
+    every trial's record - iterations, final pose, errors, H, mask - is bitwise the same."""
+    from dcreg_amd import montecarlo as mcm
+    pts = h.cylinder_cloud()
+    cfg = api.default_config(search_radius=1.0, max_iterations=30, CONVERGENCE_THRESH_TRANS=1e-3, CONVERGENCE_THRESH_ROT=1e-5, KAPPA_TARGET=10.0,
+                             STD_REG_GAMMA=100.0, use_weight_derivative=1, always_compute_schur=1)
+    base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
+    cols = [c for c in range(64) if c != mcm.R_TIME]
+    recs = {}
+    for name, opts, slots in (("four", {"one_wave_batches": 0}, 128), ("one", {"one_wave_batches": 1}, 128), ("forced_small", {"one_wave": 2}, 12)):
+        ctx = api.Context(0)
+        try:
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.set_target(pts, 1.0); ctx.set_source(pts)
+            rec, st = ctx.montecarlo_job(base, 77, 400, 0.5, np.deg2rad(2.0), "Ours", cfg, slots=slots)
+            recs[name] = rec[:, cols]
+            assert st["total_runs"] == 400
+        finally:
+            ctx.close()
+    assert np.array_equal(recs["one"], recs["four"]) and np.array_equal(recs["forced_small"], recs["four"])
