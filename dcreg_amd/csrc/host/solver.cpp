@@ -68,7 +68,9 @@ static void diagBlocks(const Mat6 &H, dcreg_analysis &res) {
     std::memcpy(res.lambda_sub_trans, w.data(), sizeof(double) * 3);
     res.cond_diag_trans = vmax3(res.lambda_sub_trans) / std::max(vmin3(res.lambda_sub_trans), 1e-12);
 }
-static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis &res, bool defer_diag = false) {
+// defer_diag: the diagonal blocks and the axis alignment of the eigenvectors (read by the report writers only) are left to analyzeFinish;
+// returns whether the alignment is owed (the analysis got that far)
+static bool schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis &res, bool defer_diag = false) {
     const Mat3 Hrr = block3(H, 0, 0), Htt = block3(H, 3, 3), Hrt = block3(H, 0, 3), Htr = block3(H, 3, 0);
     if (!defer_diag) diagBlocks(H, res);
 
@@ -76,7 +78,7 @@ static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis
     const bool okT = fullPivLuInverse3(Htt, HttInv), okR = fullPivLuInverse3(Hrr, HrrInv);
     if (!(okT && okR)) {   // :2464-2469
         res.cond_schur_rot = res.cond_schur_trans = std::numeric_limits<double>::infinity();
-        return;
+        return false;
     }
     Mat3 SR = mul(mul(Hrt, HttInv), Htr), ST = mul(mul(Htr, HrrInv), Hrt);
     for (int i = 0; i < 9; ++i) { SR.v[i] = Hrr.v[i] - SR.v[i]; ST.v[i] = Htt.v[i] - ST.v[i]; }
@@ -84,7 +86,7 @@ static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis
     const bool e1 = symEig<3>(SR, lr, Vr), e2 = symEig<3>(ST, lt, Vt);
     if (!(e1 && e2)) {     // :2460-2463
         res.cond_schur_rot = res.cond_schur_trans = std::numeric_limits<double>::infinity();
-        return;
+        return false;
     }
     std::memcpy(res.lambda_schur_rot, lr.data(), sizeof(double) * 3);
     std::memcpy(res.lambda_schur_trans, lt.data(), sizeof(double) * 3);
@@ -92,8 +94,10 @@ static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis
     std::memcpy(res.schur_V_trans, Vt.v, sizeof(Vt.v));
     res.cond_schur_rot = vmax3(res.lambda_schur_rot) / std::max(vmin3(res.lambda_schur_rot), 1e-12);
     res.cond_schur_trans = vmax3(res.lambda_schur_trans) / std::max(vmin3(res.lambda_schur_trans), 1e-12);
-    alignAndOrthonormalize(res.schur_V_rot, res.aligned_V_rot, res.rot_indices);
-    alignAndOrthonormalize(res.schur_V_trans, res.aligned_V_trans, res.trans_indices);
+    if (!defer_diag) {
+        alignAndOrthonormalize(res.schur_V_rot, res.aligned_V_rot, res.rot_indices);
+        alignAndOrthonormalize(res.schur_V_trans, res.aligned_V_trans, res.trans_indices);
+    }
     // P = blockdiag(V_R diag(1/max(l, lmax/kappa_tg)) V_R^T, same for t)
     for (int blk = 0; blk < 2; ++blk) {
         const double *lam = blk ? res.lambda_schur_trans : res.lambda_schur_rot;
@@ -105,6 +109,7 @@ static void schurAnalysis(const Mat6 &H, const dcreg_config &cfg, dcreg_analysis
             res.P_preconditioner[(3 * blk + i) * 6 + 3 * blk + j] = s;
         }
     }
+    return defer_diag;
 }
 
 // full eigen-decomposition block of the analysis (dcreg.hpp:66-89): eigenvalues / eigenvectors / singular values / condition
@@ -139,7 +144,8 @@ static bool evdIsDiagnosticOnly(int detection, int handling) {
 
 // defer_evd: leave the full eigen-decomposition block - and the diagonal blocks of the Schur analysis - out when nothing of the step
 // depends on them; analyzeFinish() then completes the record, bit for bit what the one-pass analysis writes.
-// (returns a mask of what is owed: 1 = the full eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis)
+// (returns a mask of what is owed: 1 = the full eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis, 4 = the axis
+//  alignment of the Schur eigenvectors)
 static int analyze(const Mat6 &H, int detection, int handling, const dcreg_config &cfg, dcreg_analysis &res, bool defer_evd = false) {
     const double nan = std::numeric_limits<double>::quiet_NaN();
     std::memset(&res, 0, sizeof(res));
@@ -155,7 +161,7 @@ static int analyze(const Mat6 &H, int detection, int handling, const dcreg_confi
     const bool evdOk = deferred ? false : fullEvdBlock(H, res);      // dcreg.hpp:66-89
 
     const bool schur = detection == DCREG_SCHUR_CONDITION_NUMBER || handling == DCREG_PRECONDITIONED_CG || cfg.always_compute_schur;
-    if (schur) schurAnalysis(H, cfg, res, deferred);
+    const bool align_owed = schur && schurAnalysis(H, cfg, res, deferred);
 
     switch (detection) {
     case DCREG_SCHUR_CONDITION_NUMBER: {
@@ -197,7 +203,7 @@ static int analyze(const Mat6 &H, int detection, int handling, const dcreg_confi
         break;
     default: break;                        // NONE_DETE and everything else: not degenerate
     }
-    return (deferred ? 1 : 0) | ((deferred && schur) ? 2 : 0);
+    return (deferred ? 1 : 0) | ((deferred && schur) ? 2 : 0) | (align_owed ? 4 : 0);
 }
 
 // preconditioned conjugate gradients on the 6x6 SPD system (dcreg.hpp:279-287 is a stub)
@@ -299,6 +305,10 @@ void analyzeFinish(const double H[36], dcreg_analysis &res, int owed) {
     const Mat6 M = toMat6(H);
     if (owed & 1) fullEvdBlock(M, res);
     if (owed & 2) diagBlocks(M, res);
+    if (owed & 4) {
+        alignAndOrthonormalize(res.schur_V_rot, res.aligned_V_rot, res.rot_indices);
+        alignAndOrthonormalize(res.schur_V_trans, res.aligned_V_trans, res.trans_indices);
+    }
 }
 void solveDegenerateSystem(const double H[36], const double g[6], int handling, const dcreg_config &cfg,
                            dcreg_analysis &an, double x[6]) {

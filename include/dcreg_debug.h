@@ -70,7 +70,7 @@ int dcreg_launch_series_passes(dcreg_ctx *, uint8_t *advanced, int64_t cap);
  * returns the number of blocks of that launch.  Waits for the stream. */
 int dcreg_team_pass_stamps(dcreg_ctx *, uint64_t *out, int64_t cap_blocks);
 
-/* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 1 = the full
+/* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 4 = the axis alignment of the Schur eigenvectors, 1 = the full
  * eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis); the record must equal dcreg_analyze_degeneracy's */
 int dcreg_analyze_degeneracy_two_part(const double H[36], int detection, int handling, const dcreg_config *, dcreg_analysis *, int *owed);
 
