@@ -3,6 +3,8 @@
 // the device seam (dcreg_linearize), and the num_runs loop of TestRunner::runMethod (:331-390) as a
 // lock-step batch over independent trials (dcreg_icp_run_trials).
 #include <omp.h>
+#include <sched.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -25,6 +27,33 @@ void analyzeFinish(const double H[36], dcreg_analysis &res, int owed);
 }
 
 namespace {
+
+// The CPUs this process can keep busy: min(affinity mask, cgroup quota).  A container shows the MACHINE's hardware threads to OpenMP
+// (omp_get_max_threads() = 256 on a box whose cgroup grants 16): a team of that size on a sixteenth of the CPUs made the Monte-Carlo
+// experiment seven times slower for a caller that had not called dcreg_set_host_threads (measured).  The engines never use more.
+inline int usable_cpus() {
+    static const int n = [] {
+        int cpus = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus <= 0) cpus = (int)std::max(1L, sysconf(_SC_NPROCESSORS_ONLN));
+        double quota = 0.0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0}; double per = 0.0;
+            if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0.0) quota = std::atof(q) / per;
+            std::fclose(f);
+        } else {
+            double q = -1.0, per = 0.0;                                                   // cgroup v1
+            if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(fq, "%lf", &q) != 1) q = -1.0; std::fclose(fq); }
+            if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(fp, "%lf", &per) != 1) per = 0.0; std::fclose(fp); }
+            if (q > 0.0 && per > 0.0) quota = q / per;
+        }
+        if (quota >= 1.0) cpus = std::min(cpus, (int)quota);
+        return std::max(1, cpus);
+    }();
+    return n;
+}
+inline int host_team() { return std::max(1, std::min(omp_get_max_threads(), usable_cpus())); }
 
 using Clock = std::chrono::steady_clock;
 inline double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
@@ -297,7 +326,7 @@ static int run_trials_core(dcreg_ctx *ctx, int64_t n_trials, const double *R0, c
         const int nl = (int)G.live.size();
         // host steps 6-9 of every live trial are independent: spread them over host threads
         std::vector<uint8_t> ended((size_t)nl, 0);
-        const int nthreads = std::max(1, std::min({omp_get_max_threads(), 32, nl / 8}));
+        const int nthreads = std::max(1, std::min({host_team(), 32, nl / 8}));
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int j = 0; j < nl; ++j) {
             Slot &S = slot[(size_t)G.live[(size_t)j]];
@@ -372,7 +401,7 @@ int dcreg_icp_run_montecarlo(dcreg_ctx *ctx, const double base_xyzrpy[6], uint64
     if (!ctx || !base_xyzrpy || !cfg || !results || n_trials < 0 || first_trial < 0 || trial_stride < 1) return DCREG_E_INVALID;
     if (n_trials == 0) return DCREG_OK;
     std::vector<double> R0((size_t)n_trials * 9), t0((size_t)n_trials * 3);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_team())
     for (int64_t j = 0; j < n_trials; ++j) {
         double T[16];
         dcreg_trial_pose(base_xyzrpy, seed, first_trial + j * trial_stride, trans_amp, rot_amp_rad, T, nullptr);

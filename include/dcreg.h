@@ -372,7 +372,9 @@ int dcreg_comm_allgather(dcreg_ctx *, const double *send, double *recv, int64_t 
 int dcreg_comm_info(const dcreg_ctx *, int *rank, int *world);
 
 /* host threads the batched engines may use for the per-trial 6x6 steps (OpenMP; the reference hard-codes 8, :1714).  Launchers
- * that pin OMP_NUM_THREADS=1 (torch.distributed.run) should set this to the CPUs the rank really owns. */
+ * that pin OMP_NUM_THREADS=1 (torch.distributed.run) should set this to the CPUs the rank really owns.  Whatever is set, the engines
+ * never use more threads than the process can keep busy - min(affinity mask, cgroup CPU quota): OpenMP's default inside a container is
+ * the machine's hardware thread count. */
 int dcreg_set_host_threads(int n);
 int dcreg_get_host_threads(void);
 
