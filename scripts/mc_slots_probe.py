@@ -13,12 +13,14 @@ cfg = api.default_config(search_radius=1.0, max_iterations=30, CONVERGENCE_THRES
 base = (0.2, 0.8, 0.5, h.deg2rad(0.1), h.deg2rad(0.1), h.deg2rad(2.0))
 ctx = api.Context(0)
 ctx.set_target(pts, 1.0); ctx.set_source(pts)
-for slots in (256, 256):
+THREADS = [int(x) for x in os.environ.get("MC_THREADS", "0").split(",")]
+for thr, slots in [(t, sl) for t in THREADS for sl in (1024, 1536, 2048, 3072, 1024)]:
+    if thr: api.set_host_threads(thr)
     ctx.montecarlo_job(base, 2024, 5000, 0.5, np.deg2rad(2.0), "Ours", cfg, slots=slots, want_records=False)
     ts = []
     for rep in range(3):
         t0 = time.perf_counter()
         _, st = ctx.montecarlo_job(base, 2024, 5000, 0.5, np.deg2rad(2.0), "Ours", cfg, slots=slots, want_records=False)
         ts.append(time.perf_counter() - t0)
-    print("slots %4d: %.2f ms  %.3f M it/s" % (slots, 1e3 * min(ts), st["iterations_total"] / min(ts) / 1e6), flush=True)
+    print("threads %2d slots %4d: %.2f ms  %.3f M it/s" % (thr, slots, 1e3 * min(ts), st["iterations_total"] / min(ts) / 1e6), flush=True)
 ctx.close()
