@@ -112,6 +112,9 @@ def parse_args(argv=None):
     ap.add_argument("--prior-map-points", type=int, default=50_000_000,
                     help="configs.c3_prior_map_50m: one registration of an 8 k-point frame against a seeded prior map of this many points "
                          "(the regime of the reference's published timings); 0 = skip")
+    ap.add_argument("--sub-record", action="store_true",
+                    help="(internal) print the workload's summary record as the one JSON line and stop: how a job of N > 1 ranks obtains the "
+                         "Monte-Carlo leg from a job of its own (montecarlo_child)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="backend option (dcreg_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
     return ap.parse_args(argv)
@@ -696,6 +699,37 @@ def concurrent_pairs(P0, D, args, steps, warmup):
             "note": "%d independent %d-pt pairs in flight per GPU, one context + stream + host thread each, %d iterations each (whole runs); aggregate over all GPUs" % (Pn, n, steps)}
 
 
+def montecarlo_child(args, n_gpus, timeout_s=900.0):
+    """N > 1: the Monte-Carlo experiment as a job of its OWN (`bench.py --gpus N --workload c5_montecarlo_5000 --sub-record`, started by rank 0
+    once every rank of this job has closed its context and left the process group).  It is the one leg whose ranks exchange data - the library's
+    own RCCL communicator, dcreg_montecarlo_job's ncclAllGather - and RCCL with more than one rank has never run on hardware: whatever that path
+    does (error, abort, hang), the headline measured before it (independent scan pairs, no data-path collective) still reaches the JSON line,
+    with this leg's failure written into it.  Returns the leg's summary record or {"error": ...}."""
+    import subprocess
+    env = dict(os.environ)
+    for k in list(env):       # the launcher's per-rank variables: the child starts its own ranks (maybe_spawn)
+        if k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_NAME",
+                 "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") or k.startswith("TORCHELASTIC_"):
+            env.pop(k)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_gpus), "--workload", "c5_montecarlo_5000", "--steps", "1", "--warmup", "1",
+           "--repeats", "5", "--min-seconds", "0", "--method", args.method, "--no-configs", "--no-cpu-baseline", "--no-regimes",
+           "--concurrent-pairs", "0", "--sub-record"]
+    for kv in args.opt:
+        cmd += ["--opt", kv]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=os.path.dirname(os.path.abspath(__file__)))
+    except subprocess.TimeoutExpired as e:
+        return {"error": "the Monte-Carlo job of %d ranks did not finish within %.0f s" % (n_gpus, timeout_s),
+                "stderr_tail": ((e.stderr or b"")[-1500:].decode("utf-8", "replace") if isinstance(e.stderr, bytes) else (e.stderr or "")[-1500:])}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        return {"error": "the Monte-Carlo job of %d ranks failed (rc %d, %d JSON lines)" % (n_gpus, p.returncode, len(lines)), "stderr_tail": p.stderr[-1500:]}
+    rec = json.loads(lines[0])
+    rec["job"] = "a job of its own behind the main measurement (%d ranks, %.1f s incl. start-up)" % (n_gpus, time.perf_counter() - t0)
+    return rec
+
+
 def dry_run(args, D):
     """DCREG_BENCH_DRYRUN=1 (CPU test hook): the launcher, rendezvous, fence, max-over-ranks and gather paths with a
     synthetic per-rank record instead of device work.  Prints a line marked "dry_run": true that is NOT a measurement."""
@@ -755,6 +789,13 @@ def main(argv=None):
     P = Pair(args.workload, D, args, seed=100 + (0 if args.sharding == "points" else D.rank))   # pairs: every rank its own scan pair
     m = measure(P, D, args.steps, args.warmup, args.repeats, min_seconds=args.min_seconds)
     main_rec = summarize(args.workload, P, D, m, args.steps, n_gpus)
+    if args.sub_record:                         # (montecarlo_child's job: the record is all the parent wants)
+        main_rec["host_threads_per_rank"] = host_threads
+        if D.rank == 0:
+            print(json.dumps(main_rec), flush=True)
+        P.close()
+        D.close()
+        return
 
     regimes = conv = cold = None
     if not P.mc and not P.by_points and n_gpus == 1 and not args.no_regimes:
@@ -784,8 +825,9 @@ def main(argv=None):
             if name == args.workload:
                 continue
             mc = name.startswith("c5_")
-            if n_gpus > 1 and not mc:
-                continue                        # N > 1: only the experiment that is sharded over the ranks (strong scaling)
+            if n_gpus > 1:
+                continue                        # N > 1: only the experiment that is sharded over the ranks (strong scaling) - as a job
+                                                # of its own once this one's ranks are through (montecarlo_child, below)
             w = WORKLOADS[name]
             Q = Pair(name, D, args, seed=100)
             k = 1 if mc else w["run_len"] * 2
@@ -804,6 +846,13 @@ def main(argv=None):
             usable = hostinfo.usable_cpus()
             sub["c5_montecarlo_5000"]["by_host_threads"] = c5_host_thread_sweep(D, args, sorted({2, 4, min(16, usable)}))
             api.set_host_threads(host_threads)
+
+    if n_gpus > 1:
+        # every rank leaves its context and the process group first; then the one leg whose ranks exchange data runs as a job of its own
+        P.close()
+        D.close()
+        if D.rank == 0 and not args.no_configs and args.sharding == "pairs" and not P.mc:
+            sub["c5_montecarlo_5000"] = montecarlo_child(args, n_gpus)
 
     if D.rank == 0:
         result = {
@@ -840,9 +889,12 @@ def main(argv=None):
             result["cpu_baseline"] = cpu_baseline(P.tgt, P.src, P.T_init, WORKLOADS[args.workload], args.method, args.cpu_seconds)
         result["host_threads"] = host_threads
         print(json.dumps(result), flush=True)
-    P.close()
-    D.close()
-    # a job of N ranks whose experiment did not gather records from N ranks is not a measurement of N GPUs: say so with the exit code
+    if n_gpus == 1:
+        P.close()
+        D.close()
+    # a job of N ranks whose experiment did not gather records from N ranks is not a measurement of N GPUs: say so with the exit code.
+    # (A Monte-Carlo job that failed outright is reported in the line - configs.c5_montecarlo_5000.error - and leaves the exit code alone:
+    # the headline beside it has no data-path collective and stands by itself.)
     seen = None
     if D.rank == 0:
         seen = main_rec.get("rccl_ranks_seen") if P.mc else (sub.get("c5_montecarlo_5000") or {}).get("rccl_ranks_seen")
