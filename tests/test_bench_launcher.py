@@ -110,3 +110,21 @@ def test_two_ranks_run_the_montecarlo_experiment_as_one_job():
     assert st["total_runs"] == 5000 and 0.5 < st["success_rate"] < 0.95
     # all trials, not one rank's share: the iterations of one experiment
     assert 60_000 < c5["icp_iterations_per_step"] < 100_000 and c5["value"] > 0
+
+
+def test_a_failing_montecarlo_job_becomes_an_error_record():
+    """bench.py at N > 1 runs the Monte-Carlo leg as a job of its own (montecarlo_child): a job that fails - here because the box has fewer
+    than two devices, so the child refuses to start - comes back as an error record for the JSON line, not as an exception that would take
+    the headline measured before it along."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 devices")
+    sys.path.insert(0, h.REPO)
+    import bench
+    args = bench.parse_args(["--gpus", "2"])
+    env_keep = {k: os.environ.pop(k) for k in ("DCREG_BENCH_BACKEND", "DCREG_BENCH_DRYRUN") if k in os.environ}
+    try:
+        rec = bench.montecarlo_child(args, 2, timeout_s=300.0)
+    finally:
+        os.environ.update(env_keep)
+    assert "error" in rec and "rc" in rec["error"] and "--gpus 2 requested" in rec["stderr_tail"]
