@@ -46,6 +46,11 @@ for case in range(n_cases):
                 soft += 1; tag = "soft"
             else:
                 bad += 1; tag = "HARD"
+            if first_div is not None and first_div < min(len(logs), len(ologs)):       # how far apart, and how large the update itself is
+                da, db = np.array(logs[first_div].update_dx[:]), np.array(ologs[first_div].dx[:])
+                print("     |dx - dx_oracle| max %.3e at iteration %d, |dx| max %.3e; final pose: trans diff %.3e, R diff %.3e" % (
+                    np.max(np.abs(da - db)), first_div, np.max(np.abs(db)), np.max(np.abs(np.array(res.t[:]) - np.array(ores.t[:]))),
+                    np.max(np.abs(np.array(res.R[:]) - np.array(ores.R[:])))), flush=True)
             print("%s case %d %s: iterations %d/%d converged %d/%d first divergence at %s (n_eff %s vs %s)" % (
                 tag, case, m, res.iterations, ores.iterations, res.converged, ores.converged, first_div,
                 logs[first_div].effective_points if first_div is not None and first_div < len(logs) else "-",
