@@ -132,7 +132,7 @@ EXPORTS = [
     "dcreg_default_lin_params", "dcreg_linearize", "dcreg_linearize_batch", "dcreg_linearize_batch_begin",
     "dcreg_linearize_batch_end", "dcreg_linearize_batch_begin_warm", "dcreg_reserve_warm_states", "dcreg_reset_warm_state", "dcreg_hint_misalignment", "dcreg_linearize_debug", "dcreg_launch_stats_get", "dcreg_knn", "dcreg_kdtree_build", "dcreg_kdtree_info", "dcreg_knn_timed",
     "dcreg_linearize_gated_begin", "dcreg_linearize_gate_open", "dcreg_linearize_gate_abort",
-    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_launch_series", "dcreg_launch_series_passes", "dcreg_team_pass_stamps", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
+    "dcreg_index_info_get", "dcreg_kernel_time", "dcreg_launch_series", "dcreg_launch_series_passes", "dcreg_team_pass_stamps", "dcreg_roi_info", "dcreg_default_config", "dcreg_analyze_degeneracy", "dcreg_analyze_degeneracy_two_part",
     "dcreg_solve_degenerate_system", "dcreg_unpack_hessian", "dcreg_boxplus", "dcreg_pose6d_to_matrix",
     "dcreg_pose_error", "dcreg_icp_run", "dcreg_icp_run_sharded", "dcreg_icp_run_many", "dcreg_icp_run_euler", "dcreg_icp_run_trials", "dcreg_icp_run_montecarlo", "dcreg_p2p_error", "dcreg_sizeof", "dcreg_version", "dcreg_trial_pose",
     "dcreg_set_host_threads", "dcreg_get_host_threads", "dcreg_comm_unique_id", "dcreg_comm_init", "dcreg_comm_destroy", "dcreg_comm_allgather_sum", "dcreg_icp_run_sharded_rccl",
@@ -579,6 +579,14 @@ class Context:
         st = np.zeros((n + 1, 8), np.uint64)          # the last row: outcome counts (served with slack, layers, wide, rows, list, OUT, no slack, refit)
         self._L.dcreg_team_pass_stamps(self._h, st.ctypes.data_as(C.POINTER(C.c_uint64)), n + 1)
         return st
+
+    def roi_info(self):
+        """dcreg_roi_info: the window index of a large map (dcreg_debug.h)"""
+        v = (C.c_double * 11)()
+        self._L.dcreg_roi_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._check(self._L.dcreg_roi_info(self._h, v), "dcreg_roi_info")
+        return {"box_min": [v[0], v[1], v[2]], "box_max": [v[3], v[4], v[5]], "points": int(v[6]), "cell": v[7], "windows_built": int(v[8]),
+                "active": bool(v[9]), "whole_map_capped": bool(v[10])}
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()

@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include "../../../include/dcreg_debug.h"
 #include "context.hpp"
@@ -164,7 +165,12 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
     const double h_cap = radius_hint > 0.0 ? radius_hint * 1.00001 : ext / std::cbrt((double)n) * 4.0;
     uint32_t occ = 0;
     double h = c->opt_cell > 0.0 ? c->opt_cell : h_cap;
-    h = cap_cell_for_budget(h, mn, mx, max_cells);
+    c->last_build_capped = false;            // (the table budget decided the cell edge or the x sub-cells: dcreg_ctx::whole_capped)
+    {
+        const double h0 = h;
+        h = cap_cell_for_budget(h, mn, mx, max_cells);
+        if (h > h0) c->last_build_capped = true;
+    }
     rc = build_grid_at(c, d, h, mn, mx, &occ);
     if (rc) return rc;
     if (c->opt_cell <= 0.0) {
@@ -175,7 +181,11 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
         for (int pass = 0; pass < 2 && m1 > target_occ * 1.3; ++pass) {
             double h2 = h1 * std::pow(target_occ / m1, 1.0 / expo);
             h2 = std::max(h2, h_cap / 64.0);
-            h2 = cap_cell_for_budget(h2, mn, mx, max_cells);
+            {
+                const double h20 = h2;
+                h2 = cap_cell_for_budget(h2, mn, mx, max_cells);
+                if (h2 > h20) c->last_build_capped = true;
+            }
             if (h2 >= h1 * 0.95) break;
             rc = build_grid_at(c, d, h2, mn, mx, &occ);
             if (rc) return rc;
@@ -188,7 +198,7 @@ static int build_index(dcreg_ctx *c, const GridDst &d, double radius_hint, uint3
     // the cell edge is settled: cut x into sub-cells (same rows, same table loads, tighter candidate runs), as far as the
     // table budget allows
     int sx = c->opt_x_subdiv;
-    while (sx > 1 && (double)d.grid->nx * sx * d.grid->ny * d.grid->nz > max_cells) sx >>= 1;
+    while (sx > 1 && (double)d.grid->nx * sx * d.grid->ny * d.grid->nz > max_cells) { sx >>= 1; c->last_build_capped = true; }
     if (sx > 1) {
         uint32_t occ_sub = 0;
         rc = build_grid_at(c, d, d.grid->h, mn, mx, &occ_sub, sx);
@@ -250,6 +260,107 @@ static GridDst target_dst(dcreg_ctx *c) {
     return GridDst{c->d_tgt_raw, c->n_tgt, &c->d_tgt, &c->tgt_cap, &c->d_cell_start, &c->cell_cap, &c->grid, &c->n_cells};
 }
 
+// ------------------------------------------------------------------------------------------ the window index of a large map (context.hpp)
+static void swap_index(dcreg_ctx *c) {
+    dcreg_ctx::IndexSet &s = c->roi_store;
+    std::swap(c->d_tgt_raw, s.raw); std::swap(c->tgt_raw_cap, s.raw_cap); std::swap(c->n_tgt, s.n);
+    std::swap(c->d_tgt, s.sorted); std::swap(c->tgt_cap, s.sorted_cap);
+    std::swap(c->d_cell_start, s.cell_start); std::swap(c->cell_cap, s.cell_cap);
+    std::swap(c->grid, s.grid); std::swap(c->n_cells, s.n_cells); std::swap(c->occupied_cells, s.occupied);
+    std::swap(c->d_gap, s.gap); std::swap(c->gap_cap, s.gap_cap);
+    std::swap(c->d_owner, s.owner); std::swap(c->owner_cap, s.owner_cap);
+    std::swap(c->d_ymask, s.ymask); std::swap(c->ymask_cap, s.ymask_cap);
+    c->roi_active = !c->roi_active;
+    drop_warm(c);                 // the states' positions are positions in the other index's order
+    c->order_valid = false;
+    c->last_pose_valid = false;
+}
+
+int roi_deactivate(dcreg_ctx *c) {
+    if (c && c->roi_active) swap_index(c);
+    return DCREG_OK;
+}
+
+// bounding box of the source at a pose: the box of the eight corners of its body-frame box
+static void source_box_at(const dcreg_ctx *c, const double *R, const double *t, double lo[3], double hi[3]) {
+    for (int a = 0; a < 3; ++a) { lo[a] = 1e300; hi[a] = -1e300; }
+    for (int k = 0; k < 8; ++k) {
+        const double p[3] = {(k & 1) ? c->src_mx[0] : c->src_mn[0], (k & 2) ? c->src_mx[1] : c->src_mn[1], (k & 4) ? c->src_mx[2] : c->src_mn[2]};
+        for (int a = 0; a < 3; ++a) {
+            const double w = R[a * 3] * p[0] + R[a * 3 + 1] * p[1] + R[a * 3 + 2] * p[2] + t[a];
+            lo[a] = std::min(lo[a], w); hi[a] = std::max(hi[a], w);
+        }
+    }
+}
+// every query of a linearisation at this pose, and the ball of the search radius around it, lies inside the window's box
+static bool roi_covers(const dcreg_ctx *c, const double *R, const double *t, double pad) {
+    double lo[3], hi[3];
+    source_box_at(c, R, t, lo, hi);
+    for (int a = 0; a < 3; ++a) {
+        if (!(lo[a] - pad >= c->roi_lo[a] && hi[a] + pad <= c->roi_hi[a])) return false;      // (also false for a NaN pose)
+    }
+    return true;
+}
+static bool roi_wanted(const dcreg_ctx *c) { return c->opt_roi_index == 2 || (c->opt_roi_index == 1 && c->whole_capped); }
+
+static int build_gap_field(dcreg_ctx *c, double radius_hint);
+static int build_row_words(dcreg_ctx *c);
+// A single-pose linearisation at (R, t) with this search radius is about to be queued: make the index it should search the active one -
+// the window if the map wants one (building it around the pose when there is none that covers it), the whole map otherwise.
+static int roi_ensure(dcreg_ctx *c, const double *R, const double *t, double search_radius) {
+    if (!roi_wanted(c)) return roi_deactivate(c);
+    const double pad = std::max(search_radius, c->radius_hint) * (1.0 + c->opt_cert_margin) * 1.001 + 1e-3;
+    if (c->roi_built && pad <= c->roi_pad && roi_covers(c, R, t, pad)) {
+        if (c->roi_empty) return roi_deactivate(c);
+        if (!c->roi_active) swap_index(c);
+        return DCREG_OK;
+    }
+    // ---- a new window around this pose
+    (void)roi_deactivate(c);                                        // the members are the whole map's
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                    // (nothing in flight reads the buffers that are about to be replaced)
+    double lo[3], hi[3];
+    source_box_at(c, R, t, lo, hi);
+    for (int a = 0; a < 3; ++a) {
+        if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) return DCREG_OK;          // a pose that is not a pose: the whole map, the kernels decide
+        c->roi_lo[a] = lo[a] - pad - c->opt_roi_margin; c->roi_hi[a] = hi[a] + pad + c->opt_roi_margin;
+    }
+    c->roi_pad = pad;
+    c->roi_built = false; c->roi_empty = false;
+    const int64_t n = c->n_tgt;
+    if (ensure(c, c->d_roi_flags, c->roi_flags_cap, (size_t)n)) return DCREG_E_NOMEM;
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
+    // (the box in floats, rounded outwards: a point the float comparison keeps out is farther than pad from every query)
+    const float fl[3] = {std::nextafterf((float)c->roi_lo[0], -INFINITY), std::nextafterf((float)c->roi_lo[1], -INFINITY), std::nextafterf((float)c->roi_lo[2], -INFINITY)};
+    const float fh[3] = {std::nextafterf((float)c->roi_hi[0], INFINITY), std::nextafterf((float)c->roi_hi[1], INFINITY), std::nextafterf((float)c->roi_hi[2], INFINITY)};
+    hipLaunchKernelGGL(k_roi_flags, dim3(std::min<unsigned>(blocks_for(n, 256), 4096u)), dim3(256), 0, c->stream, c->d_tgt_raw, n, fl[0], fl[1], fl[2], fh[0], fh[1], fh[2],
+                       c->d_roi_flags, c->d_scratch);
+    uint32_t count = 0;
+    HIP_TRY(c, hipMemcpyAsync(&count, c->d_scratch, sizeof(count), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    c->roi_rebuilds += 1;
+    if (count == 0u || (int64_t)count == n) {        // nothing of the map in the box / all of it: the whole map's index serves inside this box
+        c->roi_built = true; c->roi_empty = true;
+        return DCREG_OK;
+    }
+    dcreg_ctx::IndexSet &s = c->roi_store;
+    if (ensure(c, s.raw, s.raw_cap, (size_t)count)) return DCREG_E_NOMEM;
+    {   // the points of the box in the map's order (stable: ties and the plane fit's row order are decided by the original index anyway)
+        size_t tmp = 0;
+        HIP_TRY(c, rocprim::select(nullptr, tmp, c->d_tgt_raw, c->d_roi_flags, s.raw, c->d_scratch + 8, (size_t)n, c->stream));
+        if (ensure(c, c->sort_tmp, c->sort_tmp_cap, tmp) != DCREG_OK) return DCREG_E_NOMEM;
+        HIP_TRY(c, rocprim::select(c->sort_tmp, tmp, c->d_tgt_raw, c->d_roi_flags, s.raw, c->d_scratch + 8, (size_t)n, c->stream));
+    }
+    s.n = (int64_t)count;
+    swap_index(c);                                                  // the members are the window's now (its buffers of the last build are reused)
+    int rc = build_index(c, target_dst(c), c->radius_hint * (1.0 + c->opt_cert_margin), &c->occupied_cells);
+    if (rc == DCREG_OK) rc = build_gap_field(c, c->radius_hint * (1.0 + c->opt_cert_margin));
+    if (rc == DCREG_OK) rc = build_row_words(c);
+    if (rc != DCREG_OK) { swap_index(c); return rc; }               // (the whole map stays usable)
+    c->roi_built = true;
+    return DCREG_OK;
+}
+
 // grid over the body-frame source cloud (backward pass of dcreg_p2p_error); built lazily, once per source
 int build_aux_index(dcreg_ctx *c) {
     if (c->aux_valid) return DCREG_OK;
@@ -300,6 +411,8 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     if (!c) return DCREG_E_INVALID;
     if (n <= 0) { c->fail("target cloud is null or empty"); return DCREG_E_INVALID; }   // icp_test_runner.cpp:1643
     HIP_TRY(c, hipSetDevice(c->device));
+    (void)roi_deactivate(c);             // the new map goes into the whole map's buffers; a window of the old one means nothing
+    c->roi_built = false; c->whole_capped = false;
     int rc = upload_cloud(c, xyz, n, stride, on_device, c->d_tgt_raw, c->tgt_raw_cap);
     if (rc) return rc;
     c->n_tgt = n;
@@ -307,6 +420,7 @@ static int set_target(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
     // the cells are sized for the SEARCH radius (make_lin_args): one ring must cover it
     rc = build_index(c, target_dst(c), radius_hint * (1.0 + c->opt_cert_margin), &c->occupied_cells);
     if (rc) { c->n_tgt = 0; return rc; }
+    c->whole_capped = c->last_build_capped;
     rc = build_gap_field(c, radius_hint * (1.0 + c->opt_cert_margin));
     if (rc) { c->n_tgt = 0; return rc; }
     rc = build_row_words(c);
@@ -334,6 +448,7 @@ static int set_source(dcreg_ctx *c, const float *xyz, int64_t n, int64_t stride,
         if (rc) return rc;
     }
     for (int a = 0; a < 3; ++a) if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) { c->fail("source cloud has non-finite coordinates"); return DCREG_E_INVALID; }
+    for (int a = 0; a < 3; ++a) { c->src_mn[a] = mn[a]; c->src_mx[a] = mx[a]; }
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-6});
     const double inv_q = 2097151.0 / ext * 0.999999;
     {   // farthest corner of the bounding box: no point is farther from the body-frame origin
@@ -560,6 +675,14 @@ static int linearize_begin(dcreg_ctx *c, int slot, int n_poses, const double *R9
     if (c->n_tgt <= 0) { c->fail("KdTree/target index is not set up in context"); return DCREG_E_STATE; }   // :1639
     if (c->n_src <= 0) { c->fail("measure cloud is not set"); return DCREG_E_STATE; }
     if (c->need_set_device) { HIP_TRY(c, hipSetDevice(c->device)); }     // (before make_lin_args: the Euler branch allocates and copies)
+    // which index the launch searches (context.hpp, the window of a large map): single-pose product launches the window around their pose, a
+    // gated launch whatever is active (its pose is checked when the gate opens), everything else the whole map
+    if (!gated && (c->roi_active || roi_wanted(c))) {
+        if (!p) { c->fail("null argument"); return DCREG_E_INVALID; }
+        const bool product = n_poses == 1 && !state_ids && (!dbg_host || stamps_only);
+        const int rr = product ? roi_ensure(c, R9, t3, p->search_radius) : roi_deactivate(c);
+        if (rr) return rr;
+    }
     LinArgs a;
     int rc = make_lin_args(c, p, a);
     if (rc) return rc;
@@ -1187,7 +1310,8 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
                     c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner,
-                    c->d_adv_counts, c->d_team_stamps};
+                    c->d_adv_counts, c->d_team_stamps, c->d_roi_flags, c->roi_store.raw, c->roi_store.sorted, c->roi_store.cell_start, c->roi_store.gap,
+                    c->roi_store.owner, c->roi_store.ymask};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {
         for (void *b : {(void *)S.d_partials, (void *)S.d_poses, (void *)S.d_tickets}) if (b) (void)hipFree(b);
@@ -1241,6 +1365,8 @@ int dcreg_set_option(dcreg_ctx *c, const char *key, double v) {
     else if (k == "time_kernels") { c->opt_time_kernels = v > 0.0 ? (int)v : 0; c->launch_counter = 0; }
     else if (k == "record_launches") { c->opt_record_launches = v != 0.0; if (v == 0.0) c->launch_series.clear(); }
     else if (k == "curve_x_scale") c->opt_curve_x_scale = (v > 0.0 && v <= 1.0) ? v : 1.0;   // next dcreg_set_source: patches of the curve order 1 / v times as long in x
+    else if (k == "roi_index") { c->opt_roi_index = (int)std::min(std::max(v, 0.0), 2.0); c->roi_built = false; }   // 0 never, 1 auto, 2 always (next single-pose launch)
+    else if (k == "roi_margin") { c->opt_roi_margin = std::min(std::max(v, 0.0), 1.0e6); c->roi_built = false; }
     else if (k == "max_table_entries") c->opt_max_table_entries = (int64_t)std::min(std::max(v, 1048576.0), 2147483648.0);   // next dcreg_set_target
     else if (k == "advance") c->opt_advance = (int)v;            // the advance pass in front of single-pose launches: 0 never, 1 (default) by the host's rule, 2 whenever possible
     else if (k == "one_wave") c->opt_one_wave = (int)v;                  // k_lin in one-wave blocks: 0 never, 1 by the rule (launches of many blocks in which most waves search), 2 wherever possible
@@ -1329,6 +1455,13 @@ int dcreg_linearize_gated_begin(dcreg_ctx *c, int slot, const dcreg_lin_params *
 int dcreg_linearize_gate_open(dcreg_ctx *c, const double R[9], const double t[3]) {
     if (!c) return DCREG_E_INVALID;
     if (c->gate_slot < 0 || !R || !t) { c->fail("no gated linearisation waits for a pose"); return DCREG_E_STATE; }
+    if (c->roi_active && !roi_covers(c, R, t, c->roi_pad)) {
+        // the queued launch was built on a window this pose has left: it is called off; the caller starts the launch the plain way
+        // (DCREG_E_STATE = "no launch waits", as after a timeout) and that builds the window around the new pose
+        (void)dcreg_linearize_gate_abort(c);
+        c->fail("the pose left the window of the map the queued launch was built on: launch called off");
+        return DCREG_E_STATE;
+    }
     gate_publish(c, c->gate_seq << 1, R, t);
     std::memcpy(c->last_R, R, sizeof(c->last_R)); std::memcpy(c->last_t, t, sizeof(c->last_t));
     c->last_pose_valid = true;
@@ -1354,6 +1487,7 @@ int dcreg_linearize_debug(dcreg_ctx *c, const double R[9], const double t[3], co
 int dcreg_knn(dcreg_ctx *c, const float *q, int64_t n, int64_t stride, int k, double max_radius, int32_t *idx, float *d2) {
     if (!c) return DCREG_E_INVALID;
     if (!q || !idx || !d2 || n < 0 || (k != 1 && k != 5)) { c->fail("invalid k-NN arguments (k must be 1 or 5)"); return DCREG_E_INVALID; }
+    (void)roi_deactivate(c);
     if (c->n_tgt <= 0) { c->fail("target index is not set"); return DCREG_E_STATE; }
     if (n == 0) return DCREG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1370,10 +1504,22 @@ int dcreg_knn(dcreg_ctx *c, const float *q, int64_t n, int64_t stride, int k, do
 
 int dcreg_index_info_get(const dcreg_ctx *c, dcreg_index_info *info) {
     if (!c || !info) return DCREG_E_INVALID;
-    info->cell = c->grid.h;
-    info->origin[0] = c->grid.ox; info->origin[1] = c->grid.oy; info->origin[2] = c->grid.oz;
-    info->dims[0] = c->grid.nx; info->dims[1] = c->grid.ny; info->dims[2] = c->grid.nz;
-    info->n_cells = c->n_cells; info->n_target = c->n_tgt; info->n_source = c->n_src; info->max_ring = c->last_max_ring;
+    const dcreg::GridDev &g = c->roi_active ? c->roi_store.grid : c->grid;         // the whole map's index, whichever is active
+    info->cell = g.h;
+    info->origin[0] = g.ox; info->origin[1] = g.oy; info->origin[2] = g.oz;
+    info->dims[0] = g.nx; info->dims[1] = g.ny; info->dims[2] = g.nz;
+    info->n_cells = c->roi_active ? c->roi_store.n_cells : c->n_cells; info->n_target = c->roi_active ? c->roi_store.n : c->n_tgt;
+    info->n_source = c->n_src; info->max_ring = c->last_max_ring;
+    return DCREG_OK;
+}
+
+int dcreg_roi_info(const dcreg_ctx *c, double info[11]) {
+    if (!c || !info) return DCREG_E_INVALID;
+    for (int a = 0; a < 3; ++a) { info[a] = c->roi_lo[a]; info[3 + a] = c->roi_hi[a]; }
+    const bool have = c->roi_built && !c->roi_empty;
+    info[6] = have ? (double)(c->roi_active ? c->n_tgt : c->roi_store.n) : 0.0;
+    info[7] = have ? (c->roi_active ? c->grid.h : c->roi_store.grid.h) : 0.0;
+    info[8] = (double)c->roi_rebuilds; info[9] = c->roi_active ? 1.0 : 0.0; info[10] = c->whole_capped ? 1.0 : 0.0;
     return DCREG_OK;
 }
 

@@ -57,6 +57,37 @@ struct dcreg_ctx {
     double radius_hint = 0.0;
     int last_max_ring = 0;
 
+    // ---- the WINDOW index of a large map (context.hip roi_ensure).  A prior map whose dense cell table would exceed "max_table_entries" gets
+    // coarser cells the larger its extent - a local search then pays for the size of the map.  Single-pose linearisations of such a map
+    // therefore search a second index built over the points of a BOX around the transformed source (its bounding box at the pose, the search
+    // radius, "roi_margin" metres on top): the same points as the whole map holds there, in cells sized for their density alone.  Every
+    // neighbour of every query lies inside the box, so the searches return what they would on the whole map (exact: the sums are bitwise the
+    // same, tests/test_gpu_round6.py); a pose that leaves the box rebuilds the window around itself.  One of the two indices is ACTIVE (the
+    // members above: what every kernel launch uses), the other is kept in roi_store; swapping them drops the neighbour states (their
+    // positions refer to one index's sorted order).  Everything but the single-pose product launches (k-NN, metrics, batches, dumps, the
+    // kd-tree comparator) runs on the whole map.
+    struct IndexSet {
+        float4 *raw = nullptr; size_t raw_cap = 0; int64_t n = 0;
+        float4 *sorted = nullptr; size_t sorted_cap = 0;
+        uint32_t *cell_start = nullptr; size_t cell_cap = 0;
+        dcreg::GridDev grid{}; int64_t n_cells = 0; uint32_t occupied = 0;
+        uint8_t *gap = nullptr; size_t gap_cap = 0;
+        uint32_t *owner = nullptr; size_t owner_cap = 0;
+        uint32_t *ymask = nullptr; size_t ymask_cap = 0;
+    };
+    IndexSet roi_store;            // the index that is NOT active
+    bool roi_active = false;       // the members above hold the window, roi_store the whole map
+    bool roi_built = false;        // a window exists for the box roi_lo .. roi_hi
+    bool roi_empty = false;        // ... but the map has no point in it: the whole map serves inside this box
+    int opt_roi_index = 1;         // 0 never, 1 when the whole map's build ran into the table budget, 2 always
+    double opt_roi_margin = 20.0;  // metres of the box beyond what the first pose needs
+    bool whole_capped = false;     // the whole map's build enlarged its cells or dropped x sub-cells for the table budget
+    bool last_build_capped = false;
+    double roi_lo[3] = {}, roi_hi[3] = {}, roi_pad = 0.0;
+    double src_mn[3] = {}, src_mx[3] = {};      // bounding box of the source in the body frame (dcreg_set_source)
+    int64_t roi_rebuilds = 0;
+    uint8_t *d_roi_flags = nullptr; size_t roi_flags_cap = 0;
+
     // auxiliary grid over the body-frame source (backward pass of dcreg_p2p_error)
     float4 *d_aux = nullptr; size_t aux_cap = 0;
     uint32_t *d_aux_cell_start = nullptr; size_t aux_cell_cap = 0;
@@ -212,6 +243,7 @@ namespace dcreg {
 int launch_linearize(dcreg_ctx *c, int n_poses, const double *R9, const double *t3, const dcreg_lin_params *p,
                      dcreg_lin_out *outs, dcreg_lin_debug *dbg_host);
 void kdtree_free(void *kd);      // kdtree.hip (the comparator index of dcreg_debug.h)
+int roi_deactivate(dcreg_ctx *c);      // context.hip: make the whole map's index the active one (entry points that are not single-pose linearisations)
 int launch_knn(dcreg_ctx *c, const GridDev &grid, const float4 *d_q, int64_t n, int k, double max_radius, const PoseArg *pose,
                int32_t *d_idx, float *d_d2, bool sweep = false);
 }  // namespace dcreg

@@ -160,6 +160,7 @@ extern "C" {
 
 int dcreg_kdtree_build(dcreg_ctx *c, int leaf_size) {
     if (!c) return DCREG_E_INVALID;
+    (void)roi_deactivate(c);
     if (c->n_tgt <= 0) { c->fail("target cloud is not set"); return DCREG_E_STATE; }
     if (leaf_size < 1 || leaf_size > 256) { c->fail("kd-tree leaf size must be 1 .. 256"); return DCREG_E_INVALID; }
     HIP_TRY3(c, hipSetDevice(c->device));
@@ -194,6 +195,7 @@ int dcreg_knn_timed(dcreg_ctx *c, const float *q, int64_t n, int64_t stride, int
                     int32_t *idx, float *d2, double *kernel_ms) {
     if (!c) return DCREG_E_INVALID;
     if (!q || !idx || !d2 || n <= 0 || stride < 3 || (k != 1 && k != 5) || repeats < 1 || (index < 0 || index > 2)) { c->fail("invalid arguments"); return DCREG_E_INVALID; }
+    (void)roi_deactivate(c);
     if (c->n_tgt <= 0) { c->fail("target index is not set"); return DCREG_E_STATE; }
     if (index == 1 && (!c->kd || ((KdTree *)c->kd)->n != c->n_tgt)) { c->fail("dcreg_kdtree_build first (after the last dcreg_set_target)"); return DCREG_E_STATE; }
     HIP_TRY3(c, hipSetDevice(c->device));

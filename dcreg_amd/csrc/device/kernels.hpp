@@ -1272,6 +1272,24 @@ __host__ __device__ inline float ord2f(uint32_t o) {
     union { uint32_t u; float f; } cv; cv.u = u; return cv.f;
 }
 
+// the window index of a large map (context.hip roi_ensure): flag[i] = point i lies inside the box, *count += the flags (one atomic per block)
+static __global__ __launch_bounds__(256) void k_roi_flags(const float4 *__restrict__ p, int64_t n, float lx, float ly, float lz, float hx, float hy, float hz,
+                                                         uint8_t *__restrict__ flag, uint32_t *__restrict__ count) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 q = p[i];
+        const bool in = q.x >= lx && q.x <= hx && q.y >= ly && q.y <= hy && q.z >= lz && q.z <= hz;
+        flag[i] = in ? (uint8_t)1 : (uint8_t)0;
+        mine += in ? 1u : 0u;
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(count, s_cnt);
+}
+
 // bounds[0..2] = min (ordered-uint), bounds[3..5] = max
 static __global__ void k_bounds(const float4 *__restrict__ p, int64_t n, uint32_t *bounds) {
     float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};

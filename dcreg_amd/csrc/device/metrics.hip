@@ -53,6 +53,7 @@ extern "C" int dcreg_p2p_error(dcreg_ctx *c, const double T[16], double error_th
                                double *chamfer, int64_t *valid) {
     if (!c) return DCREG_E_INVALID;
     if (!T || !rmse || !fitness || !chamfer || !valid) { c->fail("null argument"); return DCREG_E_INVALID; }
+    (void)roi_deactivate(c);              // the metrics are taken on the whole map (context.hpp, the window index)
     if (c->n_tgt <= 0 || c->n_src <= 0) { c->fail("target / source clouds are not set"); return DCREG_E_STATE; }
     HIP_TRY2(c, hipSetDevice(c->device));
     const int64_t ns = c->n_src, nt = c->n_tgt;

@@ -70,6 +70,14 @@ int dcreg_launch_series_passes(dcreg_ctx *, uint8_t *advanced, int64_t cap);
  * returns the number of blocks of that launch.  Waits for the stream. */
 int dcreg_team_pass_stamps(dcreg_ctx *, uint64_t *out, int64_t cap_blocks);
 
+/* The window index of a large map (options "roi_index" 0 never / 1 when the whole map's cell table ran into "max_table_entries" (default) /
+ * 2 always, "roi_margin" metres, default 20): single-pose linearisations of such a map search an index over the map's points inside a box
+ * around the transformed source - same neighbours, same sums (bitwise), cells sized for the local density instead of the map's extent;
+ * everything else (dcreg_knn, dcreg_p2p_error, batches, dumps) runs on the whole map.  info[0..5] = the box (min xyz, max xyz),
+ * info[6] = points in the window, info[7] = its cell edge, info[8] = windows built since the context was created, info[9] = 1 while the
+ * window is the active index, info[10] = 1 when the whole map's build was cut by the table budget. */
+int dcreg_roi_info(const dcreg_ctx *, double info[11]);
+
 /* the analysis as the pipelined engine takes it: the part the step needs first, then what that left owed (*owed: 4 = the axis alignment of the Schur eigenvectors, 1 = the full
  * eigen-decomposition block, 2 = the diagonal blocks of the Schur analysis); the record must equal dcreg_analyze_degeneracy's */
 int dcreg_analyze_degeneracy_two_part(const double H[36], int detection, int handling, const dcreg_config *, dcreg_analysis *, int *owed);

@@ -273,3 +273,104 @@ def test_montecarlo_batches_in_one_wave_blocks_give_the_same_records():
         finally:
             ctx.close()
     assert np.array_equal(recs["one"], recs["four"]) and np.array_equal(recs["forced_small"], recs["four"])
+
+
+def _window_pair(n_map=3_000_000, extent=90.0):
+    tgt, src = h.scene_prior_map(n_map, extent=extent)
+    return tgt, src, h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
+
+
+def _run_record(ctx, T0, cfg):
+    res, logs = ctx.icp_run(T0, "Ours", cfg)
+    return (tuple(res.R[:]), tuple(res.t[:]), res.iterations, res.converged, res.status,
+            [(tuple(L.H_upper[:]), tuple(L.gradient[:]), L.effective_points, L.corr_pt_count, tuple(L.update_dx[:])) for L in logs])
+
+
+@pytest.mark.timeout(900)
+def test_the_window_index_of_a_large_map_is_invisible():
+    """The window index (context.hpp: single-pose linearisations of a large map search an index over the map's points in a box around the
+    transformed source): with it forced ("roi_index" 2) a walk of poses - steps inside the window, a jump that leaves it (a new window is
+    built), the way back - gives bitwise the 31 sums of a context that searches the whole map; whole registrations (pipelined runs: gated
+    launches, one of them with a margin of ZERO, so that nearly every pose leaves the window, the queued launch is called off and the window
+    rebuilt) return bitwise the same poses, iteration counts and per-iteration sums; dcreg_knn and dcreg_p2p_error of the windowed context
+    answer from the whole map."""
+    tgt, src, gt, T0 = _window_pair()
+    prm = api.default_lin_params(0.5, 0)
+    cfg = api.default_config(search_radius=0.5, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=1e-5,
+                             CONVERGENCE_THRESH_TRANS=1e-3, use_weight_derivative=0, always_compute_schur=1, gt_matrix=gt.reshape(16))
+    whole, win, win0 = api.Context(0), api.Context(0), api.Context(0)
+    try:
+        whole.set_option("roi_index", 0)
+        win.set_option("roi_index", 2); win.set_option("roi_margin", 3.0)
+        win0.set_option("roi_index", 2); win0.set_option("roi_margin", 0.0)
+        for c in (whole, win, win0):
+            c.set_target(tgt, 0.5); c.set_source(src)
+        assert not win.roi_info()["active"]
+        # a walk: inside the window, out of it, back
+        steps = [(0, 0, 0, 0), (0.02, -0.01, 0.0, 0.001), (0.5, 0.4, 0.02, 0.01), (2.5, -2.0, 0.1, 0.02), (9.0, 7.0, 0.0, 0.05), (9.05, 7.02, 0.0, 0.051),
+                 (0.02, -0.01, 0.0, 0.001), (-30.0, 25.0, 0.3, 0.2), (0, 0, 0, 0)]
+        built = []
+        for dx, dy, dz, yaw in steps:
+            T = T0 @ h.pose6d_matrix(dx, dy, dz, 0.0, 0.0, yaw)
+            a = whole.linearize(T[:3, :3], T[:3, 3], prm)
+            b = win.linearize(T[:3, :3], T[:3, 3], prm)
+            assert _same_sums(a, b), (dx, dy, dz, yaw, a["n_eff"], b["n_eff"])
+            built.append(win.roi_info()["windows_built"])
+        info = win.roi_info()
+        assert info["active"] and 0 < info["points"] < len(tgt) and built[0] == 1 and built[2] == 1 and built[4] > built[2] and built[-1] > built[4]
+        assert win.index_info().n_target == len(tgt) and whole.index_info().n_cells == win.index_info().n_cells       # (the info is the whole map's)
+        # whole registrations (new frame each time, as the registration path runs: dcreg_set_source + run)
+        for c in (whole, win, win0):
+            c.set_source(src)
+        r_whole, r_win, r_win0 = _run_record(whole, T0, cfg), _run_record(win, T0, cfg), _run_record(win0, T0, cfg)
+        assert r_whole[4] == 0 and r_whole[2] > 5
+        assert r_win == r_whole
+        assert r_win0 == r_whole
+        assert win0.roi_info()["windows_built"] > 3                     # margin 0: the window followed the pose through the run
+        # a second run from the warm state of the first, and the other methods
+        assert _run_record(win, T0, cfg) == _run_record(whole, T0, cfg)
+        # everything else answers from the whole map
+        q = (tgt[::40000] + np.float32(0.01)).astype(np.float32)
+        ia, da = whole.knn(q, 5)
+        ib, db = win.knn(q, 5)
+        assert np.array_equal(ia, ib) and np.array_equal(da.view(np.uint32), db.view(np.uint32)) and not win.roi_info()["active"]
+        assert win.p2p_error(T0, 1.0) == whole.p2p_error(T0, 1.0)
+        b = win.linearize(T0[:3, :3], T0[:3, 3], prm)                   # ... and the next linearisation is back on the window
+        assert win.roi_info()["active"] and _same_sums(whole.linearize(T0[:3, :3], T0[:3, 3], prm), b)
+        # batches and dumps run on the whole map
+        Rs = np.stack([T0[:3, :3], T0[:3, :3]]); ts = np.stack([T0[:3, 3], T0[:3, 3] + 0.01])
+        ba, bb = whole.linearize_batch(Rs, ts, prm), win.linearize_batch(Rs, ts, prm)
+        assert all(_same_sums(x, y) for x, y in zip(ba, bb)) and not win.roi_info()["active"]
+    finally:
+        for c in (whole, win, win0):
+            c.close()
+
+
+@pytest.mark.timeout(900)
+def test_the_window_index_engages_by_itself_when_the_table_budget_binds():
+    """Default rule ("roi_index" 1): a map whose dense cell table runs into "max_table_entries" - here a budget of 2^21 entries on a 3 M-point
+    map, the situation of a 200 M-point map under the default 2^30 - registers frames on a window with the cells its density asks for; a map
+    that fits its budget never builds one.  Same registration, bit for bit, either way."""
+    tgt, src, gt, T0 = _window_pair()
+    cfg = api.default_config(search_radius=0.5, max_iterations=30, KAPPA_TARGET=10.0, STD_REG_GAMMA=100.0, CONVERGENCE_THRESH_ROT=1e-5,
+                             CONVERGENCE_THRESH_TRANS=1e-3, use_weight_derivative=0, always_compute_schur=1, gt_matrix=gt.reshape(16))
+    fits, capped = api.Context(0), api.Context(0)
+    try:
+        capped.set_option("max_table_entries", 1 << 21)
+        for c in (fits, capped):
+            c.set_target(tgt, 0.5); c.set_source(src)
+        ra, rb = _run_record(fits, T0, cfg), _run_record(capped, T0, cfg)
+        assert ra == rb and ra[4] == 0 and ra[2] > 5
+        ia, ib = fits.roi_info(), capped.roi_info()
+        assert not ia["whole_map_capped"] and not ia["active"] and ia["windows_built"] == 0
+        assert ib["whole_map_capped"] and ib["active"] and ib["windows_built"] == 1 and 0 < ib["points"] < len(tgt)
+        assert ib["cell"] < 0.75 * capped.index_info().cell          # the window's cells are the density's, the whole map's the budget's
+        # the next frames of the drive reuse the window
+        for k in range(3):
+            T = T0 @ h.pose6d_matrix(0.3 * (k + 1), 0.1 * k, 0.0, 0.0, 0.0, 0.002 * k)
+            for c in (fits, capped):
+                c.set_source(src)
+            assert _run_record(fits, T, cfg) == _run_record(capped, T, cfg)
+        assert capped.roi_info()["windows_built"] == 1
+    finally:
+        fits.close(); capped.close()
