@@ -115,6 +115,9 @@ def parse_args(argv=None):
     ap.add_argument("--sub-record", action="store_true",
                     help="(internal) print the workload's summary record as the one JSON line and stop: how a job of N > 1 ranks obtains the "
                          "Monte-Carlo leg from a job of its own (montecarlo_child)")
+    ap.add_argument("--prior-map-points-large", type=int, default=200_000_000,
+                    help="configs.c3_prior_map_200m: the same registration against a 1.4 km x 1.4 km seeded map of this many points (the upper end of the "
+                         "reference's published range; its dense cell table runs into the budget, so the frames are registered on the window index); 0 = skip")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="backend option (dcreg_set_option), e.g. --opt warm_start=0 --opt cell_factor=1.5 (ablations)")
     return ap.parse_args(argv)
@@ -564,7 +567,7 @@ def converged_run(P, D, repeats=10, cold=False):
                 cfg.CONVERGENCE_THRESH_ROT, cfg.CONVERGENCE_THRESH_TRANS, P.w["run_len"])}
 
 
-def c3_registration(D, args, repeats=20, prior_map_points=0):
+def c3_registration(D, args, repeats=20, prior_map_points=0, extent=350.0):
     """prior_map_points > 0: the same registration against a LARGE seeded prior map (scenes.scene_prior_map: the regime of the reference's
     published timings, 1-10 k-point frames against 53-241 M-point maps) - map upload + index build reported beside it, once.
     What the reference itself times (icp_test_runner.cpp:442-461; paper tables 6 / 7: Parking Lot 2.11 ms per registration on 1-10 k-point
@@ -574,7 +577,7 @@ def c3_registration(D, args, repeats=20, prior_map_points=0):
     import dcreg_amd
     from dcreg_amd import api, scenes as h
     t_gen = time.perf_counter()
-    tgt, src = h.scene_prior_map(prior_map_points) if prior_map_points else h.scene_parkinglot()
+    tgt, src = h.scene_prior_map(prior_map_points, extent=extent) if prior_map_points else h.scene_parkinglot()
     t_gen = time.perf_counter() - t_gen
     gt, T0 = h.pose6d_matrix(**h.PK01_GT), h.pose6d_matrix(**h.PK01_INIT)
     ctx = dcreg_amd.Context(D.local_rank)
@@ -589,14 +592,18 @@ def c3_registration(D, args, repeats=20, prior_map_points=0):
                              CONVERGENCE_THRESH_TRANS=1e-3, use_weight_derivative=0, always_compute_schur=1, gt_matrix=gt.reshape(16))
     t_src, t_tot, its = [], [], []
     res = None
+    t_first = 0.0
     for rep in range(repeats + 3):
         ta = time.perf_counter()
         ctx.set_source(src)
         tb = time.perf_counter()
         res, _ = ctx.icp_run(T0, args.method, cfg, log_capacity=0)
         tc = time.perf_counter()
+        if rep == 0:
+            t_first = tc - ta
         if rep >= 3:
             t_src.append(tb - ta); t_tot.append(tc - ta); its.append(res.iterations)
+    roi = ctx.roi_info()
     # one more registration, logged (untimed): which launches ran the small-frame pass, and what they searched
     ctx.set_option("record_launches", 1)
     ctx.launch_series(reset=True)
@@ -618,8 +625,14 @@ def c3_registration(D, args, repeats=20, prior_map_points=0):
            "trans_error_vs_gt_m": float(te), "rot_error_vs_gt_deg": float(re_), "repeats": repeats,
            "workload": "%s: %d-pt frame vs %d-pt map, radius 0.5, method %s, thresholds 1e-5 rad / 1e-3 m, init / gt poses of config/icp_pk01.yaml; "
                        "frame from a host buffer every time (dcreg_set_source), map resident" % (
-                           "seeded prior map (scenes.scene_prior_map)" if prior_map_points else "PK01 stand-in", len(src), len(tgt), args.method),
+                           ("seeded prior map (scenes.scene_prior_map, %.0f m x %.0f m)" % (2 * extent, 2 * extent)) if prior_map_points else "PK01 stand-in", len(src), len(tgt), args.method),
            "candidates_per_query": cand,
+           "window_index": {"active": roi["active"], "points": roi["points"], "grid_cell_m": roi["cell"], "windows_built": roi["windows_built"],
+                            "box_min": roi["box_min"], "box_max": roi["box_max"], "whole_map_table_capped": roi["whole_map_capped"],
+                            "ms_first_registration": 1e3 * t_first,
+                            "note": "single-pose linearisations of a map whose dense cell table ran into max_table_entries search an index over the map's points in a box "
+                                    "around the transformed frame (bitwise the whole map's sums); built by the first registration, kept while the pose stays inside; "
+                                    "candidates_per_query above is the WHOLE map's index (debug dumps run there)"},
            "map": {"points": int(len(tgt)), "grid_cell_m": info.cell, "grid_cells": int(info.n_cells), "dims": [int(v) for v in info.dims],
                    "s_set_target_from_host": t_map, "s_scene_generation": t_gen},
            "launch_structure": {"k_lin_alone": int((ser["advanced"] == 0).sum()), "k_advance_team_then_k_lin": int((ser["advanced"] == 2).sum()),
@@ -843,6 +856,8 @@ def main(argv=None):
             sub["c3_pk01_8k_registration"] = c3_registration(D, args)
             if args.prior_map_points > 0:
                 sub["c3_prior_map_50m"] = c3_registration(D, args, repeats=20, prior_map_points=args.prior_map_points)
+            if args.prior_map_points_large > 0:
+                sub["c3_prior_map_200m"] = c3_registration(D, args, repeats=20, prior_map_points=args.prior_map_points_large, extent=700.0)
             usable = hostinfo.usable_cpus()
             sub["c5_montecarlo_5000"]["by_host_threads"] = c5_host_thread_sweep(D, args, sorted({2, 4, min(16, usable)}))
             api.set_host_threads(host_threads)

@@ -131,7 +131,17 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *                   next dcreg_set_target;
  *   "max_table_entries" default 2^30 (at most 2^31): entries of the dense cell table - one uint32 per x sub-cell of the target's
  *                   bounding box; a map whose cells at the wanted edge would need more gets fewer x sub-cells first and a larger cell
- *                   edge after that (next dcreg_set_target).
+ *                   edge after that (next dcreg_set_target);
+ *   "roi_index", "roi_margin": the WINDOW index of a large map.  A map whose table ran into that budget is searched through cells that
+ *                   grow with its extent; dcreg_linearize / the engines' single-pose launches therefore search such a map through a
+ *                   second index over the map's points inside a box around the transformed source cloud (its bounding box at the pose +
+ *                   the search radius + roi_margin metres, default 20) - the same neighbours and bitwise the same sums, cells sized for
+ *                   the local density.  Built by the first linearisation (milliseconds: it reads the whole map once), kept until a
+ *                   pose leaves the box, then rebuilt around that pose (a queued gated launch is called off: dcreg_linearize_gate_open
+ *                   returns DCREG_E_STATE and the caller starts the launch with dcreg_linearize_batch_begin, as the engines do).
+ *                   roi_index 1 (default) = for maps whose build was cut by the budget, 0 = never, 2 = always.  dcreg_knn,
+ *                   dcreg_p2p_error, batched launches and debug dumps always run on the whole map; dcreg_index_info_get describes
+ *                   the whole map's index (dcreg_debug.h dcreg_roi_info: the window).
  * Profiling / experiment knobs are listed in dcreg_debug.h. */
 int dcreg_set_option(dcreg_ctx *, const char *key, double value);
 /* target cloud: copies + builds the device spatial index (stands for kd-tree build, utils.hpp:403).
