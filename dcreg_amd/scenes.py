@@ -198,8 +198,10 @@ def scene_prior_map(n_map=50_000_000, n_frame=8_000, seed=11, extent=350.0, fram
         tgt[i0:i0 + m, 0] = c[0] + gx
         tgt[i0:i0 + m, 1] = c[1] + gy
         tgt[i0:i0 + m, 2] = c[2] - np.float32(1.8) + height(gx, gy) + rng.standard_normal(m, dtype=np.float32) * np.float32(0.01)
-    # facades: 64 vertical planes, 20 - 60 m long, 8 m high, random position / heading (a dozen of them within the frame's range)
-    nf = 64
+    # facades: 64 vertical planes per 700 m x 700 m (the count grows with the map's area, so that a larger map is more of the same map and not
+    # the same facades with more points on each), 20 - 60 m long, 8 m high, random position / heading (a dozen of them within the frame's range)
+    area = max(1.0, (float(extent) / 350.0) ** 2)
+    nf = int(round(64 * area))
     fc = ((rng.random((nf, 2), dtype=np.float32) * 2 - 1) * e * np.float32(0.9))
     fc[:12] = (rng.random((12, 2), dtype=np.float32) * 2 - 1) * np.float32(frame_range * 0.9)
     fh = rng.random(nf, dtype=np.float32) * np.float32(np.pi)
@@ -211,8 +213,8 @@ def scene_prior_map(n_map=50_000_000, n_frame=8_000, seed=11, extent=350.0, fram
     tgt[o:o + n_wall, 0] = c[0] + wx
     tgt[o:o + n_wall, 1] = c[1] + wy
     tgt[o:o + n_wall, 2] = c[2] - np.float32(1.8) + height(wx, wy) + rng.random(n_wall, dtype=np.float32) * np.float32(8.0)
-    # poles: 400 thin vertical cylinders (two dozen within the frame's range)
-    npc = 400
+    # poles: 400 thin vertical cylinders per 700 m x 700 m (two dozen within the frame's range)
+    npc = int(round(400 * area))
     pc = (rng.random((npc, 2), dtype=np.float32) * 2 - 1) * e * np.float32(0.95)
     pc[:24] = (rng.random((24, 2), dtype=np.float32) * 2 - 1) * np.float32(frame_range * 0.9)
     k = rng.integers(0, npc, n_pole)
