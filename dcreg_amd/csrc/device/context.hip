@@ -13,7 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "../../../include/dcreg_debug.h"
 #include "context.hpp"
@@ -316,6 +316,9 @@ static int roi_ensure(dcreg_ctx *c, const double *R, const double *t, double sea
         return DCREG_OK;
     }
     // ---- a new window around this pose
+    const bool roi_timing = std::getenv("DCREG_ROI_TIMING") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (roi_timing) { (void)hipStreamSynchronize(c->stream); auto t1 = std::chrono::steady_clock::now(); std::fprintf(stderr, "[roi] %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tp0).count()); tp0 = t1; } };
     (void)roi_deactivate(c);                                        // the members are the whole map's
     HIP_TRY(c, hipStreamSynchronize(c->stream));                    // (nothing in flight reads the buffers that are about to be replaced)
     double lo[3], hi[3];
@@ -326,36 +329,57 @@ static int roi_ensure(dcreg_ctx *c, const double *R, const double *t, double sea
     }
     c->roi_pad = pad;
     c->roi_built = false; c->roi_empty = false;
+    // the map's points in the box: the x-runs of the whole map's (y,z) rows that cross it - contiguous ranges of its cell-sorted points (every cell
+    // the box touches is taken whole: a few points more than the box holds, all of them the map's), read through the whole map's OWN index,
+    // i.e. a pass over the window and not over the map
     const int64_t n = c->n_tgt;
-    if (ensure(c, c->d_roi_flags, c->roi_flags_cap, (size_t)n)) return DCREG_E_NOMEM;
-    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, sizeof(uint32_t), c->stream));
-    // (the box in floats, rounded outwards: a point the float comparison keeps out is farther than pad from every query)
-    const float fl[3] = {std::nextafterf((float)c->roi_lo[0], -INFINITY), std::nextafterf((float)c->roi_lo[1], -INFINITY), std::nextafterf((float)c->roi_lo[2], -INFINITY)};
-    const float fh[3] = {std::nextafterf((float)c->roi_hi[0], INFINITY), std::nextafterf((float)c->roi_hi[1], INFINITY), std::nextafterf((float)c->roi_hi[2], INFINITY)};
-    hipLaunchKernelGGL(k_roi_flags, dim3(std::min<unsigned>(blocks_for(n, 256), 4096u)), dim3(256), 0, c->stream, c->d_tgt_raw, n, fl[0], fl[1], fl[2], fh[0], fh[1], fh[2],
-                       c->d_roi_flags, c->d_scratch);
+    const GridDev &g = c->grid;
+    int c0[3], c1[3];                                   // cell ranges [c0, c1) of the box in the whole map's grid
+    const double org[3] = {g.ox, g.oy, g.oz};
+    const int dims[3] = {g.nx, g.ny, g.nz};
+    for (int a = 0; a < 3; ++a) {
+        const double f0 = std::floor((c->roi_lo[a] - org[a]) * g.inv_h) - 1.0, f1 = std::floor((c->roi_hi[a] - org[a]) * g.inv_h) + 2.0;    // (one cell of slack: float cell keys)
+        c0[a] = (int)std::min(std::max(f0, 0.0), (double)dims[a]); c1[a] = (int)std::min(std::max(f1, 0.0), (double)dims[a]);
+    }
+    const int ny_box = c1[1] - c0[1], nz_box = c1[2] - c0[2];
+    const int64_t n_rows64 = (int64_t)ny_box * nz_box;
     uint32_t count = 0;
-    HIP_TRY(c, hipMemcpyAsync(&count, c->d_scratch, sizeof(count), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
     c->roi_rebuilds += 1;
-    if (count == 0u || (int64_t)count == n) {        // nothing of the map in the box / all of it: the whole map's index serves inside this box
+    if (c1[0] > c0[0] && n_rows64 > 0 && n_rows64 < ((int64_t)1 << 30)) {
+        const int n_rows = (int)n_rows64, nxs = g.nx * g.sx, x0s = c0[0] * g.sx, x1s = c1[0] * g.sx;
+        if (ensure(c, c->d_vals, c->vals_cap, (size_t)n_rows) || ensure(c, c->d_vals2, c->vals2_cap, (size_t)n_rows)) return DCREG_E_NOMEM;
+        hipLaunchKernelGGL(k_roi_rows, dim3(blocks_for(n_rows, 256)), dim3(256), 0, c->stream, g.cell_start, nxs, g.ny, x0s, x1s, c0[1], ny_box, c0[2], n_rows, c->d_vals);
+        size_t tmp = 0;
+        HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp, c->d_vals, c->d_vals2, 0u, (size_t)n_rows, rocprim::plus<uint32_t>(), c->stream));
+        if (ensure(c, c->sort_tmp, c->sort_tmp_cap, tmp) != DCREG_OK) return DCREG_E_NOMEM;
+        HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp, tmp, c->d_vals, c->d_vals2, 0u, (size_t)n_rows, rocprim::plus<uint32_t>(), c->stream));
+        uint32_t last[2] = {0u, 0u};
+        HIP_TRY(c, hipMemcpyAsync(&last[0], c->d_vals + (n_rows - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&last[1], c->d_vals2 + (n_rows - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        count = last[0] + last[1];
+        if (count != 0u && (int64_t)count < n) {
+            dcreg_ctx::IndexSet &s = c->roi_store;
+            if (ensure(c, s.raw, s.raw_cap, (size_t)count)) return DCREG_E_NOMEM;
+            hipLaunchKernelGGL(k_roi_copy, dim3((unsigned)n_rows), dim3(256), 0, c->stream, g.pts, g.cell_start, nxs, g.ny, x0s, x1s, c0[1], ny_box, c0[2], c->d_vals2, s.raw);
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
+    if (count == 0u || (int64_t)count >= n) {        // nothing of the map in the box / all of it: the whole map's index serves inside this box
         c->roi_built = true; c->roi_empty = true;
         return DCREG_OK;
     }
     dcreg_ctx::IndexSet &s = c->roi_store;
-    if (ensure(c, s.raw, s.raw_cap, (size_t)count)) return DCREG_E_NOMEM;
-    {   // the points of the box in the map's order (stable: ties and the plane fit's row order are decided by the original index anyway)
-        size_t tmp = 0;
-        HIP_TRY(c, rocprim::select(nullptr, tmp, c->d_tgt_raw, c->d_roi_flags, s.raw, c->d_scratch + 8, (size_t)n, c->stream));
-        if (ensure(c, c->sort_tmp, c->sort_tmp_cap, tmp) != DCREG_OK) return DCREG_E_NOMEM;
-        HIP_TRY(c, rocprim::select(c->sort_tmp, tmp, c->d_tgt_raw, c->d_roi_flags, s.raw, c->d_scratch + 8, (size_t)n, c->stream));
-    }
     s.n = (int64_t)count;
+    lap("extract");
     swap_index(c);                                                  // the members are the window's now (its buffers of the last build are reused)
     int rc = build_index(c, target_dst(c), c->radius_hint * (1.0 + c->opt_cert_margin), &c->occupied_cells);
+    lap("build_index");
     if (rc == DCREG_OK) rc = build_gap_field(c, c->radius_hint * (1.0 + c->opt_cert_margin));
+    lap("gap_field");
     if (rc == DCREG_OK) rc = build_row_words(c);
+    lap("row_words");
     if (rc != DCREG_OK) { swap_index(c); return rc; }               // (the whole map stays usable)
     c->roi_built = true;
     return DCREG_OK;
@@ -1310,7 +1334,7 @@ void dcreg_backend_destroy(dcreg_ctx *c) {
     void *bufs[] = {c->d_tgt_raw, c->d_tgt, c->d_src_raw, c->d_src, c->d_stage, c->d_keys, c->d_keys2, c->d_vals, c->d_vals2,
                     c->d_mkeys, c->d_mkeys2, c->d_cell_start, c->d_scratch, c->sort_tmp,
                     c->d_nn_idx, c->d_nn_d2, c->d_p2p_part, c->d_aligned, c->d_aux, c->d_aux_cell_start, c->d_state, c->d_state_batch, c->d_search_count, c->d_gap, c->d_ymask, c->d_owner,
-                    c->d_adv_counts, c->d_team_stamps, c->d_roi_flags, c->roi_store.raw, c->roi_store.sorted, c->roi_store.cell_start, c->roi_store.gap,
+                    c->d_adv_counts, c->d_team_stamps, c->roi_store.raw, c->roi_store.sorted, c->roi_store.cell_start, c->roi_store.gap,
                     c->roi_store.owner, c->roi_store.ymask};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (LinSlot &S : c->slots) {

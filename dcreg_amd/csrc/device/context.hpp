@@ -86,7 +86,6 @@ struct dcreg_ctx {
     double roi_lo[3] = {}, roi_hi[3] = {}, roi_pad = 0.0;
     double src_mn[3] = {}, src_mx[3] = {};      // bounding box of the source in the body frame (dcreg_set_source)
     int64_t roi_rebuilds = 0;
-    uint8_t *d_roi_flags = nullptr; size_t roi_flags_cap = 0;
 
     // auxiliary grid over the body-frame source (backward pass of dcreg_p2p_error)
     float4 *d_aux = nullptr; size_t aux_cap = 0;

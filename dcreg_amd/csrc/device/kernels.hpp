@@ -1272,22 +1272,22 @@ __host__ __device__ inline float ord2f(uint32_t o) {
     union { uint32_t u; float f; } cv; cv.u = u; return cv.f;
 }
 
-// the window index of a large map (context.hip roi_ensure): flag[i] = point i lies inside the box, *count += the flags (one atomic per block)
-static __global__ __launch_bounds__(256) void k_roi_flags(const float4 *__restrict__ p, int64_t n, float lx, float ly, float lz, float hx, float hy, float hz,
-                                                         uint8_t *__restrict__ flag, uint32_t *__restrict__ count) {
-    __shared__ uint32_t s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0u;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 q = p[i];
-        const bool in = q.x >= lx && q.x <= hx && q.y >= ly && q.y <= hy && q.z >= lz && q.z <= hz;
-        flag[i] = in ? (uint8_t)1 : (uint8_t)0;
-        mine += in ? 1u : 0u;
-    }
-    if (mine) atomicAdd(&s_cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(count, s_cnt);
+// the window index of a large map (context.hip roi_ensure): the map's points in the cells [x0, x1) x [y0, y0 + ny_box) x [z0, ..) of the WHOLE
+// map's index are the x-runs of n_rows (y,z) rows - contiguous ranges of the cell-sorted points.  k_roi_rows: their lengths;
+// k_roi_copy (one block per row): the runs one after the other into the window's raw cloud (the points keep their original index in w).
+static __global__ void k_roi_rows(const uint32_t *__restrict__ cell_start, int nxs, int ny, int x0s, int x1s, int y0, int ny_box, int z0, int n_rows,
+                                  uint32_t *__restrict__ len) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const size_t row = ((size_t)(z0 + r / ny_box) * (size_t)ny + (size_t)(y0 + r % ny_box)) * (size_t)nxs;
+    len[r] = cell_start[row + (size_t)x1s] - cell_start[row + (size_t)x0s];
+}
+static __global__ __launch_bounds__(256) void k_roi_copy(const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start, int nxs, int ny, int x0s, int x1s,
+                                                        int y0, int ny_box, int z0, const uint32_t *__restrict__ off, float4 *__restrict__ out) {
+    const int r = blockIdx.x;
+    const size_t row = ((size_t)(z0 + r / ny_box) * (size_t)ny + (size_t)(y0 + r % ny_box)) * (size_t)nxs;
+    const uint32_t s = cell_start[row + (size_t)x0s], n = cell_start[row + (size_t)x1s] - s, o = off[r];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[(size_t)o + i] = pts[(size_t)s + i];
 }
 
 // bounds[0..2] = min (ordered-uint), bounds[3..5] = max

@@ -35,6 +35,14 @@ for opts in sets:
             t_first = time.perf_counter() - ta
         if rep >= 3:
             tt.append(time.perf_counter() - ta); its.append(res.iterations)
+    # a pose 40 m on (and back): what a new window costs once the buffers exist
+    t_win = []
+    for dx in (40.0, 0.0, 40.0, 0.0):
+        Tm = T0.copy(); Tm[0, 3] += dx
+        ta = time.perf_counter()
+        ctx.linearize(Tm[:3, :3], Tm[:3, 3], api.default_lin_params(0.5, 0))
+        t_win.append(1e3 * (time.perf_counter() - ta))
+    print("    linearisations 40 m on / back / on / back (each builds a window where one is in use): %s ms" % " ".join("%.1f" % v for v in t_win), flush=True)
     roi = ctx.roi_info()
     print("    first registration %.1f ms (incl. the window build where one is built); window: %s" % (1e3 * t_first, roi), flush=True)
     ctx.set_option("record_launches", 1); ctx.set_option("time_kernels", 1); ctx.launch_series(reset=True)
