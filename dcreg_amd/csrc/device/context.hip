@@ -316,9 +316,6 @@ static int roi_ensure(dcreg_ctx *c, const double *R, const double *t, double sea
         return DCREG_OK;
     }
     // ---- a new window around this pose
-    const bool roi_timing = std::getenv("DCREG_ROI_TIMING") != nullptr;
-    auto tp0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) { if (roi_timing) { (void)hipStreamSynchronize(c->stream); auto t1 = std::chrono::steady_clock::now(); std::fprintf(stderr, "[roi] %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tp0).count()); tp0 = t1; } };
     (void)roi_deactivate(c);                                        // the members are the whole map's
     HIP_TRY(c, hipStreamSynchronize(c->stream));                    // (nothing in flight reads the buffers that are about to be replaced)
     double lo[3], hi[3];
@@ -372,14 +369,10 @@ static int roi_ensure(dcreg_ctx *c, const double *R, const double *t, double sea
     }
     dcreg_ctx::IndexSet &s = c->roi_store;
     s.n = (int64_t)count;
-    lap("extract");
     swap_index(c);                                                  // the members are the window's now (its buffers of the last build are reused)
     int rc = build_index(c, target_dst(c), c->radius_hint * (1.0 + c->opt_cert_margin), &c->occupied_cells);
-    lap("build_index");
     if (rc == DCREG_OK) rc = build_gap_field(c, c->radius_hint * (1.0 + c->opt_cert_margin));
-    lap("gap_field");
     if (rc == DCREG_OK) rc = build_row_words(c);
-    lap("row_words");
     if (rc != DCREG_OK) { swap_index(c); return rc; }               // (the whole map stays usable)
     c->roi_built = true;
     return DCREG_OK;

@@ -136,7 +136,7 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *                   grow with its extent; dcreg_linearize / the engines' single-pose launches therefore search such a map through a
  *                   second index over the map's points inside a box around the transformed source cloud (its bounding box at the pose +
  *                   the search radius + roi_margin metres, default 20) - the same neighbours and bitwise the same sums, cells sized for
- *                   the local density.  Built by the first linearisation (milliseconds: it reads the whole map once), kept until a
+ *                   the local density.  Built by the first linearisation (about 4 ms, whatever the map's size), kept until a
  *                   pose leaves the box, then rebuilt around that pose (a queued gated launch is called off: dcreg_linearize_gate_open
  *                   returns DCREG_E_STATE and the caller starts the launch with dcreg_linearize_batch_begin, as the engines do).
  *                   roi_index 1 (default) = for maps whose build was cut by the budget, 0 = never, 2 = always.  dcreg_knn,
