@@ -810,27 +810,42 @@ def main(argv=None):
         D.close()
         return
 
+    # Everything below is reported BESIDE the headline: a leg that fails (a timeout, a device error in a side workload) is written into the
+    # line as {"error": ...} and never takes the headline measured above with it.
+    side_errors = {}
+
+    def guard(name, fn, *a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:           # noqa: BLE001 - whatever a side leg raises is reported, not propagated
+            side_errors[name] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            return {"error": side_errors[name]}
+
     regimes = conv = cold = None
     if not P.mc and not P.by_points and n_gpus == 1 and not args.no_regimes:
-        regimes = regime_probe(P)
-        conv = converged_run(P, D)
-        cold = converged_run(P, D, cold=True)
+        regimes = guard("roofline_by_regime", regime_probe, P)
+        conv = guard("converged_run", converged_run, P, D)
+        cold = guard("cold_run", lambda: converged_run(P, D, cold=True))
+
+    # final statistics gather (the only collective): per-rank pose error / rmse / correspondences after one whole run
+    try:
+        P._restart()
+        if not P.mc:
+            P.run_steps(WORKLOADS[args.workload]["run_len"])
+        T_fin = np.eye(4); T_fin[:3, :3] = np.array(P.res.R[:]).reshape(3, 3); T_fin[:3, 3] = P.res.t[:]
+        gt = h.pose6d_matrix(**h.PK01_GT) if WORKLOADS[args.workload]["scene"] == "parkinglot" else np.eye(4)
+        te, re_ = api.pose_error(gt, T_fin)
+        last = P.ctx.linearize(T_fin[:3, :3], T_fin[:3, 3], api.default_lin_params(WORKLOADS[args.workload]["radius"], WORKLOADS[args.workload]["wd"]))
+        mine = [te, re_, float(last["n_eff"]), float(100 + D.rank)]
+    except Exception as e:               # noqa: BLE001 - every rank still takes part in the gather
+        side_errors["final_stats"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        mine = [float("nan"), float("nan"), float("nan"), float(100 + D.rank)]
+    recs = D.gather_rows(mine)
 
     conc = None
     if args.concurrent_pairs > 1 and not P.mc and not P.by_points and n_gpus == 1:
         run_len = WORKLOADS[args.workload]["run_len"]
-        conc = concurrent_pairs(P, D, args, steps=2 * run_len, warmup=run_len)
-        P._restart()
-
-    # final statistics gather (the only collective): per-rank pose error / rmse / correspondences after one whole run
-    P._restart()
-    if not P.mc:
-        P.run_steps(WORKLOADS[args.workload]["run_len"])
-    T_fin = np.eye(4); T_fin[:3, :3] = np.array(P.res.R[:]).reshape(3, 3); T_fin[:3, 3] = P.res.t[:]
-    gt = h.pose6d_matrix(**h.PK01_GT) if WORKLOADS[args.workload]["scene"] == "parkinglot" else np.eye(4)
-    te, re_ = api.pose_error(gt, T_fin)
-    last = P.ctx.linearize(T_fin[:3, :3], T_fin[:3, 3], api.default_lin_params(WORKLOADS[args.workload]["radius"], WORKLOADS[args.workload]["wd"]))
-    recs = D.gather_rows([te, re_, float(last["n_eff"]), float(100 + D.rank)])
+        conc = guard("concurrent_pairs", concurrent_pairs, P, D, args, steps=2 * run_len, warmup=run_len)
 
     sub = {}
     if not args.no_configs and args.sharding == "pairs":
@@ -842,24 +857,31 @@ def main(argv=None):
                 continue                        # N > 1: only the experiment that is sharded over the ranks (strong scaling) - as a job
                                                 # of its own once this one's ranks are through (montecarlo_child, below)
             w = WORKLOADS[name]
-            Q = Pair(name, D, args, seed=100)
-            k = 1 if mc else w["run_len"] * 2
-            mq = measure(Q, D, steps=k, warmup=1 if mc else w["run_len"], repeats=5)
-            sub[name] = summarize(name, Q, D, mq, k, n_gpus)
-            sub[name]["host_threads_per_rank"] = host_threads
-            if n_gpus == 1 and not mc and not args.no_regimes:
-                sub[name]["roofline_by_regime"] = regime_probe(Q, runs=4)
-                sub[name]["converged_run"] = converged_run(Q, D, repeats=5)
-                sub[name]["cold_run"] = converged_run(Q, D, repeats=5, cold=True)
-            Q.close()
+
+            def one_config(name=name, w=w, mc=mc):
+                Q = Pair(name, D, args, seed=100)
+                try:
+                    k = 1 if mc else w["run_len"] * 2
+                    mq = measure(Q, D, steps=k, warmup=1 if mc else w["run_len"], repeats=5)
+                    rec = summarize(name, Q, D, mq, k, n_gpus)
+                    rec["host_threads_per_rank"] = host_threads
+                    if n_gpus == 1 and not mc and not args.no_regimes:
+                        rec["roofline_by_regime"] = regime_probe(Q, runs=4)
+                        rec["converged_run"] = converged_run(Q, D, repeats=5)
+                        rec["cold_run"] = converged_run(Q, D, repeats=5, cold=True)
+                    return rec
+                finally:
+                    Q.close()
+            sub[name] = guard(name, one_config)
         if n_gpus == 1:
-            sub["c3_pk01_8k_registration"] = c3_registration(D, args)
+            sub["c3_pk01_8k_registration"] = guard("c3_pk01_8k_registration", c3_registration, D, args)
             if args.prior_map_points > 0:
-                sub["c3_prior_map_50m"] = c3_registration(D, args, repeats=20, prior_map_points=args.prior_map_points)
+                sub["c3_prior_map_50m"] = guard("c3_prior_map_50m", c3_registration, D, args, repeats=20, prior_map_points=args.prior_map_points)
             if args.prior_map_points_large > 0:
-                sub["c3_prior_map_200m"] = c3_registration(D, args, repeats=20, prior_map_points=args.prior_map_points_large, extent=700.0)
+                sub["c3_prior_map_200m"] = guard("c3_prior_map_200m", c3_registration, D, args, repeats=20, prior_map_points=args.prior_map_points_large, extent=700.0)
             usable = hostinfo.usable_cpus()
-            sub["c5_montecarlo_5000"]["by_host_threads"] = c5_host_thread_sweep(D, args, sorted({2, 4, min(16, usable)}))
+            if "error" not in sub.get("c5_montecarlo_5000", {"error": 1}):
+                sub["c5_montecarlo_5000"]["by_host_threads"] = guard("c5_by_host_threads", c5_host_thread_sweep, D, args, sorted({2, 4, min(16, usable)}))
             api.set_host_threads(host_threads)
 
     if n_gpus > 1:
@@ -901,7 +923,9 @@ def main(argv=None):
         if sub:
             result["configs"] = sub
         if n_gpus == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(P.tgt, P.src, P.T_init, WORKLOADS[args.workload], args.method, args.cpu_seconds)
+            result["cpu_baseline"] = guard("cpu_baseline", cpu_baseline, P.tgt, P.src, P.T_init, WORKLOADS[args.workload], args.method, args.cpu_seconds)
+        if side_errors:
+            result["side_leg_errors"] = side_errors
         result["host_threads"] = host_threads
         print(json.dumps(result), flush=True)
     if n_gpus == 1:
