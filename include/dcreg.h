@@ -139,7 +139,7 @@ int dcreg_set_stream(dcreg_ctx *, void *hip_stream);
  *                   the local density.  Built by the first linearisation (about 4 ms, whatever the map's size), kept until a
  *                   pose leaves the box, then rebuilt around that pose (a queued gated launch is called off: dcreg_linearize_gate_open
  *                   returns DCREG_E_STATE and the caller starts the launch with dcreg_linearize_batch_begin, as the engines do).
- *                   roi_index 1 (default) = for maps whose build was cut by the budget, 0 = never, 2 = always.  dcreg_knn,
+ *                   roi_index 1 (default) = for maps whose cell edge the budget enlarged by more than one step (x 1.26) or whose x sub-cells it took, 0 = never, 2 = always.  dcreg_knn,
  *                   dcreg_p2p_error, batched launches and debug dumps always run on the whole map; dcreg_index_info_get describes
  *                   the whole map's index (dcreg_debug.h dcreg_roi_info: the window).
  * Profiling / experiment knobs are listed in dcreg_debug.h. */

@@ -70,7 +70,7 @@ int dcreg_launch_series_passes(dcreg_ctx *, uint8_t *advanced, int64_t cap);
  * returns the number of blocks of that launch.  Waits for the stream. */
 int dcreg_team_pass_stamps(dcreg_ctx *, uint64_t *out, int64_t cap_blocks);
 
-/* The window index of a large map (options "roi_index" 0 never / 1 when the whole map's cell table ran into "max_table_entries" (default) /
+/* The window index of a large map (options "roi_index" 0 never / 1 when "max_table_entries" enlarged the whole map's cell edge by more than one step or took its x sub-cells (default) /
  * 2 always, "roi_margin" metres, default 20): single-pose linearisations of such a map search an index over the map's points inside a box
  * around the transformed source - same neighbours, same sums (bitwise), cells sized for the local density instead of the map's extent;
  * everything else (dcreg_knn, dcreg_p2p_error, batches, dumps) runs on the whole map.  info[0..5] = the box (min xyz, max xyz),
