@@ -3,7 +3,10 @@
   * dcreg_reset_warm_state(ctx, -1) drops the context's own neighbour state: the next run is bitwise the run of a fresh context (the
     reference's fresh ICPContext per run, icp_test_runner.cpp:408-409 - what bench.py's `cold_run` times);
   * small frames from host buffers go through the context's pinned block: the caller's buffer may be overwritten as soon as
-    dcreg_set_source returns."""
+    dcreg_set_source returns;
+  * the linearisation kernel in one-wave blocks, the Monte-Carlo job, the 5 M-point prior map against the oracle;
+  * the WINDOW index of a large map (context.hpp): bitwise invisible - walks in and out of the window, whole pipelined runs incl. one whose
+    every pose leaves the window, k-NN / metrics / batches on the whole map - and engaged by itself when the table budget binds."""
 import numpy as np
 import pytest
 
